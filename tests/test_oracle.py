@@ -1,0 +1,144 @@
+"""Pin the CPU oracle against golden vectors generated from the reference
+(tests/golden/make_golden.py) and cross-check torch CPU ops against the
+independent numpy restatements.  CPU only."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import w2l_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=True)
+
+
+def meta_of(z):
+    return ast.literal_eval(str(z['meta']))
+
+
+def sd_from(z, prefix='p0/'):
+    return {k[len(prefix):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize('case', ['w2l_ml1', 'w2l_ml3', 'w2l_mix5'])
+def test_w2l_end_to_end_matches_reference(case):
+    z = load(case + '.npz')
+    meta = meta_of(z)
+    layers = [(l['output_size'], l['kernel_size'], l['stride'], l['dilation'], 0.0) for l in meta['layers']]
+    sd = sd_from(z)
+    res = O.wav2letter_step(torch.from_numpy(z['x']), torch.from_numpy(z['in_lens']), torch.from_numpy(z['targets']),
+                            torch.from_numpy(z['target_lens']), sd, layers, want_input_grad=True)
+    np.testing.assert_allclose(res['log_probs'].numpy(), z['log_probs'], rtol=1e-5, atol=1e-5)
+    assert abs(float(res['loss']) - float(z['loss'])) < 1e-4 * max(1.0, abs(float(z['loss'])))
+    np.testing.assert_array_equal(res['out_lens'].numpy(), z['out_lens'])
+    np.testing.assert_allclose(res['input_grad'].numpy(), z['input_grad'], rtol=1e-4, atol=1e-6)
+    for k, g in res['grads'].items():
+        ref = z['g/' + k]
+        scale = max(np.abs(ref).max(), 1e-6)
+        assert np.abs(g.numpy() - ref).max() <= 2e-4 * scale + 2e-5, k
+    for k in z.files:
+        if k.startswith('p1/'):
+            np.testing.assert_allclose(sd[k[3:]].numpy(), z[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    # greedy decode + metrics
+    idx = O.argmax_lowest(res['log_probs'].numpy())
+    np.testing.assert_array_equal(idx, z['argmax'])
+    strings = O.greedy_strings(idx, z['out_lens'], O.ENGLISH_LOWERCASE)
+    assert strings == list(z['decoded'])
+    cs = [O.cer_ratio(e, p) for e, p in zip(z['texts'], strings)]
+    ws = [O.wer_ratio(e, p) for e, p in zip(z['texts'], strings)]
+    assert abs(sum(c[0] for c in cs) / sum(c[1] for c in cs) - float(z['cer'])) < 1e-12
+    assert abs(sum(w[0] for w in ws) / sum(w[1] for w in ws) - float(z['wer'])) < 1e-12
+    # eval mode (running stats)
+    lp_eval, _ = O.wav2letter_forward(torch.from_numpy(z['x']), sd, layers, training=False)
+    np.testing.assert_allclose(lp_eval.numpy(), z['out_eval'], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('case', ['jasper_sep2', 'jasper_dense'])
+def test_jasper_end_to_end_matches_reference(case):
+    z = load(case + '.npz')
+    meta = meta_of(z)
+    sd = sd_from(z)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if v.dtype.is_floating_point and 'running_' not in k}
+    work = dict(sd)
+    work.update(params)
+    x = torch.from_numpy(z['x']).requires_grad_(True)
+    lp, out_lens = O.jasper_forward(x, torch.from_numpy(z['in_lens']), work, meta['blocks'], training=True)
+    np.testing.assert_allclose(lp.detach().numpy(), z['log_probs'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(out_lens.numpy(), z['out_lens'])
+    loss = O.ctc_criterion(lp, torch.from_numpy(z['targets']), out_lens, torch.from_numpy(z['target_lens']))
+    assert abs(float(loss) - float(z['loss'])) < 1e-4 * max(1.0, abs(float(z['loss'])))
+    loss.backward()
+    for k, p in params.items():
+        ref = z['g/' + k]
+        assert np.abs(p.grad.numpy() - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-6) + 2e-5, k
+    for k in z.files:
+        if k.startswith('p1/'):
+            np.testing.assert_allclose(work[k[3:]].numpy(), z[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    out_eval, _ = O.jasper_forward(torch.from_numpy(z['x']), torch.from_numpy(z['in_lens']), work, meta['blocks'],
+                                   training=False)
+    np.testing.assert_allclose(out_eval.detach().numpy(), z['out_eval'], rtol=1e-4, atol=1e-5)
+
+
+def test_conv1dblock_ops_numpy_restatement():
+    z = load('ops_conv1dblock.npz')
+    for tag in ['asym_s2', 'dil2', 'k1', 'even_k13']:
+        cin, cout, k, s, d, T = [int(v) for v in z[f'{tag}/cfg']]
+        pl, pr = O.conv1d_block_padding(cin, k, s, d)
+        assert (pl, pr) == tuple(int(v) for v in z[f'{tag}/pad'])
+        x = z[f'{tag}/x']
+        w, b = z[f'{tag}/p/conv1.weight'], z[f'{tag}/p/conv1.bias']
+        y = O.np_conv1d(O.np_reflect_pad(x, pl, pr), w, b, s, d)
+        ybn, m, v, vu = O.np_batch_norm_train(y, z[f'{tag}/p/batch_norm.weight'], z[f'{tag}/p/batch_norm.bias'], 1e-3)
+        out = np.clip(ybn, 0, 20)
+        np.testing.assert_allclose(out, z[f'{tag}/y'], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(0.1 * 0 + 0.9 * m, z[f'{tag}/running_mean'], rtol=1e-4, atol=1e-5)   # momentum .9
+        np.testing.assert_allclose(0.1 * 1 + 0.9 * vu, z[f'{tag}/running_var'], rtol=1e-4, atol=1e-5)
+        # and the torch-composed oracle block
+        sd = {'conv1.weight': torch.from_numpy(w), 'conv1.bias': torch.from_numpy(b),
+              'batch_norm.weight': torch.from_numpy(z[f'{tag}/p/batch_norm.weight']),
+              'batch_norm.bias': torch.from_numpy(z[f'{tag}/p/batch_norm.bias']),
+              'batch_norm.running_mean': torch.zeros(cout), 'batch_norm.running_var': torch.ones(cout)}
+        yt = O.conv1d_block_forward(torch.from_numpy(x), sd, '', stride=s, dilation=d, bn=True, activation=True,
+                                    training=True)
+        np.testing.assert_allclose(yt.numpy(), z[f'{tag}/y'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(z['clamp/grad'], [0, 1, 1, 1, 0])      # closed interval
+
+
+def test_ctc_numpy_matches_reference_criterion():
+    z = load('ctc_cases.npz')
+    loss, nll, grad = O.np_ctc_mean(z['log_probs'], z['targets'], z['in_lens'], z['target_lens'])
+    assert abs(loss - float(z['loss'])) < 1e-4
+    np.testing.assert_allclose(nll, z['nll'], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(grad, z['grad'], rtol=1e-4, atol=1e-6)
+    assert nll[3] == 0 and nll[5] == 0          # zero_infinity cases
+    assert np.all(grad[1, 33:] == 0)            # t >= input length
+
+
+def test_greedy_known_answers():
+    z = load('greedy_cases.npz')
+    labels = list(z['labels'])
+    idx = O.argmax_lowest(z['probs'])
+    np.testing.assert_array_equal(idx, z['argmax'])
+    assert O.greedy_strings(idx, z['sizes'], labels) == list(z['strings'])
+    # unit_tests/decoder_test.py:40-42
+    small = O.greedy_strings(O.argmax_lowest(np.array([[[0.8, 0.2, 0, 0], [0.6, 0.4, 0, 0]]])), None,
+                             ['_', 'A', 'B', ' '])
+    assert small == [''] == list(z['small'])
+    for (a, b), c, w in zip(z['pairs'], z['cer'], z['wer']):
+        assert O.cer_ratio(str(a), str(b)) == tuple(c)
+        assert O.wer_ratio(str(a), str(b)) == tuple(w)
+
+
+def test_padding_rule_full_table():
+    cin = 64
+    pads = []
+    for (c, k, s, d, _) in O.W2L_LAYERS:
+        pads.append(sum(O.conv1d_block_padding(cin, k, s, d)))
+        cin = c
+    assert pads == [9, 10, 10, 10, 12, 12, 12, 16, 16, 16, 20, 20, 20, 24, 24, 24, 56, 56, 56, 0]
