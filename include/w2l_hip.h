@@ -1,0 +1,159 @@
+/*
+ * w2l_hip.h -- C ABI of libw2l_hip.so: the MI355X (gfx950) kernels under the
+ * Wav2Letter / Jasper forward + CTC + backward training step.
+ *
+ * The reference (assafmu/wav2letter_pytorch) is 100% Python and has no native
+ * interface of its own; every entry point below replaces the torch ATen op the
+ * reference calls at the cited site.  A binding only needs plain pointers and
+ * sizes (ctypes stub: wav2letter_pytorch_amd/_lib.py).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - activations are channels-last "NTC" [N][rows][C] with C the padded channel
+ *     count (multiple of 64, pad channels are zero); bf16 unless stated;
+ *   - `stream` is a hipStream_t passed as void*; all launches are asynchronous on
+ *     it, nothing synchronises, nothing is allocated or freed;
+ *   - return 0 on success, otherwise a hipError_t / 1 for bad arguments, with a
+ *     message retrievable through w2l_last_error() (thread-local);
+ *   - re-entrant: may be called concurrently from the Python main thread
+ *     (forward) and autograd worker threads (backward).
+ */
+#ifndef W2L_HIP_H
+#define W2L_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* w2l_last_error(void);
+int w2l_abi_version(void);
+
+/* ---- layout / packing ---------------------------------------------------- */
+
+/* fp32 weights w[co][ci][kw] (arbitrary element strides) ->
+ *   w_fwd  [Kw][CoutP][CinP] bf16 (hi, and lo = residual if w_fwd_lo != NULL)
+ *   w_dgr  [Kw][CinP][CoutP] bf16 with taps flipped: w_dgr[k][ci][co] = w[co][ci][Kw-1-k]
+ * pad rows/cols are zero.  Replaces nothing in the reference; it is the operand
+ * layout for nn.Conv1d (wav2letter.py:35-36, jasper.py:96-105). */
+int w2l_pack_weights(const float* w, int64_t s_co, int64_t s_ci, int64_t s_kw, int Cout, int Cin, int Kw,
+                     int CoutP, int CinP, void* w_fwd_hi, void* w_fwd_lo, void* w_dgr_hi, void* w_dgr_lo,
+                     void* stream);
+
+/* input spectrogram fp32 [N][C][T] -> padded NTC bf16 [N][pad_l+T+pad_r][CP];
+ * pad_mode 1 = reflect (nn.ReflectionPad1d, wav2letter.py:28-34,41), 0 = zeros
+ * (Conv1d padding=, jasper.py:96-105).  lens (optional, [N] int32): rows t >= lens[n]
+ * are zeroed first (MaskedConv1d, jasper.py:114-119). */
+int w2l_nct_to_ntc(const float* x, int N, int C, int T, int CP, int pad_l, int pad_r, int pad_mode,
+                   const int32_t* lens, void* out_hi, void* out_lo, void* stream);
+
+/* fp32 dense [N][T][C] -> zero-haloed bf16 [N][halo_b+T+halo_a][CP] (+ optional lo), and per-channel
+ * column sums colsum[CP] (bias gradient of an un-normalised conv: the 1x1 classifier,
+ * wav2letter.py:69, jasper.py:432-433). */
+int w2l_pad_cast(const float* g, int N, int T, int C, int CP, int halo_b, int halo_a, void* out_hi, void* out_lo,
+                 float* colsum, void* stream);
+
+/* ---- Conv1d as implicit GEMM on MFMA (nn.Conv1d fwd: wav2letter.py:42, jasper.py:127;
+ *      its dgrad: autograd of the same call sites) ---------------------------------
+ * y[n][t][co] (+)= bias[co] + sum_{kw,ci} w[kw][co][ci] * xp[n][t*stride + kw*dil][ci]
+ * xp is a physically padded buffer (reflect or zero halo written by the producer);
+ * x_rows_total = number of rows of Cin elements readable from xp (reads are clamped).
+ * y is dense [N][Tout][Cout] bf16 (y_f32=0) or fp32 (y_f32=1; accumulate=1 adds to y).
+ * stats_partial (optional) [w2l_conv_stat_tiles(N,Tout)][2][Cout]: per column-tile sums of y
+ * and y^2 over valid t (BatchNorm batch statistics, wav2letter.py:37,43).
+ * dgrad = the same call with xp := zero-haloed dy, w := w_dgr, Cin<->Cout, stride 1. */
+int w2l_conv_stat_tiles(int N, int Tout);
+int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y, int y_f32,
+                     int accumulate, const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout,
+                     int Kw, int stride, int dil, void* stream);
+
+/* Conv1d weight gradient (autograd of the same call sites):
+ * dw[kw][co][ci] (+)= sum_{n,t} dy[n][t][co] * xp[n][t*stride + kw*dil][ci]
+ * dy: zero-haloed bf16, pointer at valid row 0, rows [Tout, roundup(Tout,64)) must be zero.
+ * dw fp32 [Kw][Cout][Cin].  accumulate=1 adds to dw (fp32 atomics).  With accumulate=0 the
+ * library may still split the (n,t) reduction over blocks and combine with atomics: when
+ * w2l_wgrad_needs_zero() != 0 the caller must zero-fill dw first. */
+int w2l_wgrad_needs_zero(int N, int Cin, int Cout, int Tout, int Kw);
+int w2l_conv1d_wgrad(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride, int64_t x_rows_total,
+                     float* dw, int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int accumulate,
+                     void* stream);
+
+/* ---- BatchNorm1d + Dropout + activation (wav2letter.py:43-46, jasper.py:363,376,448) ---- */
+
+/* partial [ntiles][2][C] -> batch mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale;
+ * running stats updated with the UNBIASED variance: r = (1-momentum)*r + momentum*batch.
+ * If partial == NULL (eval mode) scale/shift come from the running stats. */
+int w2l_bn_finalize(const float* partial, int ntiles, int C, int64_t count, const float* gamma, const float* beta,
+                    float eps, float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                    float* scale, float* shift, void* stream);
+
+typedef struct {
+    int32_t N, T, C;        /* valid rows per utterance; padded channel count */
+    const void* y;          /* conv output, dense [N][T][C] */
+    int32_t y_f32;          /* 0: bf16, 1: fp32 */
+    const float* scale;     /* NULL => identity (no BatchNorm) */
+    const float* shift;
+    const float* mean;      /* backward only */
+    const float* invstd;
+    const void* y2;         /* optional residual branch (jasper.py:400-410), same layout/dtype as y */
+    const float* scale2;
+    const float* shift2;
+    const float* mean2;
+    const float* invstd2;
+    int32_t act;            /* 0 none, 1 clamp[0,20] (wav2letter.py:46), 2 ReLU (jasper.py:448) */
+    float drop_p;           /* nn.Dropout p; 0 => no mask is read or written */
+    uint64_t seed, offset;  /* Philox4x32-10 key / stream offset */
+    uint8_t* mask;          /* keep bits, one byte per 8 channels: [N*T*C/8] */
+    const int32_t* lens;    /* optional [N]: rows t >= lens[n] produce 0 / receive 0 gradient */
+} w2l_bnact_t;
+
+/* a = act(dropout(y*scale+shift [+ y2*scale2+shift2])) written to a padded buffer
+ * [N][pad_l+T+pad_r+tail][C] for the NEXT conv: halo rows are reflected copies (pad_mode 1) or zeros. */
+int w2l_bn_act_fwd(const w2l_bnact_t* d, void* out_hi, void* out_lo, int out_rows, int pad_l, int pad_r,
+                   int pad_mode, void* stream);
+
+typedef struct {
+    const void* dxp;        /* gradient wrt the padded activation buffer [N][pad_l+T+pad_r][C], bf16 or fp32 */
+    int32_t f32;
+    int32_t pad_l, pad_r, pad_mode;   /* fold reflected halo rows back (mode 1) or skip the halo (mode 0) */
+} w2l_gradsrc_t;
+
+/* sums over (n,t) of g and g*xhat per channel for each branch:
+ * partial [nblocks][4][C] = {sum g, sum g*xhat1, sum g (branch2), sum g*xhat2}; nblocks = w2l_bn_bwd_blocks(). */
+int w2l_bn_bwd_blocks(int N, int T, int C);
+int w2l_bn_act_bwd_reduce(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2, float* partial,
+                          void* stream);
+/* partial -> sums [4][C] (sum_g = d beta, sum_gx = d gamma) */
+int w2l_bn_bwd_finalize(const float* partial, int nblocks, int C, float* sums, void* stream);
+/* dy = scale*(g - sum_g/M - xhat*sum_gx/M) into zero-haloed buffers [N][halo_b+T+halo_a][C] (hi[,lo]);
+ * dy2 likewise for the residual branch (NULL if none).  The conv bias gradient under BatchNorm is
+ * sum(dy) == 0 identically (the reference's value is fp32 rounding noise); it is not computed. */
+int w2l_bn_act_bwd_apply(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2, const float* sums,
+                         void* dy_hi, void* dy_lo, int halo_b, int halo_a, void* dy2_hi, void* dy2_lo, int halo2_b,
+                         int halo2_a, void* stream);
+
+/* ---- log_softmax + CTC (wav2letter.py:86-87, jasper.py:469-473, base_asr_models.py:23,81,90) ---- */
+/* logits fp32 [N][T][CP] (first C valid) -> out fp32 [N][T][C]; mode 0 log_softmax, 1 softmax */
+int w2l_log_softmax_fwd(const float* logits, int N, int T, int C, int CP, int mode, float* out, void* stream);
+/* grad wrt logits (dense [N][T][C]) from grad wrt out and out itself */
+int w2l_log_softmax_bwd(const float* gout, const float* out, int N, int T, int C, int mode, float* glogits,
+                        void* stream);
+/* workspace bytes for w2l_ctc_loss */
+int64_t w2l_ctc_workspace_bytes(int N, int T, int Smax);
+/* nn.CTCLoss(blank, reduction='mean', zero_infinity): log_probs [N][T][C] fp32 (batch-major),
+ * targets [N][Smax] int32 (padded), lengths int32 [N].  Outputs: nll[N] (0 where infinite and zero_infinity),
+ * loss[1] = mean_n(nll_n / max(S_n,1)), grad [N][T][C] = d loss / d log_probs in torch's convention
+ * (exp(lp) - posterior) * grad_scale / (N*max(S_n,1)), zero for t >= input_lengths[n]). */
+int w2l_ctc_loss(const float* log_probs, const int32_t* targets, const int32_t* input_lengths,
+                 const int32_t* target_lengths, int N, int T, int C, int Smax, int blank, int zero_infinity,
+                 float* nll, float* loss, float* grad, void* workspace, void* stream);
+
+/* ---- greedy decode (decoder.py:136) + Levenshtein (decoder.py:49,60) ---- */
+/* argmax over the last dim, ties -> lowest index (torch.max): probs fp32 [rows][C] -> idx int32 [rows] */
+int w2l_argmax(const float* probs, int64_t rows, int C, int32_t* idx, void* stream);
+/* host-side edit distance over int32 symbol arrays */
+int w2l_levenshtein_host(const int32_t* a_host, int na, const int32_t* b_host, int nb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,291 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point against the CPU oracle
+(oracle/w2l_oracle.py, torch-CPU fp32 / numpy) on the same seeded inputs.
+Tolerances: bf16-operand kernels are compared on bf16-rounded inputs (fp32 accumulate) at
+2e-3 relative to the output scale; fp32 elementwise kernels at 1e-5."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+@pytest.fixture(scope='module')
+def L():
+    from wav2letter_pytorch_amd import _lib
+    assert torch.cuda.is_available()
+    return _lib
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def to_ntc_padded(x_nct, pad_l, pad_r, mode, cp=None):
+    """reference construction of the padded channels-last buffer on the CPU"""
+    n, c, t = x_nct.shape
+    cp = cp or c
+    if pad_l or pad_r:
+        x_nct = F.pad(x_nct, (pad_l, pad_r), mode='reflect' if mode == 1 else 'constant')
+    out = torch.zeros(n, t + pad_l + pad_r, cp)
+    out[:, :, :c] = x_nct.transpose(1, 2)
+    return out
+
+
+@pytest.mark.parametrize('N,C,T,CP,pl,pr,mode', [(3, 64, 100, 64, 4, 5, 1), (2, 40, 37, 64, 28, 28, 1), (2, 64, 50, 64, 3, 3, 0),
+                                                 (1, 29, 33, 64, 0, 0, 0)])
+def test_nct_to_ntc(L, N, C, T, CP, pl, pr, mode):
+    torch.manual_seed(0)
+    x = torch.randn(N, C, T)
+    xd = x.cuda()
+    hi = torch.empty(N, pl + T + pr, CP, dtype=torch.bfloat16, device='cuda')
+    lo = torch.empty_like(hi)
+    L.check(L.lib.w2l_nct_to_ntc(L.ptr(xd), N, C, T, CP, pl, pr, mode, None, L.ptr(hi), L.ptr(lo), L.stream_ptr()))
+    ref = to_ntc_padded(x, pl, pr, mode, CP)
+    assert torch.equal(hi.float().cpu(), bf(ref))
+    rec = hi.float().cpu() + lo.float().cpu()
+    assert (rec - ref).abs().max() <= 2 ** -16 * ref.abs().max()
+    # length masking
+    lens = torch.tensor([T - 7] + [T] * (N - 1), dtype=torch.int32).cuda()
+    L.check(L.lib.w2l_nct_to_ntc(L.ptr(xd), N, C, T, CP, pl, pr, 0, L.ptr(lens), L.ptr(hi), None, L.stream_ptr()))
+    xm = x.clone()
+    xm[0, :, T - 7:] = 0
+    assert torch.equal(hi.float().cpu(), bf(to_ntc_padded(xm, pl, pr, 0, CP)))
+
+
+def pack(L, w, precise=False):
+    cout, cin, kw = w.shape
+    coutp, cinp = (cout + 63) // 64 * 64, (cin + 63) // 64 * 64
+    wd = w.cuda()
+    fh = torch.empty(kw, coutp, cinp, dtype=torch.bfloat16, device='cuda')
+    dh = torch.empty(kw, cinp, coutp, dtype=torch.bfloat16, device='cuda')
+    fl = torch.empty_like(fh) if precise else None
+    dl = torch.empty_like(dh) if precise else None
+    L.check(L.lib.w2l_pack_weights(L.ptr(wd), wd.stride(0), wd.stride(1), wd.stride(2), cout, cin, kw, coutp, cinp,
+                                   L.ptr(fh), L.ptr(fl), L.ptr(dh), L.ptr(dl), L.stream_ptr()))
+    return fh, fl, dh, dl, coutp, cinp
+
+
+def test_pack_weights(L):
+    torch.manual_seed(1)
+    for (cout, cin, kw) in [(96, 40, 5), (128, 64, 11), (29, 128, 1)]:
+        w = torch.randn(cout, cin, kw)
+        for wsrc in (w, torch.randn(kw, cout, cin).permute(1, 2, 0)):
+            fh, fl, dh, dl, coutp, cinp = pack(L, wsrc, precise=True)
+            ref = torch.zeros(kw, coutp, cinp)
+            ref[:, :cout, :cin] = wsrc.permute(2, 0, 1)
+            assert torch.equal(fh.float().cpu(), bf(ref))
+            refd = torch.zeros(kw, cinp, coutp)
+            refd[:, :cin, :cout] = wsrc.flip(2).permute(2, 1, 0)
+            assert torch.equal(dh.float().cpu(), bf(refd))
+            assert ((fh.float() + fl.float()).cpu() - ref).abs().max() <= 2 ** -16 * ref.abs().max()
+            assert ((dh.float() + dl.float()).cpu() - refd).abs().max() <= 2 ** -16 * refd.abs().max()
+
+
+CONV_CASES = [
+    # N, Cin, Cout, Kw, s, d, T(valid in), pad_l, pad_r
+    (2, 64, 128, 11, 2, 1, 100, 4, 5),      # layer-0 shape: stride 2, asymmetric reflect pad
+    (3, 128, 128, 11, 1, 1, 137, 5, 5),
+    (2, 64, 192, 29, 1, 2, 150, 28, 28),    # dilation 2, Cout not a multiple of the 128 tile
+    (2, 192, 64, 1, 1, 1, 70, 0, 0),        # 1x1 (classifier-like, Cout < tile)
+    (1, 256, 256, 13, 1, 1, 500, 6, 6),     # T spans several 128-row tiles
+]
+
+
+def conv_inputs(N, Cin, Cout, Kw, T, pl, pr, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, Kw, generator=g) / (Cin * Kw) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    return x, w, b
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('precise', [False, True])
+def test_conv_igemm_forward(L, case, precise):
+    N, Cin, Cout, Kw, s, d, T, pl, pr = case
+    x, w, b = conv_inputs(N, Cin, Cout, Kw, T, pl, pr, 3)
+    xp = to_ntc_padded(x, pl, pr, 1)
+    rows = xp.shape[1]
+    Tout = (rows - (Kw - 1) * d - 1) // s + 1
+    fh, fl, _, _, coutp, cinp = pack(L, w, precise)
+    xh = xp.to(torch.bfloat16).cuda()
+    xl = (xp - xh.float().cpu()).to(torch.bfloat16).cuda()
+    y = torch.full((N, Tout, coutp), float('nan'), dtype=torch.float32 if precise else torch.bfloat16, device='cuda')
+    tiles = L.lib.w2l_conv_stat_tiles(N, Tout)
+    stats = torch.zeros(tiles, 2, coutp, device='cuda')
+    bd = torch.zeros(coutp)
+    bd[:Cout] = b
+    bd = bd.cuda()
+    st = L.stream_ptr()
+    args = (N, cinp, coutp, Tout, Kw, s, d, st)
+    if not precise:
+        L.check(L.lib.w2l_conv1d_igemm(L.ptr(xh), rows * cinp, N * rows, L.ptr(fh), L.ptr(y), 0, 0, L.ptr(bd),
+                                       L.ptr(stats), *args))
+        ref = F.conv1d(F.pad(bf(x), (pl, pr), mode='reflect'), bf(w), b, stride=s, dilation=d)
+        tol = 1e-2          # bf16 output rounding (2^-8 relative per element)
+    else:
+        L.check(L.lib.w2l_conv1d_igemm(L.ptr(xh), rows * cinp, N * rows, L.ptr(fh), L.ptr(y), 1, 0, L.ptr(bd), None, *args))
+        L.check(L.lib.w2l_conv1d_igemm(L.ptr(xh), rows * cinp, N * rows, L.ptr(fl), L.ptr(y), 1, 1, None, None, *args))
+        L.check(L.lib.w2l_conv1d_igemm(L.ptr(xl), rows * cinp, N * rows, L.ptr(fh), L.ptr(y), 1, 1, None, L.ptr(stats), *args))
+        ref = F.conv1d(F.pad(x, (pl, pr), mode='reflect'), w, b, stride=s, dilation=d)
+        tol = 1e-4
+    torch.cuda.synchronize()
+    got = y.float().cpu()[:, :, :Cout].transpose(1, 2)
+    assert torch.isfinite(got).all()
+    assert relerr(got, ref) < tol, relerr(got, ref)
+    if coutp > Cout:
+        assert (y.float().cpu()[:, :, Cout:] == 0).all()
+    # BatchNorm partial statistics: sums over (n, t) of y and y^2
+    s1 = stats[:, 0, :Cout].sum(0).cpu()
+    s2 = stats[:, 1, :Cout].sum(0).cpu()
+    r1, r2 = ref.sum((0, 2)), (ref * ref).sum((0, 2))
+    assert (s1 - r1).abs().max() <= 5e-3 * r2.sqrt().max() * (N * Tout) ** 0.5 * (1 if not precise else 0.05)
+    assert relerr(s2, r2) < (2e-2 if not precise else 1e-3)
+
+
+@pytest.mark.parametrize('case', [c for c in CONV_CASES if c[4] == 1])
+@pytest.mark.parametrize('precise', [False, True])
+def test_conv_dgrad(L, case, precise):
+    """dgrad = the same kernel over zero-haloed dy with flipped/transposed weights"""
+    N, Cin, Cout, Kw, s, d, T, pl, pr = case
+    x, w, b = conv_inputs(N, Cin, Cout, Kw, T, pl, pr, 4)
+    Tp = T + pl + pr
+    Tout = Tp - (Kw - 1) * d
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(N, Cout, Tout, generator=g)
+    _, _, dh, dl, coutp, cinp = pack(L, w, precise)
+    hb = (Kw - 1) * d
+    ha = max(hb, (Tout + 63) // 64 * 64 - Tout)
+    dyp = to_ntc_padded(dy, hb, ha, 0, coutp)
+    rows = dyp.shape[1]
+    dyh = dyp.to(torch.bfloat16).cuda()
+    dyl = (dyp - dyh.float().cpu()).to(torch.bfloat16).cuda()
+    dx = torch.full((N, Tp, cinp), float('nan'), dtype=torch.float32 if precise else torch.bfloat16, device='cuda')
+    st = L.stream_ptr()
+    args = (N, coutp, cinp, Tp, Kw, 1, d, st)
+    if not precise:
+        L.check(L.lib.w2l_conv1d_igemm(L.ptr(dyh), rows * coutp, N * rows, L.ptr(dh), L.ptr(dx), 0, 0, None, None, *args))
+        xr = F.pad(bf(x), (pl, pr), mode='reflect').requires_grad_(True)
+        F.conv1d(xr, bf(w), None, dilation=d).backward(bf(dy))
+        tol = 1e-2
+    else:
+        L.check(L.lib.w2l_conv1d_igemm(L.ptr(dyh), rows * coutp, N * rows, L.ptr(dh), L.ptr(dx), 1, 0, None, None, *args))
+        L.check(L.lib.w2l_conv1d_igemm(L.ptr(dyh), rows * coutp, N * rows, L.ptr(dl), L.ptr(dx), 1, 1, None, None, *args))
+        L.check(L.lib.w2l_conv1d_igemm(L.ptr(dyl), rows * coutp, N * rows, L.ptr(dh), L.ptr(dx), 1, 1, None, None, *args))
+        xr = F.pad(x, (pl, pr), mode='reflect').requires_grad_(True)
+        F.conv1d(xr, w, None, dilation=d).backward(dy)
+        tol = 1e-4
+    torch.cuda.synchronize()
+    got = dx.float().cpu()[:, :, :Cin].transpose(1, 2)
+    assert relerr(got, xr.grad) < tol, relerr(got, xr.grad)
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('precise', [False, True])
+def test_conv_wgrad(L, case, precise):
+    N, Cin, Cout, Kw, s, d, T, pl, pr = case
+    x, w, b = conv_inputs(N, Cin, Cout, Kw, T, pl, pr, 6)
+    xp = to_ntc_padded(x, pl, pr, 1)
+    rows = xp.shape[1]
+    Tout = (rows - (Kw - 1) * d - 1) // s + 1
+    g = torch.Generator().manual_seed(7)
+    dy = torch.randn(N, Cout, Tout, generator=g)
+    coutp, cinp = (Cout + 63) // 64 * 64, (Cin + 63) // 64 * 64
+    hb = (Kw - 1) * d
+    ha = max(hb, (Tout + 63) // 64 * 64 - Tout)
+    dyp = to_ntc_padded(dy, hb, ha, 0, coutp)
+    drows = dyp.shape[1]
+    dyh = dyp.to(torch.bfloat16).cuda()
+    dyl = (dyp - dyh.float().cpu()).to(torch.bfloat16).cuda()
+    xh = xp.to(torch.bfloat16).cuda()
+    xl = (xp - xh.float().cpu()).to(torch.bfloat16).cuda()
+    dw = torch.zeros(Kw, coutp, cinp, device='cuda')
+    st = L.stream_ptr()
+
+    def run(dyt, xt, acc):
+        L.check(L.lib.w2l_conv1d_wgrad(C.c_void_p(dyt.data_ptr() + hb * coutp * 2), drows * coutp, L.ptr(xt), rows * cinp,
+                                       N * rows, L.ptr(dw), N, cinp, coutp, Tout, Kw, s, d, acc, st))
+
+    if not precise:
+        run(dyh, xh, 0)
+        wr = bf(w).requires_grad_(True)
+        F.conv1d(F.pad(bf(x), (pl, pr), mode='reflect'), wr, None, stride=s, dilation=d).backward(bf(dy))
+        tol = 2e-3
+    else:
+        run(dyh, xh, 1)
+        run(dyh, xl, 1)
+        run(dyl, xh, 1)
+        wr = w.clone().requires_grad_(True)
+        F.conv1d(F.pad(x, (pl, pr), mode='reflect'), wr, None, stride=s, dilation=d).backward(dy)
+        tol = 1e-4
+    torch.cuda.synchronize()
+    got = dw.cpu()[:, :Cout, :Cin].permute(1, 2, 0)
+    assert relerr(got, wr.grad) < tol, relerr(got, wr.grad)
+
+
+def test_log_softmax_and_argmax(L):
+    torch.manual_seed(8)
+    N, T, Cn, CP = 3, 50, 29, 64
+    logits = torch.randn(N, T, CP) * 3
+    ld = logits.cuda()
+    for mode in (0, 1):
+        out = torch.empty(N, T, Cn, device='cuda')
+        L.check(L.lib.w2l_log_softmax_fwd(L.ptr(ld), N, T, Cn, CP, mode, L.ptr(out), L.stream_ptr()))
+        lr = logits[:, :, :Cn].clone().requires_grad_(True)
+        ref = F.log_softmax(lr, -1) if mode == 0 else F.softmax(lr, -1)
+        assert (out.cpu() - ref).abs().max() < 1e-5
+        g = torch.randn(N, T, Cn)
+        ref.backward(g)
+        gl = torch.empty(N, T, Cn, device='cuda')
+        L.check(L.lib.w2l_log_softmax_bwd(L.ptr(g.cuda()), L.ptr(out), N, T, Cn, mode, L.ptr(gl), L.stream_ptr()))
+        assert (gl.cpu() - lr.grad).abs().max() < 1e-5
+    z = np.load(os.path.join(GOLD, 'greedy_cases.npz'), allow_pickle=True)
+    probs = torch.from_numpy(z['probs']).cuda()
+    idx = torch.empty(probs.shape[0], probs.shape[1], dtype=torch.int32, device='cuda')
+    L.check(L.lib.w2l_argmax(L.ptr(probs), probs.shape[0] * probs.shape[1], probs.shape[2], L.ptr(idx), L.stream_ptr()))
+    np.testing.assert_array_equal(idx.cpu().numpy(), z['argmax'])       # bit-exact, ties -> lowest index
+
+
+def test_ctc_golden_cases(L):
+    """loss / nll / grad against the reference's criterion (tests/golden/ctc_cases.npz): ragged input
+    lengths, empty target, repeated labels, infeasible alignments under zero_infinity."""
+    from wav2letter_pytorch_amd.ctc_loss import CTCLoss
+    z = np.load(os.path.join(GOLD, 'ctc_cases.npz'))
+    lp = torch.from_numpy(z['log_probs']).cuda().requires_grad_(True)
+    crit = CTCLoss(blank=0, reduction='mean', zero_infinity=True)
+    loss = crit(lp.transpose(0, 1), torch.from_numpy(z['targets']), torch.from_numpy(z['in_lens']),
+                torch.from_numpy(z['target_lens']))
+    loss.backward()
+    assert abs(float(loss) - float(z['loss'])) < 1e-4
+    g = lp.grad.cpu().numpy()
+    np.testing.assert_allclose(g, z['grad'], rtol=1e-3, atol=2e-6)
+    assert np.all(g[1, 33:] == 0) and np.all(g[3] == 0) and np.all(g[5] == 0)
+
+
+@pytest.mark.parametrize('N,T,S', [(4, 250, 100), (2, 500, 160), (3, 64, 5)])
+def test_ctc_vs_oracle_random(L, N, T, S):
+    from wav2letter_pytorch_amd.ctc_loss import CTCLoss
+    g = torch.Generator().manual_seed(N * 1000 + T)
+    lp = torch.log_softmax(torch.randn(N, T, 29, generator=g) * 2, -1)
+    tl = torch.randint(max(1, S // 2), S + 1, (N,), generator=g, dtype=torch.int32)
+    tg = torch.randint(1, 29, (N, S), generator=g, dtype=torch.int32)
+    il = torch.randint(T - T // 4, T + 1, (N,), generator=g, dtype=torch.int32)
+    lr = lp.clone().requires_grad_(True)
+    ref = F.ctc_loss(lr.transpose(0, 1), tg, il, tl, blank=0, reduction='mean', zero_infinity=True)
+    ref.backward()
+    ld = lp.cuda().requires_grad_(True)
+    loss = CTCLoss(0, 'mean', True)(ld.transpose(0, 1), tg, il, tl)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
+    np.testing.assert_allclose(ld.grad.cpu().numpy(), lr.grad.numpy(), rtol=2e-3, atol=1e-6)

@@ -1,0 +1,110 @@
+"""ctypes binding of libw2l_hip.so (C ABI: include/w2l_hip.h).
+
+The library is the product: there is NO CPU or PyTorch fallback.  Loading fails
+loudly if the shared object is missing, and every compute call fails loudly if
+its tensors are not on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  -- must be imported first so the .so binds to torch's bundled HIP runtime
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libw2l_hip.so')
+
+c_p = C.c_void_p
+c_i = C.c_int
+c_i64 = C.c_int64
+c_u64 = C.c_uint64
+c_f = C.c_float
+
+
+class BnActDesc(C.Structure):
+    """w2l_bnact_t (include/w2l_hip.h)."""
+    _fields_ = [
+        ('N', C.c_int32), ('T', C.c_int32), ('C', C.c_int32),
+        ('y', c_p), ('y_f32', C.c_int32),
+        ('scale', c_p), ('shift', c_p), ('mean', c_p), ('invstd', c_p),
+        ('y2', c_p), ('scale2', c_p), ('shift2', c_p), ('mean2', c_p), ('invstd2', c_p),
+        ('act', C.c_int32), ('drop_p', c_f), ('seed', c_u64), ('offset', c_u64),
+        ('mask', c_p), ('lens', c_p),
+    ]
+
+
+class GradSrc(C.Structure):
+    """w2l_gradsrc_t (include/w2l_hip.h)."""
+    _fields_ = [('dxp', c_p), ('f32', C.c_int32), ('pad_l', C.c_int32), ('pad_r', C.c_int32),
+                ('pad_mode', C.c_int32)]
+
+
+_SIGNATURES = {
+    'w2l_last_error': (C.c_char_p, []),
+    'w2l_abi_version': (c_i, []),
+    'w2l_pack_weights': (c_i, [c_p, c_i64, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    'w2l_nct_to_ntc': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    'w2l_pad_cast': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    'w2l_conv_stat_tiles': (c_i, [c_i, c_i]),
+    'w2l_conv1d_igemm': (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'w2l_wgrad_needs_zero': (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    'w2l_conv1d_wgrad': (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'w2l_bn_finalize': (c_i, [c_p, c_i, c_i, c_i64, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'w2l_bn_act_fwd': (c_i, [C.POINTER(BnActDesc), c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    'w2l_bn_bwd_blocks': (c_i, [c_i, c_i, c_i]),
+    'w2l_bn_act_bwd_reduce': (c_i, [C.POINTER(BnActDesc), C.POINTER(GradSrc), C.POINTER(GradSrc), c_p, c_p]),
+    'w2l_bn_bwd_finalize': (c_i, [c_p, c_i, c_i, c_p, c_p]),
+    'w2l_bn_act_bwd_apply': (c_i, [C.POINTER(BnActDesc), C.POINTER(GradSrc), C.POINTER(GradSrc), c_p, c_p, c_p, c_i,
+                                   c_i, c_p, c_p, c_i, c_i, c_p]),
+    'w2l_log_softmax_fwd': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'w2l_log_softmax_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'w2l_ctc_workspace_bytes': (c_i64, [c_i, c_i, c_i]),
+    'w2l_ctc_loss': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    'w2l_argmax': (c_i, [c_p, c_i64, c_i, c_p, c_p]),
+    'w2l_levenshtein_host': (c_i, [c_p, c_i, c_p, c_i]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class W2LError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} not found: build the HIP extension first '
+            f'(python -c "import __graft_entry__ as g; g.build()" or make -C wav2letter_pytorch_amd/csrc). '
+            f'There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        msg = lib.w2l_last_error()
+        raise W2LError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise W2LError('wav2letter_pytorch_amd runs on MI355X only: got a CPU tensor '
+                           '(there is no CPU fallback; move the model and batch to cuda)')

@@ -1,0 +1,482 @@
+// BatchNorm1d (train / eval) + Dropout + activation, forward and backward, over
+// channels-last activations (gfx950).  HBM-bound: every pass moves 16 bytes per
+// lane, per-channel reductions stay in registers -> LDS -> one partial row per
+// block (deterministic two-stage sums, no atomics).
+//
+// Replaces, fused: nn.BatchNorm1d(momentum=.9, eps=1e-3) + nn.Dropout + torch.clamp(0,20)
+// (wav2letter.py:37-38,43-46) and nn.BatchNorm1d(eps=1e-3, momentum=.1) + ReLU + Dropout +
+// residual add + MaskedConv1d's masked_fill (jasper.py:116-119,363,376,409-410,448), and the
+// reflect-padding of the next conv's input (wav2letter.py:28-34,41) incl. its backward fold.
+#include "common.h"
+#include "../../include/w2l_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------- Philox4x32-10
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// keep-bits for the 8 channels of group index `gidx`: bit j set <=> channel j kept.
+// One Philox call gives eight 16-bit uniforms; keep iff u16 >= p * 65536.
+__device__ __forceinline__ uint32_t dropout_bits(uint64_t seed, uint64_t offset, uint64_t gidx, uint32_t thresh) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)gidx, (uint32_t)(gidx >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bits |= ((r[j] & 0xFFFFu) >= thresh ? 1u : 0u) << (2 * j);
+        bits |= ((r[j] >> 16) >= thresh ? 1u : 0u) << (2 * j + 1);
+    }
+    return bits;
+}
+
+// ---------------------------------------------------------------- 8-channel loads / stores
+template <bool F32>
+__device__ __forceinline__ void load8(const void* base, int64_t off, float v[8]) {
+    if (F32) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off);
+        const f32x4 a = p[0], b = p[1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+    } else {
+        const u16x8 a = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16_raw*>(base) + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bf16_bits_to_f32(a[j]);
+    }
+}
+__device__ __forceinline__ void loadp8(const float* p, int c, float v[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p + c), b = *reinterpret_cast<const f32x4*>(p + c + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+}
+__device__ __forceinline__ void store8_split(bf16_raw* hi, bf16_raw* lo, int64_t off, const float v[8]) {
+    u16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bf16_raw a, b;
+        f32_split_bf16(v[j], a, b);
+        h[j] = a; l[j] = b;
+    }
+    *reinterpret_cast<u16x8*>(hi + off) = h;
+    if (lo) *reinterpret_cast<u16x8*>(lo + off) = l;
+}
+
+__device__ __forceinline__ int pad_src_row(int r, int T, int pad_l, int pad_r, int pad_mode) {
+    int t = r - pad_l;
+    if (t >= 0 && t < T) return t;
+    if (pad_mode != 1 || t < -pad_l || t >= T + pad_r) return -1;
+    t = t < 0 ? -t : 2 * (T - 1) - t;
+    return (t >= 0 && t < T) ? t : -1;
+}
+
+// pre-activation value z = dropout(bn(y) [+ bn2(y2)]) for 8 channels, and which of them pass
+// the activation's gradient.  Returns keep bits (after dropout).
+template <bool F32>
+__device__ __forceinline__ uint32_t preact8(const w2l_bnact_t& d, int64_t row /* n*T+t */, int cg, int G, float z[8],
+                                            float y1[8], float y2v[8], uint32_t thresh, float inv_keep,
+                                            bool write_mask) {
+    const int c = cg * 8;
+    const int64_t off = row * d.C + c;
+    load8<F32>(d.y, off, y1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = y1[j];
+    if (d.scale) {
+        float sc[8], sh[8];
+        loadp8(d.scale, c, sc);
+        loadp8(d.shift, c, sh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = y1[j] * sc[j] + sh[j];
+    }
+    if (d.y2) {
+        load8<F32>(d.y2, off, y2v);
+        if (d.scale2) {
+            float sc[8], sh[8];
+            loadp8(d.scale2, c, sc);
+            loadp8(d.shift2, c, sh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] += y2v[j] * sc[j] + sh[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] += y2v[j];
+        }
+    }
+    uint32_t bits = 0xFFu;
+    if (d.drop_p > 0.f) {
+        const int64_t gidx = row * G + cg;
+        if (write_mask) {
+            bits = dropout_bits(d.seed, d.offset, (uint64_t)gidx, thresh);
+            d.mask[gidx] = (uint8_t)bits;
+        } else {
+            bits = d.mask[gidx];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = (bits >> j) & 1u ? z[j] * inv_keep : 0.f;
+    }
+    return bits;
+}
+
+__device__ __forceinline__ float activate(float z, int act) {
+    if (act == 1) return fminf(fmaxf(z, 0.f), 20.f);
+    if (act == 2) return fmaxf(z, 0.f);
+    return z;
+}
+// gradient gate: torch.clamp passes 1 on the CLOSED interval [0,20]; ReLU passes on z > 0
+__device__ __forceinline__ bool act_pass(float z, int act) {
+    if (act == 1) return z >= 0.f && z <= 20.f;
+    if (act == 2) return z > 0.f;
+    return true;
+}
+
+// ---------------------------------------------------------------- forward
+template <bool F32>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(w2l_bnact_t d, bf16_raw* out_hi, bf16_raw* out_lo, int R,
+                                                          int pad_l, int pad_r, int pad_mode, uint32_t thresh,
+                                                          float inv_keep) {
+    const int G = d.C >> 3;
+    const int64_t total = (int64_t)d.N * R * G;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+        const int cg = (int)(it % G);
+        const int64_t orow = it / G;
+        const int n = (int)(orow / R);
+        const int r = (int)(orow - (int64_t)n * R);
+        const int t = pad_src_row(r, d.T, pad_l, pad_r, pad_mode);
+        float a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = 0.f;
+        if (t >= 0 && (!d.lens || t < d.lens[n])) {
+            float z[8], y1[8], y2v[8];
+            preact8<F32>(d, (int64_t)n * d.T + t, cg, G, z, y1, y2v, thresh, inv_keep, /*write_mask=*/r - pad_l == t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = activate(z[j], d.act);
+        }
+        store8_split(out_hi, out_lo, orow * d.C + cg * 8, a);
+    }
+}
+
+// ---------------------------------------------------------------- backward helpers
+template <bool GF32>
+__device__ __forceinline__ void add_grad8(const w2l_gradsrc_t& s, int n, int t, int T, int C, int cg, float g[8]) {
+    const int R = s.pad_l + T + s.pad_r;
+    const int64_t base = (int64_t)n * R;
+    float v[8];
+    load8<GF32>(s.dxp, (base + t + s.pad_l) * C + cg * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] += v[j];
+    if (s.pad_mode == 1) {                       // fold the reflected halo rows back onto their source frame
+        if (t >= 1 && t <= s.pad_l) {
+            load8<GF32>(s.dxp, (base + s.pad_l - t) * C + cg * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] += v[j];
+        }
+        if (t <= T - 2 && t >= T - 1 - s.pad_r) {
+            load8<GF32>(s.dxp, (base + s.pad_l + 2 * (T - 1) - t) * C + cg * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] += v[j];
+        }
+    }
+}
+
+struct BwdRow {
+    float g[8];       // gradient wrt bn output(s) after activation / dropout gates
+    float xh1[8];     // normalised input of branch 1
+    float xh2[8];
+};
+
+template <bool F32, bool GF32>
+__device__ __forceinline__ void bwd_row(const w2l_bnact_t& d, const w2l_gradsrc_t& g1, const w2l_gradsrc_t* g2, int n,
+                                        int t, int cg, int G, float inv_keep, BwdRow& o) {
+    float z[8], y1[8], y2v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o.g[j] = 0.f; o.xh1[j] = 0.f; o.xh2[j] = 0.f; y2v[j] = 0.f; }
+    if (d.lens && t >= d.lens[n]) return;        // masked_fill: no gradient through zeroed frames
+    const uint32_t bits = preact8<F32>(d, (int64_t)n * d.T + t, cg, G, z, y1, y2v, 0, inv_keep, false);
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    add_grad8<GF32>(g1, n, t, d.T, d.C, cg, g);
+    if (g2) add_grad8<GF32>(*g2, n, t, d.T, d.C, cg, g);
+    const int c = cg * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool keep = (bits >> j) & 1u;
+        o.g[j] = (keep && act_pass(z[j], d.act)) ? g[j] * (d.drop_p > 0.f ? inv_keep : 1.f) : 0.f;
+    }
+    if (d.mean) {
+        float m[8], is[8];
+        loadp8(d.mean, c, m);
+        loadp8(d.invstd, c, is);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.xh1[j] = (y1[j] - m[j]) * is[j];
+    }
+    if (d.y2 && d.mean2) {
+        float m[8], is[8];
+        loadp8(d.mean2, c, m);
+        loadp8(d.invstd2, c, is);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.xh2[j] = (y2v[j] - m[j]) * is[j];
+    }
+}
+
+constexpr int BWD_ROWS_PER_BLOCK = 64;
+
+// partial[blk][4][C]: sum g, sum g*xh1, sum g, sum g*xh2
+template <bool F32, bool GF32>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(w2l_bnact_t d, w2l_gradsrc_t g1, w2l_gradsrc_t g2,
+                                                                 int has_g2, float* partial, float inv_keep) {
+    extern __shared__ float red[];               // [RPB][3][C]
+    const int G = d.C >> 3;
+    const int RPB = 256 / G;
+    const int tid = threadIdx.x;
+    const int rr = tid / G, cg = tid - rr * G;
+    const int64_t rows = (int64_t)d.N * d.T;
+    const int64_t row0 = (int64_t)blockIdx.x * BWD_ROWS_PER_BLOCK;
+    float s0[8], s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+    if (rr < RPB) {
+        for (int64_t row = row0 + rr; row < row0 + BWD_ROWS_PER_BLOCK && row < rows; row += RPB) {
+            const int n = (int)(row / d.T), t = (int)(row - (int64_t)n * d.T);
+            BwdRow o;
+            bwd_row<F32, GF32>(d, g1, has_g2 ? &g2 : nullptr, n, t, cg, G, inv_keep, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s0[j] += o.g[j];
+                s1[j] += o.g[j] * o.xh1[j];
+                s2[j] += o.g[j] * o.xh2[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[(rr * 3 + 0) * d.C + cg * 8 + j] = s0[j];
+            red[(rr * 3 + 1) * d.C + cg * 8 + j] = s1[j];
+            red[(rr * 3 + 2) * d.C + cg * 8 + j] = s2[j];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < d.C; c += 256) {
+        float a = 0.f, b = 0.f, e = 0.f;
+        for (int k = 0; k < RPB; ++k) {
+            a += red[(k * 3 + 0) * d.C + c];
+            b += red[(k * 3 + 1) * d.C + c];
+            e += red[(k * 3 + 2) * d.C + c];
+        }
+        float* dst = partial + (int64_t)blockIdx.x * 4 * d.C;
+        dst[c] = a; dst[d.C + c] = b; dst[2 * d.C + c] = a; dst[3 * d.C + c] = e;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* partial, int nblocks, int C, float* sums) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // over 4*C
+    if (i >= 4 * C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * 4 * C + i];
+    sums[i] = (float)s;
+}
+
+template <bool F32, bool GF32>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(w2l_bnact_t d, w2l_gradsrc_t g1, w2l_gradsrc_t g2,
+                                                                int has_g2, const float* sums, bf16_raw* dy_hi,
+                                                                bf16_raw* dy_lo, int hb, int ha, bf16_raw* dy2_hi,
+                                                                bf16_raw* dy2_lo, int hb2, int ha2, float inv_keep) {
+    const int G = d.C >> 3;
+    const int T = d.T;
+    const int lo_u = -(hb > hb2 ? hb : hb2);
+    const int hi_u = T + (ha > ha2 ? ha : ha2);
+    const int U = hi_u - lo_u;
+    const int R1 = hb + T + ha, R2 = hb2 + T + ha2;
+    const float invM = 1.f / ((float)d.N * (float)T);
+    const int64_t total = (int64_t)d.N * U * G;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+        const int cg = (int)(it % G);
+        const int64_t urow = it / G;
+        const int n = (int)(urow / U);
+        const int t = (int)(urow - (int64_t)n * U) + lo_u;
+        float o1[8], o2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o1[j] = 0.f; o2[j] = 0.f; }
+        if (t >= 0 && t < T) {
+            BwdRow o;
+            bwd_row<F32, GF32>(d, g1, has_g2 ? &g2 : nullptr, n, t, cg, G, inv_keep, o);
+            const int c = cg * 8;
+            if (d.mean) {
+                float sg[8], sgx[8], sc[8];
+                loadp8(sums, c, sg);
+                loadp8(sums + d.C, c, sgx);
+                loadp8(d.scale, c, sc);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o1[j] = sc[j] * (o.g[j] - sg[j] * invM - o.xh1[j] * sgx[j] * invM);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o1[j] = o.g[j] * (d.scale ? d.scale[c + j] : 1.f);
+            }
+            if (d.y2) {
+                if (d.mean2) {
+                    float sg[8], sgx[8], sc[8];
+                    loadp8(sums + 2 * d.C, c, sg);
+                    loadp8(sums + 3 * d.C, c, sgx);
+                    loadp8(d.scale2, c, sc);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o2[j] = sc[j] * (o.g[j] - sg[j] * invM - o.xh2[j] * sgx[j] * invM);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o2[j] = o.g[j] * (d.scale2 ? d.scale2[c + j] : 1.f);
+                }
+            }
+        }
+        const int r1 = t + hb, r2 = t + hb2;
+        if (dy_hi && r1 >= 0 && r1 < R1) store8_split(dy_hi, dy_lo, ((int64_t)n * R1 + r1) * d.C + cg * 8, o1);
+        if (dy2_hi && r2 >= 0 && r2 < R2) store8_split(dy2_hi, dy2_lo, ((int64_t)n * R2 + r2) * d.C + cg * 8, o2);
+    }
+}
+
+// ---------------------------------------------------------------- statistics finalize (forward)
+__global__ void bn_finalize_kernel(const float* partial, int ntiles, int C, double count, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* running_mean,
+                                   float* running_var, float* mean, float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float m, istd;
+    if (partial) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int t = 0; t < ntiles; ++t) {
+            s1 += partial[(int64_t)t * 2 * C + c];
+            s2 += partial[(int64_t)t * 2 * C + C + c];
+        }
+        const double mu = s1 / count;
+        double var = s2 / count - mu * mu;           // biased: normalisation uses it
+        if (var < 0.0) var = 0.0;
+        m = (float)mu;
+        istd = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    } else {                                         // eval: running statistics
+        m = running_mean[c];
+        istd = 1.f / sqrtf(running_var[c] + eps);
+    }
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    if (mean) { mean[c] = m; invstd[c] = istd; }
+    scale[c] = g * istd;
+    shift[c] = b - m * g * istd;
+}
+
+int elementwise_blocks(int64_t items) {
+    int64_t b = (items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+int check_desc(const w2l_bnact_t* d, const char* who) {
+    W2L_CHECK_ARG(d && d->y, "%s: null descriptor / y", who);
+    W2L_CHECK_ARG(d->N > 0 && d->T > 0 && d->C > 0 && d->C % 8 == 0 && d->C <= 2048, "%s: bad N/T/C (%d,%d,%d)", who,
+                  d->N, d->T, d->C);
+    W2L_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f, "%s: dropout p must be in [0,1)", who);
+    W2L_CHECK_ARG(d->drop_p == 0.f || d->mask, "%s: dropout needs a mask buffer", who);
+    W2L_CHECK_ARG((d->scale == nullptr) == (d->shift == nullptr), "%s: scale/shift must come together", who);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int w2l_bn_finalize(const float* partial, int ntiles, int C, int64_t count, const float* gamma,
+                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                               float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    W2L_CHECK_ARG(scale && shift && C > 0, "bn_finalize: null output");
+    W2L_CHECK_ARG(partial || (running_mean && running_var), "bn_finalize: eval mode needs running stats");
+    W2L_CHECK_ARG(!partial || (ntiles > 0 && count > 0), "bn_finalize: bad tile count");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, partial, ntiles, C,
+                       (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int w2l_bn_act_fwd(const w2l_bnact_t* d, void* out_hi, void* out_lo, int out_rows, int pad_l, int pad_r,
+                              int pad_mode, void* stream) {
+    if (int e = check_desc(d, "bn_act_fwd")) return e;
+    W2L_CHECK_ARG(out_hi && out_rows >= pad_l + d->T + pad_r && pad_l >= 0 && pad_r >= 0, "bn_act_fwd: bad output geometry");
+    W2L_CHECK_ARG(pad_mode != 1 || (pad_l < d->T && pad_r < d->T), "bn_act_fwd: reflect pad (%d,%d) needs pad < T=%d",
+                  pad_l, pad_r, d->T);
+    const uint32_t thresh = (uint32_t)(d->drop_p * 65536.f);
+    const float inv_keep = 1.f / (1.f - d->drop_p);
+    const int blocks = elementwise_blocks((int64_t)d->N * out_rows * (d->C / 8));
+    if (d->y_f32)
+        hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d,
+                           (bf16_raw*)out_hi, (bf16_raw*)out_lo, out_rows, pad_l, pad_r, pad_mode, thresh, inv_keep);
+    else
+        hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d,
+                           (bf16_raw*)out_hi, (bf16_raw*)out_lo, out_rows, pad_l, pad_r, pad_mode, thresh, inv_keep);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int w2l_bn_bwd_blocks(int N, int T, int C) {
+    (void)C;
+    return (int)(((int64_t)N * T + BWD_ROWS_PER_BLOCK - 1) / BWD_ROWS_PER_BLOCK);
+}
+
+#define W2L_DISPATCH_BWD(KERNEL, ...)                                                                      \
+    do {                                                                                                   \
+        if (d->y_f32 && g1->f32) hipLaunchKernelGGL((KERNEL<true, true>), __VA_ARGS__);                    \
+        else if (d->y_f32) hipLaunchKernelGGL((KERNEL<true, false>), __VA_ARGS__);                         \
+        else if (g1->f32) hipLaunchKernelGGL((KERNEL<false, true>), __VA_ARGS__);                          \
+        else hipLaunchKernelGGL((KERNEL<false, false>), __VA_ARGS__);                                      \
+    } while (0)
+
+extern "C" int w2l_bn_act_bwd_reduce(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2,
+                                     float* partial, void* stream) {
+    if (int e = check_desc(d, "bn_act_bwd_reduce")) return e;
+    W2L_CHECK_ARG(g1 && g1->dxp && partial, "bn_act_bwd_reduce: null pointer");
+    W2L_CHECK_ARG(!g2 || g2->f32 == g1->f32, "bn_act_bwd_reduce: gradient sources must share a dtype");
+    const int G = d->C / 8;
+    W2L_CHECK_ARG(G <= 256, "bn_act_bwd_reduce: C too large");
+    const int RPB = 256 / G;
+    const size_t lds = (size_t)RPB * 3 * d->C * sizeof(float);
+    const int blocks = w2l_bn_bwd_blocks(d->N, d->T, d->C);
+    const float inv_keep = 1.f / (1.f - d->drop_p);
+    w2l_gradsrc_t g2v = g2 ? *g2 : *g1;
+    W2L_DISPATCH_BWD(bn_act_bwd_reduce_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, *d, *g1, g2v,
+                     g2 ? 1 : 0, partial, inv_keep);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int w2l_bn_bwd_finalize(const float* partial, int nblocks, int C, float* sums, void* stream) {
+    W2L_CHECK_ARG(partial && sums && nblocks > 0 && C > 0, "bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((4 * C + 127) / 128), dim3(128), 0, (hipStream_t)stream, partial,
+                       nblocks, C, sums);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int w2l_bn_act_bwd_apply(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2,
+                                    const float* sums, void* dy_hi, void* dy_lo, int halo_b, int halo_a, void* dy2_hi,
+                                    void* dy2_lo, int halo2_b, int halo2_a, void* stream) {
+    if (int e = check_desc(d, "bn_act_bwd_apply")) return e;
+    W2L_CHECK_ARG(g1 && g1->dxp && dy_hi, "bn_act_bwd_apply: null pointer");
+    W2L_CHECK_ARG(!d->mean || sums, "bn_act_bwd_apply: BatchNorm backward needs the reduced sums");
+    W2L_CHECK_ARG(!g2 || g2->f32 == g1->f32, "bn_act_bwd_apply: gradient sources must share a dtype");
+    W2L_CHECK_ARG(halo_b >= 0 && halo_a >= 0 && halo2_b >= 0 && halo2_a >= 0, "bn_act_bwd_apply: negative halo");
+    const int hbm = halo_b > halo2_b ? halo_b : halo2_b, ham = halo_a > halo2_a ? halo_a : halo2_a;
+    if (!dy2_hi) { halo2_b = 0; halo2_a = 0; }
+    const int U = (dy2_hi ? hbm : halo_b) + d->T + (dy2_hi ? ham : halo_a);
+    const int blocks = elementwise_blocks((int64_t)d->N * U * (d->C / 8));
+    const float inv_keep = 1.f / (1.f - d->drop_p);
+    w2l_gradsrc_t g2v = g2 ? *g2 : *g1;
+    W2L_DISPATCH_BWD(bn_act_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d, *g1, g2v, g2 ? 1 : 0,
+                     sums, (bf16_raw*)dy_hi, (bf16_raw*)dy_lo, halo_b, halo_a, (bf16_raw*)dy2_hi, (bf16_raw*)dy2_lo,
+                     halo2_b, halo2_a, inv_keep);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,58 @@
+// Shared device/host helpers for the gfx950 (MI355X / CDNA4) kernels of the
+// Wav2Letter / Jasper fwd + CTC + bwd hot path.  gfx950 only: 64-wide waves,
+// v_mfma_f32_16x16x32_bf16, global_load_lds_dwordx4, ds_read_b64_tr_b16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+typedef unsigned short bf16_raw;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+
+#define W2L_WAVE 64
+
+__device__ __forceinline__ float bf16_bits_to_f32(bf16_raw v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_raw f32_to_bf16_bits(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return __builtin_bit_cast(unsigned short, b);
+}
+// hi/lo split used by the "split-bf16" (near-fp32) mode: f ~= hi + lo, |f-hi-lo| <= 2^-17 |f|
+__device__ __forceinline__ void f32_split_bf16(float f, bf16_raw& hi, bf16_raw& lo) {
+    hi = f32_to_bf16_bits(f);
+    lo = f32_to_bf16_bits(f - bf16_bits_to_f32(hi));
+}
+
+// ---- error reporting across the C ABI (no exceptions, no exit) ----
+void w2l_set_error(const char* fmt, ...);
+#define W2L_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            w2l_set_error(__VA_ARGS__);          \
+            return 1;                            \
+        }                                        \
+    } while (0)
+#define W2L_CHECK_HIP(expr)                                                             \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            w2l_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return (int)_e;                                                             \
+        }                                                                               \
+    } while (0)
+#define W2L_CHECK_LAUNCH() W2L_CHECK_HIP(hipGetLastError())
+
+// raise a kernel's dynamic-LDS limit to the full 160 KiB of a gfx950 CU (idempotent, cheap)
+hipError_t w2l_allow_big_lds(const void* kernel);
+
+// XCD-aware bijective block remap (8 XCDs, round-robin dispatch): consecutive
+// logical tiles land on the same XCD so they share that XCD's private L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}

@@ -1,0 +1,254 @@
+// Conv1d forward / data-gradient as an implicit GEMM on CDNA4 MFMA (gfx950).
+//
+//   y[n][t][co] (+)= bias[co] + sum_{kw} sum_{ci} w[kw][co][ci] * xp[n][t*s + kw*d][ci]
+//
+// GEMM view: M = co (A = weights, K-contiguous), N = t (B = activations,
+// K-contiguous because activations are channels-last), K = (kw, ci).
+// The B operand is never materialised (no im2col): for one 64-channel chunk a
+// block stages ONE time window of (BN-1)*s + (Kw-1)*d + 1 rows in LDS and every
+// tap kw reads it at a row offset kw*d, so activation traffic is amortised over
+// the Kw taps.  Weights stream one [BM x 64] tile per (chunk, tap) step.
+// Both tiles are filled by LDS-DMA (global_load_lds_dwordx4), double-buffered,
+// with the 16-byte-chunk XOR swizzle applied on the *source* address and on the
+// ds_read_b128 address (the LDS image itself is lane-linear).
+//
+// Replaces nn.Conv1d at wav2letter.py:35-36,42 / jasper.py:96-105,127 (forward) and
+// its autograd data gradient.  Padding is physical: the producer kernel writes the
+// reflect (wav2letter.py:28-34) or zero halo, so the hot loop has no padding logic.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;                 // channels per K chunk (128-byte LDS rows)
+constexpr int ROWB = BK * 2;           // bytes per LDS row
+
+struct IgemmParams {
+    const bf16_raw* x;
+    const bf16_raw* w;
+    void* y;
+    const float* bias;
+    float* stats;
+    int64_t x_rows_per_utt;   // x_bstride / Cin
+    int64_t x_max_row;        // last readable flat row
+    int N, Cin, Cout, Tout, Kw, stride, dil;
+    int tiles_t, ncols, xrows_lds;
+    int y_f32, accumulate;
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmParams p) {
+    static_assert(BM == 128 && BN == 128, "2x2 waves of 64x64");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile / p.ncols;
+    const int col = tile - tm * p.ncols;
+    const int n = col / p.tiles_t;
+    const int tt = col - n * p.tiles_t;
+    const int m0 = tm * BM;
+    const int t0 = tt * BN;
+
+    const int s = p.stride, d = p.dil, Kw = p.Kw, Cin = p.Cin;
+    const int xrows = p.xrows_lds;                 // multiple of 8
+    char* wbuf0 = smem;
+    char* wbuf1 = smem + BM * ROWB;
+    char* xbuf0 = smem + 2 * BM * ROWB;
+    char* xbuf1 = xbuf0 + xrows * ROWB;
+
+    const int64_t xrow0 = (int64_t)n * p.x_rows_per_utt + (int64_t)t0 * s;
+
+    // ---- staging helpers (each wave-instruction writes 8 LDS rows = 1 KiB) ----
+    const int srow = lane >> 3;                    // row within the 8-row group
+    const int schunk = lane & 7;                   // LDS chunk this lane fills
+    const int gchunk = schunk ^ srow;              // source chunk (rows are 8-aligned per group: row&7 == srow)
+    auto stage_w = [&](char* dst, int kw, int c) {
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i) {        // 4 groups per wave
+            const int grp = wave * (BM / 32) + i;
+            int co = m0 + grp * 8 + srow;
+            co = co < p.Cout ? co : p.Cout - 1;
+            const bf16_raw* src = p.w + ((int64_t)kw * p.Cout + co) * Cin + c * BK + gchunk * 8;
+            glds16(src, dst + grp * 1024);
+        }
+    };
+    auto stage_x = [&](char* dst, int c) {
+        const int ngrp = xrows >> 3;
+        for (int grp = wave; grp < ngrp; grp += 4) {
+            int64_t r = xrow0 + grp * 8 + srow;
+            r = r < p.x_max_row ? r : p.x_max_row;
+            const bf16_raw* src = p.x + r * Cin + c * BK + gchunk * 8;
+            glds16(src, dst + grp * 1024);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = Cin / BK;
+    const int nsteps = nchunks * Kw;
+
+    // per-lane read offsets
+    const int fr = lane & 15, fq = lane >> 4;
+    int a_off[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) a_off[mi] = (wm * 64 + mi * 16 + fr) * ROWB;
+    const int a_sw0 = ((fq) ^ (fr & 7)) << 4;          // k-substep 0: chunk fq
+    const int a_sw1 = ((4 + fq) ^ (fr & 7)) << 4;      // k-substep 1: chunk 4+fq
+    int b_row[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) b_row[ni] = (wn * 64 + ni * 16 + fr) * s;
+
+    stage_x(xbuf0, 0);
+    stage_w(wbuf0, 0, 0);
+
+    int kw = 0, c = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // prefetch the next step's tiles into the other buffers
+        int kw_n = kw + 1, c_n = c;
+        if (kw_n == Kw) { kw_n = 0; c_n = c + 1; }
+        if (step + 1 < nsteps) {
+            stage_w((step & 1) ? wbuf0 : wbuf1, kw_n, c_n);
+            if (kw_n == 0) stage_x((c_n & 1) ? xbuf1 : xbuf0, c_n);
+        }
+        const char* wb = (step & 1) ? wbuf1 : wbuf0;
+        const char* xb = (c & 1) ? xbuf1 : xbuf0;
+        const int shift = kw * d;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                a[mi] = *reinterpret_cast<const bf16x8*>(wb + a_off[mi] + (ks ? a_sw1 : a_sw0));
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int j = b_row[ni] + shift;
+                b[ni] = *reinterpret_cast<const bf16x8*>(xb + j * ROWB + (((ks * 4 + fq) ^ (j & 7)) << 4));
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        kw = kw_n;
+        c = c_n;
+    }
+
+    // ---- epilogue: bias, optional accumulate, store, BatchNorm partial statistics ----
+    // acc[mi][ni][r] = y[co = m0 + wm*64 + mi*16 + fq*4 + r][t = t0 + wn*64 + ni*16 + fr]
+    const int Cout = p.Cout, Tout = p.Tout;
+    float s1[4][4], s2[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int co = m0 + wm * 64 + mi * 16 + fq * 4;
+        const bool co_ok = co < Cout;
+        f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias && co_ok) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[mi][r] = 0.f; s2[mi][r] = 0.f; }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int t = t0 + wn * 64 + ni * 16 + fr;
+            const bool ok = co_ok && t < Tout;
+            f32x4 v = acc[mi][ni] + bias4;
+            const int64_t off = ((int64_t)n * Tout + t) * Cout + co;
+            if (ok) {
+                if (p.y_f32) {
+                    float* yp = reinterpret_cast<float*>(p.y) + off;
+                    if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yp);
+                    *reinterpret_cast<f32x4*>(yp) = v;
+                } else {
+                    u16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = f32_to_bf16_bits(v[r]);
+                    *reinterpret_cast<u16x4*>(reinterpret_cast<bf16_raw*>(p.y) + off) = o;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s1[mi][r] += v[r]; s2[mi][r] += v[r] * v[r]; }
+            }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();                               // main-loop LDS is dead from here
+        float* red = reinterpret_cast<float*>(smem);   // [2 wn][2][BM]
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = s1[mi][r], b = s2[mi][r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+                    a += __shfl_xor(a, m, 64);
+                    b += __shfl_xor(b, m, 64);
+                }
+                if (fr == 0) {
+                    const int cl = wm * 64 + mi * 16 + fq * 4 + r;
+                    red[(wn * 2 + 0) * BM + cl] = a;
+                    red[(wn * 2 + 1) * BM + cl] = b;
+                }
+            }
+        __syncthreads();
+        if (tid < BM && m0 + tid < Cout) {
+            float* dst = p.stats + (int64_t)col * 2 * Cout;
+            dst[m0 + tid] = red[0 * BM + tid] + red[2 * BM + tid];
+            dst[Cout + m0 + tid] = red[1 * BM + tid] + red[3 * BM + tid];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int w2l_conv_stat_tiles(int N, int Tout) { return N * ((Tout + 127) / 128); }
+
+extern "C" int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y,
+                                int y_f32, int accumulate, const float* bias, float* stats_partial, int N, int Cin,
+                                int Cout, int Tout, int Kw, int stride, int dil, void* stream) {
+    W2L_CHECK_ARG(xp && w && y, "conv1d_igemm: null pointer");
+    W2L_CHECK_ARG(N > 0 && Tout > 0 && Kw > 0 && stride > 0 && dil > 0, "conv1d_igemm: bad sizes");
+    W2L_CHECK_ARG(Cin % 64 == 0 && Cin > 0, "conv1d_igemm: Cin=%d must be a positive multiple of 64", Cin);
+    W2L_CHECK_ARG(Cout % 64 == 0 && Cout > 0, "conv1d_igemm: Cout=%d must be a positive multiple of 64", Cout);
+    W2L_CHECK_ARG(x_bstride % Cin == 0, "conv1d_igemm: x_bstride must be a multiple of Cin");
+    W2L_CHECK_ARG(!(accumulate && !y_f32), "conv1d_igemm: accumulate needs fp32 output");
+    constexpr int BM = 128, BN = 128;
+    IgemmParams p;
+    p.x = (const bf16_raw*)xp;
+    p.w = (const bf16_raw*)w;
+    p.y = y;
+    p.bias = bias;
+    p.stats = stats_partial;
+    p.x_rows_per_utt = x_bstride / Cin;
+    p.x_max_row = x_rows_total - 1;
+    p.N = N; p.Cin = Cin; p.Cout = Cout; p.Tout = Tout; p.Kw = Kw; p.stride = stride; p.dil = dil;
+    p.tiles_t = (Tout + BN - 1) / BN;
+    p.ncols = N * p.tiles_t;
+    const int xr = (BN - 1) * stride + (Kw - 1) * dil + 1;
+    p.xrows_lds = (xr + 7) & ~7;
+    p.y_f32 = y_f32; p.accumulate = accumulate;
+    // the last valid output row must only need rows that exist in the padded buffer
+    const int64_t need = (int64_t)(N - 1) * p.x_rows_per_utt + (int64_t)(Tout - 1) * stride + (int64_t)(Kw - 1) * dil;
+    W2L_CHECK_ARG(need <= p.x_max_row, "conv1d_igemm: padded input too small (need row %lld, have %lld)",
+                  (long long)need, (long long)p.x_max_row);
+    const int tiles_m = (Cout + BM - 1) / BM;
+    const size_t lds = 2 * BM * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
+    W2L_CHECK_ARG(lds <= 160 * 1024, "conv1d_igemm: window of %d rows does not fit LDS", p.xrows_lds);
+    auto kern = conv_igemm_kernel<BM, BN>;
+    W2L_CHECK_HIP(w2l_allow_big_lds((const void*)kern));
+    dim3 grid(tiles_m * p.ncols), block(256);
+    hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, p);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}

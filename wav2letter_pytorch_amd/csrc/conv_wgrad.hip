@@ -1,0 +1,228 @@
+// Conv1d weight gradient as an MFMA GEMM whose reduction runs over time (gfx950).
+//
+//   dw[kw][co][ci] (+)= sum_{n,t} dy[n][t][co] * xp[n][t*s + kw*d][ci]
+//
+// GEMM view per tap kw: M = co, N = ci, K = (n, t).  Both operands are
+// channels-last, i.e. the reduction index t is the SLOW axis of both tiles, so
+// the MFMA fragments (8 consecutive k per lane) are column reads of the LDS
+// images: they are fetched with ds_read_b64_tr_b16, CDNA4's transposing LDS
+// read, from row-major [t][channel] tiles that LDS-DMA fills straight from HBM.
+// One block owns a [128 co x 128 ci] tile of one tap and a slice of the (n,t)
+// range (split-K); partial tiles are combined with fp32 atomics.
+//
+// Replaces the weight-gradient half of aten::convolution_backward for the
+// nn.Conv1d call sites wav2letter.py:35-36,42 / jasper.py:96-105,127.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;       // co per block
+constexpr int BNC = 128;      // ci per block
+constexpr int BT = 64;        // t rows per K step
+constexpr int ROWB = 256;     // bytes per LDS row (128 bf16)
+
+struct WgradParams {
+    const bf16_raw* dy;
+    const bf16_raw* x;
+    float* dw;
+    int64_t dy_rows_per_utt;  // dy_bstride / Cout
+    int64_t x_rows_per_utt;
+    int64_t x_max_row;
+    int N, Cin, Cout, Tout, Kw, stride, dil;
+    int tiles_m, tiles_n, tsteps, total_steps, steps_per_split, atomic;
+    int xrows_lds;
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
+}
+
+// swizzle key of an LDS row: spreads the 8 rows one tr-read half-wave touches
+// (r..r+3 and r+8..r+11) over the 8 aligned 32-byte column pairs of a bank row.
+__device__ __forceinline__ int row_key(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+
+__device__ __forceinline__ bf16x4 tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // blockIdx.x -> (tap, ci tile, co tile); neighbouring blocks share dy / x panels through L2
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile % p.tiles_m;
+    tile /= p.tiles_m;
+    const int tn = tile % p.tiles_n;
+    const int kw = tile / p.tiles_n;
+    const int split = blockIdx.y;
+    const int m0 = tm * BM, c0 = tn * BNC;
+    const int s = p.stride;
+    const int shift = kw * p.dil;
+    const int xrows = p.xrows_lds;                 // (BT-1)*s + 1 rounded up to 4
+
+    char* abuf0 = smem;                            // dy tile  [BT][128 co]
+    char* abuf1 = smem + BT * ROWB;
+    char* bbuf0 = smem + 2 * BT * ROWB;            // x window [xrows][128 ci]
+    char* bbuf1 = bbuf0 + xrows * ROWB;
+
+    // staging: one wave-instruction fills 4 rows of 256 B
+    const int srow = lane >> 4;                    // 0..3
+    const int schunk = lane & 15;                  // LDS 16-byte chunk
+    auto stage = [&](char* adst, char* bdst, int step) {
+        const int n = step / p.tsteps;
+        const int t0 = (step - n * p.tsteps) * BT;
+        // dy rows t0..t0+63 (rows >= Tout are zero by contract)
+        const bf16_raw* abase = p.dy + ((int64_t)n * p.dy_rows_per_utt + t0) * p.Cout;
+#pragma unroll
+        for (int i = 0; i < BT / 16; ++i) {
+            const int grp = wave * (BT / 16) + i;
+            const int r = grp * 4 + srow;
+            const int g = schunk ^ (row_key(r) << 1);
+            int co = m0 + g * 8;
+            co = co < p.Cout ? co : p.Cout - 8;
+            glds16(abase + (int64_t)r * p.Cout + co, adst + grp * 1024);
+        }
+        const int64_t xrow0 = (int64_t)n * p.x_rows_per_utt + (int64_t)t0 * s + shift;
+        const int ngrp = xrows >> 2;
+        for (int grp = wave; grp < ngrp; grp += 4) {
+            const int r = grp * 4 + srow;
+            const int g = schunk ^ (row_key(r) << 1);
+            int64_t fr = xrow0 + r;
+            fr = fr < p.x_max_row ? fr : p.x_max_row;
+            int ci = c0 + g * 8;
+            ci = ci < p.Cin ? ci : p.Cin - 8;
+            glds16(p.x + fr * p.Cin + ci, bdst + grp * 1024);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int step_begin = split * p.steps_per_split;
+    int step_end = step_begin + p.steps_per_split;
+    if (step_end > p.total_steps) step_end = p.total_steps;
+
+    // tr-read lane geometry: within a 16-lane group, lane 4q+pp supplies row q, columns 4pp..4pp+3
+    const int l16 = lane & 15;
+    const int q = l16 >> 2, pp = l16 & 3;
+    const int kgrp = lane >> 4;                    // k octet of this lane group
+    // column byte offsets (before swizzle) for the A / B sub-tiles of this wave
+    int a_col[4], b_col[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_col[i] = (wm * 64 + i * 16 + pp * 4) * 2;
+        b_col[i] = (wn * 64 + i * 16 + pp * 4) * 2;
+    }
+
+    if (step_begin < step_end) stage(abuf0, bbuf0, step_begin);
+    for (int step = step_begin; step < step_end; ++step) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int par = (step - step_begin) & 1;
+        if (step + 1 < step_end) stage(par ? abuf0 : abuf1, par ? bbuf0 : bbuf1, step + 1);
+        const char* ab = par ? abuf1 : abuf0;
+        const char* bb = par ? bbuf1 : bbuf0;
+#pragma unroll
+        for (int ks = 0; ks < BT / 32; ++ks) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = ks * 32 + kgrp * 8 + h * 4 + q;      // t row this lane addresses
+                const int ra = k;
+                const int rb = k * s;
+                const int ka = row_key(ra) << 5, kb = row_key(rb) << 5;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bf16x4 va = tr_read(ab + ra * ROWB + (a_col[i] ^ ka));
+                    const bf16x4 vb = tr_read(bb + rb * ROWB + (b_col[i] ^ kb));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a[i][h * 4 + e] = va[e];
+                        b[i][h * 4 + e] = vb[e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: acc[mi][ni][r] = dw[kw][co = m0+wm*64+mi*16+fq*4+r][ci = c0+wn*64+ni*16+fr] ----
+    const int fr = lane & 15, fq = lane >> 4;
+    float* base = p.dw + (int64_t)kw * p.Cout * p.Cin;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int ci = c0 + wn * 64 + ni * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = m0 + wm * 64 + mi * 16 + fq * 4 + r;
+                if (co < p.Cout && ci < p.Cin) {
+                    float* dst = base + (int64_t)co * p.Cin + ci;
+                    if (p.atomic) atomicAdd(dst, acc[mi][ni][r]);
+                    else *dst = acc[mi][ni][r];
+                }
+            }
+        }
+}
+
+int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out) {
+    const int tiles = ((Cout + BM - 1) / BM) * ((Cin + BNC - 1) / BNC) * Kw;
+    const int tsteps = (Tout + BT - 1) / BT;
+    const int total = N * tsteps;
+    if (tsteps_out) *tsteps_out = tsteps;
+    // aim for >= 512 blocks (256 CUs x 2 resident blocks), keep >= 8 K-steps per block
+    int splits = 1;
+    while (tiles * splits < 512 && total / (splits * 2) >= 8) splits *= 2;
+    return splits;
+}
+
+}  // namespace
+
+extern "C" int w2l_wgrad_needs_zero(int N, int Cin, int Cout, int Tout, int Kw) {
+    return plan_splits(N, Cin, Cout, Tout, Kw, nullptr) > 1;
+}
+
+extern "C" int w2l_conv1d_wgrad(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride,
+                                int64_t x_rows_total, float* dw, int N, int Cin, int Cout, int Tout, int Kw,
+                                int stride, int dil, int accumulate, void* stream) {
+    W2L_CHECK_ARG(dy && xp && dw, "conv1d_wgrad: null pointer");
+    W2L_CHECK_ARG(N > 0 && Tout > 0 && Kw > 0 && stride > 0 && dil > 0, "conv1d_wgrad: bad sizes");
+    W2L_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && Cin > 0 && Cout > 0,
+                  "conv1d_wgrad: channels (%d,%d) must be positive multiples of 64", Cin, Cout);
+    W2L_CHECK_ARG(dy_bstride % Cout == 0 && x_bstride % Cin == 0, "conv1d_wgrad: batch strides must be whole rows");
+    WgradParams p;
+    p.dy = (const bf16_raw*)dy;
+    p.x = (const bf16_raw*)xp;
+    p.dw = dw;
+    p.dy_rows_per_utt = dy_bstride / Cout;
+    p.x_rows_per_utt = x_bstride / Cin;
+    p.x_max_row = x_rows_total - 1;
+    p.N = N; p.Cin = Cin; p.Cout = Cout; p.Tout = Tout; p.Kw = Kw; p.stride = stride; p.dil = dil;
+    p.tiles_m = (Cout + BM - 1) / BM;
+    p.tiles_n = (Cin + BNC - 1) / BNC;
+    const int splits = plan_splits(N, Cin, Cout, Tout, Kw, &p.tsteps);
+    p.total_steps = N * p.tsteps;
+    p.steps_per_split = (p.total_steps + splits - 1) / splits;
+    p.atomic = (splits > 1) || accumulate;
+    const int xr = (BT - 1) * stride + 1;
+    p.xrows_lds = (xr + 3) & ~3;
+    const size_t lds = 2 * BT * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
+    W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel));
+    dim3 grid(p.tiles_m * p.tiles_n * Kw, splits), block(256);
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, block, lds, (hipStream_t)stream, p);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}

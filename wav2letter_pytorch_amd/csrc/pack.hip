@@ -1,0 +1,151 @@
+// Layout kernels at the edges of the hot path (HBM-bound, tiled through LDS so
+// both the read and the write side are coalesced):
+//   * fp32 master weights -> bf16 operand layouts for the forward and dgrad GEMMs,
+//   * fp32 [N][C][T] spectrograms -> padded channels-last bf16,
+//   * fp32 classifier gradient -> zero-haloed bf16 + bias-gradient column sums.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void put_split(bf16_raw* hi, bf16_raw* lo, int64_t off, float v) {
+    bf16_raw h, l;
+    f32_split_bf16(v, h, l);
+    hi[off] = h;
+    if (lo) lo[off] = l;
+}
+
+__global__ void pack_weights_kernel(const float* w, int64_t s_co, int64_t s_ci, int64_t s_kw, int Cout, int Cin,
+                                    int Kw, int CoutP, int CinP, bf16_raw* fwd_hi, bf16_raw* fwd_lo,
+                                    bf16_raw* dgr_hi, bf16_raw* dgr_lo) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, kw = blockIdx.z;
+    // gather with the lane index on whichever source axis is denser
+    const bool ci_fast = s_ci <= s_co;
+    for (int j = ty; j < 32; j += 8) {
+        const int co = ci_fast ? co0 + j : co0 + tx;
+        const int ci = ci_fast ? ci0 + tx : ci0 + j;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) v = w[co * s_co + ci * s_ci + kw * s_kw];
+        if (ci_fast) tile[j][tx] = v; else tile[tx][j] = v;          // tile[co_l][ci_l]
+    }
+    __syncthreads();
+    if (fwd_hi) {
+        for (int j = ty; j < 32; j += 8) {
+            const int co = co0 + j, ci = ci0 + tx;
+            if (co < CoutP && ci < CinP) put_split(fwd_hi, fwd_lo, ((int64_t)kw * CoutP + co) * CinP + ci, tile[j][tx]);
+        }
+    }
+    if (dgr_hi) {
+        for (int j = ty; j < 32; j += 8) {
+            const int ci = ci0 + j, co = co0 + tx;
+            if (co < CoutP && ci < CinP)
+                put_split(dgr_hi, dgr_lo, ((int64_t)(Kw - 1 - kw) * CinP + ci) * CoutP + co, tile[tx][j]);
+        }
+    }
+}
+
+// padded row r of an utterance -> source frame t, or -1 for a zero row
+__device__ __forceinline__ int pad_src_row(int r, int T, int pad_l, int pad_r, int pad_mode) {
+    int t = r - pad_l;
+    if (t >= 0 && t < T) return t;
+    if (pad_mode != 1 || t < -pad_l || t >= T + pad_r) return -1;
+    t = t < 0 ? -t : 2 * (T - 1) - t;               // ReflectionPad1d: mirror without repeating the edge
+    return (t >= 0 && t < T) ? t : -1;
+}
+
+__global__ void nct_to_ntc_kernel(const float* x, int C, int T, int CP, int R, int pad_l, int pad_r, int pad_mode,
+                                  const int32_t* lens, bf16_raw* out_hi, bf16_raw* out_lo) {
+    __shared__ float tile[32][33];                   // [c_l][r_l]
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32, n = blockIdx.z;
+    const int len = lens ? lens[n] : T;
+    const int r = r0 + tx;
+    const int t = r < R ? pad_src_row(r, T, pad_l, pad_r, pad_mode) : -1;
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j;
+        float v = 0.f;
+        if (t >= 0 && t < len && c < C) v = x[((int64_t)n * C + c) * T + t];
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int rr = r0 + j, c = c0 + tx;
+        if (rr < R && c < CP) put_split(out_hi, out_lo, ((int64_t)n * R + rr) * CP + c, tile[tx][j]);
+    }
+}
+
+__global__ void pad_cast_kernel(const float* g, int T, int C, int CP, int R, int halo_b, bf16_raw* out_hi,
+                                bf16_raw* out_lo, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CP);
+        const int64_t row = i / CP;
+        const int r = (int)(row % R);
+        const int64_t n = row / R;
+        const int t = r - halo_b;
+        float v = 0.f;
+        if (t >= 0 && t < T && c < C) v = g[(n * T + t) * C + c];
+        put_split(out_hi, out_lo, i, v);
+    }
+}
+
+__global__ void colsum_kernel(const float* g, int64_t rows, int C, int CP, float* colsum) {
+    const int c = blockIdx.x;
+    float s = 0.f;
+    if (c < C)
+        for (int64_t r = threadIdx.x; r < rows; r += blockDim.x) s += g[r * C + c];
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) colsum[c] = red[0];
+}
+
+}  // namespace
+
+extern "C" int w2l_pack_weights(const float* w, int64_t s_co, int64_t s_ci, int64_t s_kw, int Cout, int Cin, int Kw,
+                                int CoutP, int CinP, void* w_fwd_hi, void* w_fwd_lo, void* w_dgr_hi, void* w_dgr_lo,
+                                void* stream) {
+    W2L_CHECK_ARG(w && (w_fwd_hi || w_dgr_hi), "pack_weights: null pointer");
+    W2L_CHECK_ARG(Cout > 0 && Cin > 0 && Kw > 0 && CoutP >= Cout && CinP >= Cin, "pack_weights: bad sizes");
+    W2L_CHECK_ARG(!(w_fwd_lo && !w_fwd_hi) && !(w_dgr_lo && !w_dgr_hi), "pack_weights: lo without hi");
+    dim3 grid((CinP + 31) / 32, (CoutP + 31) / 32, Kw), block(32, 8);
+    hipLaunchKernelGGL(pack_weights_kernel, grid, block, 0, (hipStream_t)stream, w, s_co, s_ci, s_kw, Cout, Cin, Kw,
+                       CoutP, CinP, (bf16_raw*)w_fwd_hi, (bf16_raw*)w_fwd_lo, (bf16_raw*)w_dgr_hi, (bf16_raw*)w_dgr_lo);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int w2l_nct_to_ntc(const float* x, int N, int C, int T, int CP, int pad_l, int pad_r, int pad_mode,
+                              const int32_t* lens, void* out_hi, void* out_lo, void* stream) {
+    W2L_CHECK_ARG(x && out_hi, "nct_to_ntc: null pointer");
+    W2L_CHECK_ARG(N > 0 && C > 0 && T > 0 && CP >= C && pad_l >= 0 && pad_r >= 0, "nct_to_ntc: bad sizes");
+    W2L_CHECK_ARG(pad_mode != 1 || (pad_l < T && pad_r < T), "nct_to_ntc: reflect padding (%d,%d) needs pad < T=%d",
+                  pad_l, pad_r, T);
+    const int R = pad_l + T + pad_r;
+    dim3 grid((R + 31) / 32, (CP + 31) / 32, N), block(32, 8);
+    hipLaunchKernelGGL(nct_to_ntc_kernel, grid, block, 0, (hipStream_t)stream, x, C, T, CP, R, pad_l, pad_r, pad_mode,
+                       lens, (bf16_raw*)out_hi, (bf16_raw*)out_lo);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int w2l_pad_cast(const float* g, int N, int T, int C, int CP, int halo_b, int halo_a, void* out_hi,
+                            void* out_lo, float* colsum, void* stream) {
+    W2L_CHECK_ARG(g && out_hi, "pad_cast: null pointer");
+    W2L_CHECK_ARG(N > 0 && T > 0 && C > 0 && CP >= C && halo_b >= 0 && halo_a >= 0, "pad_cast: bad sizes");
+    const int R = halo_b + T + halo_a;
+    const int64_t total = (int64_t)N * R * CP;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pad_cast_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, T, C, CP, R, halo_b,
+                       (bf16_raw*)out_hi, (bf16_raw*)out_lo, total);
+    W2L_CHECK_LAUNCH();
+    if (colsum) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(CP), dim3(256), 0, (hipStream_t)stream, g, (int64_t)N * T, C, CP, colsum);
+        W2L_CHECK_LAUNCH();
+    }
+    return 0;
+}

@@ -1,0 +1,117 @@
+"""Greedy CTC decoder + CER/WER (reference: decoder.py:11-145).
+
+The per-frame argmax (torch.max(probs, 2), decoder.py:136) runs as a HIP kernel
+(w2l_argmax: ties -> lowest index); ONE device-to-host copy of the int32 index matrix
+replaces the reference's per-frame ``.item()`` calls (decoder.py:108,111); repeat/blank
+collapsing is vectorised on the host.  Edit distance is the C routine
+w2l_levenshtein_host (python-Levenshtein is not a dependency).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+from .data import label_sets
+
+
+def _edit_distance(a, b) -> int:
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    b = np.ascontiguousarray(b, dtype=np.int32)
+    return int(lib.w2l_levenshtein_host(a.ctypes.data_as(C.c_void_p), len(a), b.ctypes.data_as(C.c_void_p), len(b)))
+
+
+class Decoder(object):
+    """Base decoder (decoder.py:11-83): label bookkeeping + WER/CER helpers."""
+
+    def __init__(self, labels, blank_index=0):
+        self.labels = label_sets.labels_map[labels] if type(labels) is str else labels
+        self.int_to_char = dict([(i, c) for (i, c) in enumerate(self.labels)])
+        self.blank_index = blank_index
+        space_index = len(self.labels)       # out-of-bounds index when there is no space label
+        if ' ' in self.labels:
+            space_index = list(self.labels).index(' ')
+        self.space_index = space_index
+
+    def wer(self, s1, s2):
+        """word-level edit distance (decoder.py:31-49)"""
+        vocab = {}
+        w1 = [vocab.setdefault(w, len(vocab)) for w in s1.split()]
+        w2 = [vocab.setdefault(w, len(vocab)) for w in s2.split()]
+        return _edit_distance(w1, w2)
+
+    def cer(self, s1, s2):
+        """character-level edit distance with spaces removed (decoder.py:51-60)"""
+        s1, s2 = s1.replace(' ', ''), s2.replace(' ', '')
+        return _edit_distance([ord(c) for c in s1], [ord(c) for c in s2])
+
+    def cer_ratio(self, expected, predicted):
+        return self.cer(expected, predicted), len(expected.replace(' ', ''))
+
+    def wer_ratio(self, expected, predicted):
+        return self.wer(expected, predicted), len(expected.split())
+
+    def decode(self, probs, sizes=None):
+        raise NotImplementedError
+
+
+def argmax_indices(probs: torch.Tensor) -> torch.Tensor:
+    """int32 [N, T] argmax over the label axis on the device (first maximal index)."""
+    if not probs.is_cuda:
+        if not torch.cuda.is_available():
+            raise _lib.W2LError('GreedyDecoder needs the MI355X device (no CPU fallback)')
+        probs = probs.cuda()
+    p = probs.detach().contiguous().float()
+    n, t, c = p.shape
+    idx = torch.empty(n, t, dtype=torch.int32, device=p.device)
+    check(lib.w2l_argmax(ptr(p), n * t, c, ptr(idx), stream_ptr()), 'w2l_argmax')
+    return idx
+
+
+class GreedyDecoder(Decoder):
+    def __init__(self, labels, blank_index=0):
+        super(GreedyDecoder, self).__init__(labels, blank_index)
+
+    def process_string(self, sequence, size, remove_repetitions=False):
+        """decoder.py:104-119 for one index sequence already on the host."""
+        seq = np.asarray(sequence[:size].cpu() if torch.is_tensor(sequence) else sequence[:size]).astype(np.int64)
+        keep = seq != self.blank_index
+        if remove_repetitions and len(seq) > 1:
+            keep[1:] &= seq[1:] != seq[:-1]
+        offsets = np.nonzero(keep)[0]
+        chars = []
+        for i in seq[keep]:
+            chars.append(' ' if i == self.space_index else self.int_to_char[int(i)])
+        return ''.join(chars), torch.IntTensor(offsets.astype(np.int32))
+
+    def convert_to_strings(self, sequences, sizes=None, remove_repetitions=False, return_offsets=False):
+        strings = []
+        offsets = [] if return_offsets else None
+        seqs = sequences.cpu().numpy() if torch.is_tensor(sequences) else np.asarray(sequences)
+        for x in range(len(seqs)):
+            seq_len = int(sizes[x]) if sizes is not None else len(seqs[x])
+            string, string_offsets = self.process_string(seqs[x], seq_len, remove_repetitions)
+            strings.append([string])
+            if return_offsets:
+                offsets.append([string_offsets])
+        if return_offsets:
+            return strings, offsets
+        return strings
+
+    def decode(self, probs, sizes=None, return_offsets=False):
+        """argmax decoding, repeats and blanks removed (decoder.py:121-145).
+        probs: [batch, seq_length, output_dim] (or 2-D for one utterance)."""
+        if len(probs.shape) == 2:
+            return self.decode(probs.unsqueeze(0), sizes, return_offsets)
+        idx = argmax_indices(probs)
+        if sizes is not None and torch.is_tensor(sizes):
+            sizes = sizes.detach().cpu()
+        host = idx.cpu()                      # the one D2H copy of the step
+        strings, offsets = self.convert_to_strings(host, sizes, remove_repetitions=True, return_offsets=True)
+        strings = [s[0] for s in strings]
+        if return_offsets:
+            return strings, offsets
+        return strings

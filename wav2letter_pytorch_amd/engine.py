@@ -1,0 +1,566 @@
+"""Step engine: runs the conv stack of Wav2Letter / Jasper forward and backward on the
+HIP kernels of libw2l_hip.so, one explicit pass each -- no autograd graph inside.
+
+The stack is a list of *units*; a unit is what the reference expresses as
+  Conv1dBlock (wav2letter.py:40-47): reflect-pad -> conv -> BN -> dropout -> clamp, or
+  one conv-BN(-act-dropout) step of a JasperBlock (jasper.py:379-419), the last step of a
+  block carrying the residual branch (1x1 conv + BN of the block input, add, ReLU).
+Activations between units live in HBM as channels-last bf16 buffers that are already
+padded for their consumer (reflect or zero halo), so the implicit-GEMM conv kernel does
+pure address arithmetic.  The backward pass walks the units in reverse, producing for
+each unit: BN/activation backward -> dy (zero-haloed) -> wgrad -> dgrad, and hands every
+weight gradient to an optional callback as soon as it exists (data-parallel all-reduce
+overlap, see distributed.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import BnActDesc, GradSrc, check, lib, ptr, stream_ptr
+
+ACT_NONE, ACT_CLAMP20, ACT_RELU = 0, 1, 2
+PAD_ZERO, PAD_REFLECT = 0, 1
+
+
+def roundup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def padded_channels(c: int) -> int:
+    return roundup(c, 64)
+
+
+# --------------------------------------------------------------------------- specs
+@dataclass
+class ConvSpec:
+    """One nn.Conv1d (+ optional BatchNorm1d) of the stack; tensors are the module's own
+    Parameters / buffers (state-dict names stay the reference's)."""
+    weight: torch.Tensor                  # logical [Cout, Cin, Kw]; physical [Kw, Cout, Cin] preferred
+    bias: Optional[torch.Tensor]
+    kernel: int
+    stride: int
+    dilation: int
+    pad_l: int
+    pad_r: int
+    pad_mode: int
+    bn_weight: Optional[torch.Tensor] = None
+    bn_bias: Optional[torch.Tensor] = None
+    running_mean: Optional[torch.Tensor] = None
+    running_var: Optional[torch.Tensor] = None
+    num_batches_tracked: Optional[torch.Tensor] = None
+    eps: float = 1e-3
+    momentum: float = 0.1
+    name: str = ''
+
+    @property
+    def has_bn(self) -> bool:
+        return self.bn_weight is not None
+
+    @property
+    def cout(self) -> int:
+        return self.weight.shape[0]
+
+    @property
+    def cin(self) -> int:
+        return self.weight.shape[1]
+
+    def params(self) -> List[torch.Tensor]:
+        out = [self.weight]
+        if self.bias is not None:
+            out.append(self.bias)
+        if self.has_bn:
+            out += [self.bn_weight, self.bn_bias]
+        return out
+
+
+@dataclass
+class UnitSpec:
+    main: ConvSpec
+    src: int                              # index of the activation the main conv reads
+    act: int = ACT_NONE
+    drop_p: float = 0.0
+    res: Optional[ConvSpec] = None        # residual branch conv (+BN) -- jasper.py:241-255,400-410
+    res_src: Optional[int] = None
+    mask_lens: bool = False               # zero frames t >= len before the next conv (jasper.py:116-119)
+
+
+@dataclass
+class Act:
+    """A padded channels-last activation buffer [N][pad_l + T + pad_r][CP]."""
+    hi: torch.Tensor
+    lo: Optional[torch.Tensor]
+    N: int
+    T: int
+    C: int
+    CP: int
+    pad_l: int
+    pad_r: int
+    pad_mode: int
+    lens: Optional[torch.Tensor] = None   # int32 [N] on device: frames t >= lens[n] are zero
+
+    @property
+    def rows(self) -> int:
+        return self.pad_l + self.T + self.pad_r
+
+
+@dataclass
+class _PackedW:
+    version: int
+    fwd_hi: torch.Tensor
+    fwd_lo: Optional[torch.Tensor]
+    dgr_hi: torch.Tensor
+    dgr_lo: Optional[torch.Tensor]
+    cinp: int
+    coutp: int
+
+
+@dataclass
+class _UnitCtx:
+    unit: UnitSpec
+    y: torch.Tensor = None
+    y2: Optional[torch.Tensor] = None
+    Tout: int = 0
+    scale: Optional[torch.Tensor] = None
+    shift: Optional[torch.Tensor] = None
+    mean: Optional[torch.Tensor] = None
+    invstd: Optional[torch.Tensor] = None
+    scale2: Optional[torch.Tensor] = None
+    shift2: Optional[torch.Tensor] = None
+    mean2: Optional[torch.Tensor] = None
+    invstd2: Optional[torch.Tensor] = None
+    mask: Optional[torch.Tensor] = None
+    seed: int = 0
+    offset: int = 0
+    out_index: int = 0
+    lens_out: Optional[torch.Tensor] = None
+    keep: list = field(default_factory=list)
+
+
+_pack_cache = {}
+_dropout_calls = 0
+
+
+def _phys_strides(w: torch.Tensor):
+    """element strides (s_co, s_ci, s_kw) of the logical [Cout,Cin,Kw] weight"""
+    return w.stride(0), w.stride(1), w.stride(2)
+
+
+def pack_weights(conv: ConvSpec, precise: bool, need_dgrad: bool = True) -> _PackedW:
+    """fp32 master weights -> bf16 GEMM operand layouts (cached per parameter version)."""
+    w = conv.weight
+    key = (id(w), precise)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit.version == w._version and hit.fwd_hi.device == w.device:
+        return hit
+    cout, cin, kw = w.shape
+    coutp, cinp = padded_channels(cout), padded_channels(cin)
+    dev = w.device
+    fwd_hi = torch.empty(kw, coutp, cinp, dtype=torch.bfloat16, device=dev)
+    dgr_hi = torch.empty(kw, cinp, coutp, dtype=torch.bfloat16, device=dev)
+    fwd_lo = torch.empty_like(fwd_hi) if precise else None
+    dgr_lo = torch.empty_like(dgr_hi) if precise else None
+    s_co, s_ci, s_kw = _phys_strides(w)
+    check(lib.w2l_pack_weights(ptr(w), s_co, s_ci, s_kw, cout, cin, kw, coutp, cinp, ptr(fwd_hi), ptr(fwd_lo),
+                               ptr(dgr_hi), ptr(dgr_lo), stream_ptr()), 'w2l_pack_weights')
+    pk = _PackedW(w._version, fwd_hi, fwd_lo, dgr_hi, dgr_lo, cinp, coutp)
+    _pack_cache[key] = pk
+    return pk
+
+
+def _padded_vec(v: Optional[torch.Tensor], cp: int, fill: float) -> Optional[torch.Tensor]:
+    """per-channel fp32 vector padded to CP (no copy when already that size)"""
+    if v is None:
+        return None
+    v = v.detach()
+    if v.dtype != torch.float32:
+        v = v.float()
+    if v.numel() == cp and v.is_contiguous():
+        return v
+    out = torch.full((cp,), fill, dtype=torch.float32, device=v.device)
+    out[: v.numel()] = v
+    return out
+
+
+def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw, stride, dil, precise):
+    """y = conv(x) through w2l_conv1d_igemm; split-bf16 (3 launches, fp32 accumulate) when precise."""
+    n = x.N
+    bstride = x.rows * x.CP
+    rows_total = n * x.rows - row_off
+    esz = 2
+
+    def xptr(t):
+        return C.c_void_p(t.data_ptr() + row_off * x.CP * esz)
+
+    st = stream_ptr()
+    if not precise:
+        check(lib.w2l_conv1d_igemm(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y), int(y.dtype == torch.float32), 0,
+                                   ptr(bias), ptr(stats), n, Cin, Cout, Tout, Kw, stride, dil, st), 'w2l_conv1d_igemm')
+        return
+    assert y.dtype == torch.float32
+    check(lib.w2l_conv1d_igemm(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y), 1, 0, ptr(bias), None, n, Cin, Cout,
+                               Tout, Kw, stride, dil, st), 'w2l_conv1d_igemm')
+    check(lib.w2l_conv1d_igemm(xptr(x.hi), bstride, rows_total, ptr(w_lo), ptr(y), 1, 1, None, None, n, Cin, Cout, Tout,
+                               Kw, stride, dil, st), 'w2l_conv1d_igemm')
+    check(lib.w2l_conv1d_igemm(xptr(x.lo), bstride, rows_total, ptr(w_hi), ptr(y), 1, 1, None, ptr(stats), n, Cin, Cout,
+                               Tout, Kw, stride, dil, st), 'w2l_conv1d_igemm')
+
+
+class StackEngine:
+    """Executes a list of UnitSpec.  ``precise`` selects the split-bf16 (near-fp32) mode used
+    for parity against the fp32 reference; the default is bf16 operands with fp32 accumulate."""
+
+    def __init__(self, units: Sequence[UnitSpec], head: ConvSpec, n_labels: int, precise: bool = False):
+        self.units = list(units)
+        self.head = head
+        self.n_labels = n_labels
+        self.precise = precise
+        self.grad_ready: Optional[Callable[[torch.Tensor, torch.Tensor], None]] = None
+
+    # ------------------------------------------------------------------ parameters
+    def parameters(self) -> List[torch.Tensor]:
+        out = []
+        for u in self.units:
+            out += u.main.params()
+            if u.res is not None:
+                out += u.res.params()
+        out += self.head.params()
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def _in_pad_for(self, act_index: int):
+        """padding the consumers of activation ``act_index`` need (max over consumers)"""
+        pl = pr = 0
+        mode = PAD_ZERO
+        convs = []
+        for u in self.units:
+            if u.src == act_index:
+                convs.append(u.main)
+            if u.res is not None and u.res_src == act_index:
+                convs.append(u.res)
+        if act_index == len(self.units):
+            convs.append(self.head)
+        for c in convs:
+            if c.pad_l > pl or c.pad_r > pr:
+                pl, pr = max(pl, c.pad_l), max(pr, c.pad_r)
+            if c.pad_l or c.pad_r:
+                mode = c.pad_mode
+        return pl, pr, mode
+
+    def forward(self, x: torch.Tensor, lens: Optional[torch.Tensor], training: bool, softmax_mode: int = 0):
+        """x fp32 [N, C, T] on device -> (out fp32 [N, T', n_labels], lens_out or None)."""
+        _lib.require_device(x)
+        global _dropout_calls
+        precise = self.precise
+        N, C0, T0 = x.shape
+        x = x.contiguous().float()
+        dev = x.device
+        st = stream_ptr
+        ctx = {'units': [], 'acts': [], 'training': training, 'x_shape': (N, C0, T0)}
+        lens_dev = None
+        if lens is not None and any(u.mask_lens for u in self.units):
+            lens_dev = lens.to(device=dev, dtype=torch.int32)
+        # ---- activation 0: the spectrogram, channels-last, padded for its consumers
+        pl, pr, mode = self._in_pad_for(0)
+        cp0 = padded_channels(C0)
+        a_hi = torch.empty(N, pl + T0 + pr, cp0, dtype=torch.bfloat16, device=dev)
+        a_lo = torch.empty_like(a_hi) if precise else None
+        check(lib.w2l_nct_to_ntc(ptr(x), N, C0, T0, cp0, pl, pr, mode, ptr(lens_dev), ptr(a_hi), ptr(a_lo), st()),
+              'w2l_nct_to_ntc')
+        acts: List[Act] = [Act(a_hi, a_lo, N, T0, C0, cp0, pl, pr, mode, lens_dev)]
+        cur_lens = lens_dev
+        cur_lens_f = lens_dev.float() if lens_dev is not None else None
+
+        for ui, u in enumerate(self.units):
+            uc = _UnitCtx(unit=u)
+            src = acts[u.src]
+            conv = u.main
+            y, stats, Tout = self._conv_forward(conv, src, need_stats=conv.has_bn and training)
+            uc.y, uc.Tout = y, Tout
+            coutp = y.shape[2]
+            if conv.has_bn:
+                uc.scale, uc.shift, uc.mean, uc.invstd = self._bn_finalize(conv, stats, N * Tout, coutp, training)
+            if u.res is not None:
+                rsrc = acts[u.res_src]
+                y2, stats2, Tout2 = self._conv_forward(u.res, rsrc, need_stats=u.res.has_bn and training)
+                if Tout2 != Tout or y2.shape != y.shape:
+                    raise ValueError('residual branch shape mismatch')
+                uc.y2 = y2
+                if u.res.has_bn:
+                    uc.scale2, uc.shift2, uc.mean2, uc.invstd2 = self._bn_finalize(u.res, stats2, N * Tout, coutp, training)
+            # length bookkeeping (jasper.py:109-112: true division, truncated at the next mask)
+            if u.mask_lens and cur_lens_f is not None:
+                cur_lens_f = (cur_lens_f + (conv.pad_l + conv.pad_r) - conv.dilation * (conv.kernel - 1) - 1) / conv.stride + 1
+                cur_lens = cur_lens_f.to(torch.int32)
+                uc.lens_out = cur_lens
+            # ---- BN-apply + dropout + activation -> padded input of the next conv
+            opl, opr, omode = self._in_pad_for(ui + 1)
+            out_hi = torch.empty(N, opl + Tout + opr, coutp, dtype=torch.bfloat16, device=dev)
+            out_lo = torch.empty_like(out_hi) if precise else None
+            p = u.drop_p if training else 0.0
+            if p > 0.0:
+                uc.mask = torch.empty(N * Tout * (coutp // 8), dtype=torch.uint8, device=dev)
+                uc.seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+                _dropout_calls += 1
+                uc.offset = _dropout_calls
+            d = self._desc(uc, N, Tout, coutp, p, uc.lens_out if u.mask_lens else None)
+            check(lib.w2l_bn_act_fwd(C.byref(d), ptr(out_hi), ptr(out_lo), opl + Tout + opr, opl, opr, omode, st()),
+                  'w2l_bn_act_fwd')
+            uc.out_index = ui + 1
+            acts.append(Act(out_hi, out_lo, N, Tout, conv.cout, coutp, opl, opr, omode,
+                            uc.lens_out if u.mask_lens else None))
+            ctx['units'].append(uc)
+
+        # ---- classifier (1x1 conv, bias, no BN) + (log_)softmax
+        last = acts[-1]
+        logits, _, Th = self._conv_forward(self.head, last, need_stats=False, force_f32=True)
+        out = torch.empty(N, Th, self.n_labels, dtype=torch.float32, device=dev)
+        check(lib.w2l_log_softmax_fwd(ptr(logits), N, Th, self.n_labels, logits.shape[2], softmax_mode, ptr(out), st()),
+              'w2l_log_softmax_fwd')
+        ctx['acts'] = acts
+        ctx['out'] = out
+        ctx['softmax_mode'] = softmax_mode
+        ctx['lens_out'] = cur_lens
+        return out, ctx
+
+    def _conv_forward(self, conv: ConvSpec, src: Act, need_stats: bool, force_f32: bool = False):
+        if src.pad_l < conv.pad_l or src.pad_r < conv.pad_r:
+            raise ValueError('activation buffer is not padded enough for its consumer')
+        pk = pack_weights(conv, self.precise)
+        if pk.cinp != src.CP:
+            raise ValueError(f'channel mismatch: conv expects {pk.cinp} padded channels, activation has {src.CP}')
+        N = src.N
+        Tp = src.T + conv.pad_l + conv.pad_r
+        Tout = (Tp - (conv.kernel - 1) * conv.dilation - 1) // conv.stride + 1
+        if Tout <= 0:
+            raise ValueError('input too short for this convolution')
+        f32 = self.precise or force_f32
+        y = torch.empty(N, Tout, pk.coutp, dtype=torch.float32 if f32 else torch.bfloat16, device=src.hi.device)
+        stats = None
+        if need_stats:
+            tiles = lib.w2l_conv_stat_tiles(N, Tout)
+            stats = torch.empty(tiles, 2, pk.coutp, dtype=torch.float32, device=src.hi.device)
+        bias = _padded_vec(conv.bias, pk.coutp, 0.0)
+        _igemm(src, src.pad_l - conv.pad_l, pk.fwd_hi, pk.fwd_lo, y, bias, stats, pk.cinp, pk.coutp, Tout, conv.kernel,
+               conv.stride, conv.dilation, self.precise)
+        return y, stats, Tout
+
+    def _bn_finalize(self, conv: ConvSpec, stats, count, cp, training):
+        dev = conv.weight.device
+        scale = torch.empty(cp, dtype=torch.float32, device=dev)
+        shift = torch.empty_like(scale)
+        mean = torch.empty_like(scale)
+        invstd = torch.empty_like(scale)
+        gamma = _padded_vec(conv.bn_weight, cp, 1.0)
+        beta = _padded_vec(conv.bn_bias, cp, 0.0)
+        rm, rv = conv.running_mean, conv.running_var
+        padded_running = rm is not None and rm.numel() != cp
+        if padded_running:
+            rm_p, rv_p = _padded_vec(rm, cp, 0.0).clone(), _padded_vec(rv, cp, 1.0).clone()
+        else:
+            rm_p, rv_p = rm, rv
+        if training:
+            ntiles = stats.shape[0]
+            check(lib.w2l_bn_finalize(ptr(stats), ntiles, cp, count, ptr(gamma), ptr(beta), conv.eps, conv.momentum,
+                                      ptr(rm_p), ptr(rv_p), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                                      stream_ptr()), 'w2l_bn_finalize')
+            if padded_running:
+                rm.copy_(rm_p[: rm.numel()])
+                rv.copy_(rv_p[: rv.numel()])
+            if conv.num_batches_tracked is not None:
+                conv.num_batches_tracked += 1
+        else:
+            check(lib.w2l_bn_finalize(None, 0, cp, 1, ptr(gamma), ptr(beta), conv.eps, conv.momentum, ptr(rm_p),
+                                      ptr(rv_p), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), stream_ptr()),
+                  'w2l_bn_finalize')
+        return scale, shift, mean, invstd
+
+    def _desc(self, uc: _UnitCtx, N, T, cp, p, lens) -> BnActDesc:
+        d = BnActDesc()
+        d.N, d.T, d.C = N, T, cp
+        d.y = uc.y.data_ptr()
+        d.y_f32 = int(uc.y.dtype == torch.float32)
+        for name in ('scale', 'shift', 'mean', 'invstd', 'scale2', 'shift2', 'mean2', 'invstd2'):
+            t = getattr(uc, name)
+            setattr(d, name, t.data_ptr() if t is not None else None)
+        d.y2 = uc.y2.data_ptr() if uc.y2 is not None else None
+        d.act = uc.unit.act
+        d.drop_p = float(p)
+        d.seed, d.offset = uc.seed, uc.offset
+        d.mask = uc.mask.data_ptr() if uc.mask is not None else None
+        d.lens = lens.data_ptr() if lens is not None else None
+        uc.keep.append(lens)
+        return d
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ctx, g_out: torch.Tensor):
+        """g_out: gradient wrt the (log_)softmax output [N, T', n_labels].  Returns the list of
+        parameter gradients in ``self.parameters()`` order."""
+        precise = self.precise
+        acts: List[Act] = ctx['acts']
+        out = ctx['out']
+        N, Th, L = out.shape
+        dev = out.device
+        st = stream_ptr
+        grads = {}
+        # ---- (log_)softmax backward -> classifier gradients
+        g_out = g_out.contiguous().float()
+        glog = torch.empty_like(out)
+        check(lib.w2l_log_softmax_bwd(ptr(g_out), ptr(out), N, Th, L, ctx['softmax_mode'], ptr(glog), st()),
+              'w2l_log_softmax_bwd')
+        head = self.head
+        pk = pack_weights(head, precise)
+        tail = roundup(Th, 64) - Th
+        dy_hi = torch.empty(N, Th + tail, pk.coutp, dtype=torch.bfloat16, device=dev)
+        dy_lo = torch.empty_like(dy_hi) if precise else None
+        colsum = torch.empty(pk.coutp, dtype=torch.float32, device=dev)
+        check(lib.w2l_pad_cast(ptr(glog), N, Th, L, pk.coutp, 0, tail, ptr(dy_hi), ptr(dy_lo), ptr(colsum), st()),
+              'w2l_pad_cast')
+        last = acts[-1]
+        self._wgrad(head, pk, dy_hi, dy_lo, 0, Th, last, grads)
+        if head.bias is not None:
+            grads[id(head.bias)] = colsum[: head.cout]
+            self._notify(head.bias, grads[id(head.bias)])
+        act_grads: List[List[tuple]] = [[] for _ in acts]
+        act_grads[len(acts) - 1].append(self._dgrad(head, pk, dy_hi, dy_lo, 0, last))
+
+        # ---- units in reverse
+        for uc in reversed(ctx['units']):
+            u = uc.unit
+            oi = uc.out_index
+            srcs = act_grads[oi]
+            if not srcs:
+                raise RuntimeError('activation without a gradient source')
+            if len(srcs) > 2:
+                raise NotImplementedError('more than two consumers of one activation')
+            a_out = acts[oi]
+            Tout, coutp = uc.Tout, a_out.CP
+            p = u.drop_p if (ctx['training'] and uc.mask is not None) else 0.0
+            d = self._desc(uc, N, Tout, coutp, p, uc.lens_out if u.mask_lens else None)
+            g1 = self._gsrc(srcs[0])
+            g2 = self._gsrc(srcs[1]) if len(srcs) > 1 else None
+            sums = None
+            if u.main.has_bn or (u.res is not None and u.res.has_bn):
+                nb = lib.w2l_bn_bwd_blocks(N, Tout, coutp)
+                partial = torch.empty(nb, 4, coutp, dtype=torch.float32, device=dev)
+                check(lib.w2l_bn_act_bwd_reduce(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(partial),
+                                                st()), 'w2l_bn_act_bwd_reduce')
+                sums = torch.empty(4, coutp, dtype=torch.float32, device=dev)
+                check(lib.w2l_bn_bwd_finalize(ptr(partial), nb, coutp, ptr(sums), st()), 'w2l_bn_bwd_finalize')
+            main, res = u.main, u.res
+            hb = (main.kernel - 1) * main.dilation
+            need_dx_main = self._needs_grad(u.src)
+            ha = max(hb, roundup(Tout, 64) - Tout)
+            dy_hi = torch.empty(N, hb + Tout + ha, coutp, dtype=torch.bfloat16, device=dev)
+            dy_lo = torch.empty_like(dy_hi) if precise else None
+            dy2_hi = dy2_lo = None
+            hb2 = ha2 = 0
+            if res is not None:
+                hb2 = (res.kernel - 1) * res.dilation
+                ha2 = max(hb2, roundup(Tout, 64) - Tout)
+                dy2_hi = torch.empty(N, hb2 + Tout + ha2, coutp, dtype=torch.bfloat16, device=dev)
+                dy2_lo = torch.empty_like(dy2_hi) if precise else None
+            check(lib.w2l_bn_act_bwd_apply(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(sums), ptr(dy_hi),
+                                           ptr(dy_lo), hb, ha, ptr(dy2_hi), ptr(dy2_lo), hb2, ha2, st()),
+                  'w2l_bn_act_bwd_apply')
+            # release the consumed gradient buffers early
+            act_grads[oi] = []
+            # BN parameter gradients: d beta = sum g, d gamma = sum g * xhat
+            if main.has_bn:
+                self._set(grads, main.bn_bias, sums[0, : main.cout])
+                self._set(grads, main.bn_weight, sums[1, : main.cout])
+            if res is not None and res.has_bn:
+                self._set(grads, res.bn_bias, sums[2, : res.cout])
+                self._set(grads, res.bn_weight, sums[3, : res.cout])
+            # main branch
+            pkm = pack_weights(main, precise)
+            src = acts[u.src]
+            self._wgrad(main, pkm, dy_hi, dy_lo, hb, Tout, src, grads)
+            if main.bias is not None:
+                if main.has_bn:      # sum(dy) == 0 identically under BatchNorm
+                    self._set(grads, main.bias, torch.zeros(main.cout, dtype=torch.float32, device=dev))
+                else:
+                    self._set(grads, main.bias, dy_hi[:, hb:hb + Tout, : main.cout].float().sum((0, 1)))
+            if need_dx_main:
+                act_grads[u.src].append(self._dgrad(main, pkm, dy_hi, dy_lo, hb, src))
+            if res is not None:
+                pkr = pack_weights(res, precise)
+                rsrc = acts[u.res_src]
+                self._wgrad(res, pkr, dy2_hi, dy2_lo, hb2, Tout, rsrc, grads)
+                if res.bias is not None:
+                    self._set(grads, res.bias, torch.zeros(res.cout, dtype=torch.float32, device=dev))
+                if self._needs_grad(u.res_src):
+                    act_grads[u.res_src].append(self._dgrad(res, pkr, dy2_hi, dy2_lo, hb2, rsrc))
+        return [grads.get(id(p)) for p in self.parameters()]
+
+    # ------------------------------------------------------------------ helpers
+    def _needs_grad(self, act_index: int) -> bool:
+        return act_index != 0          # the spectrogram needs no gradient in training (base_asr_models.py:78-85)
+
+    def _notify(self, param, grad):
+        if self.grad_ready is not None:
+            self.grad_ready(param, grad)
+
+    def _set(self, grads, param, grad):
+        grads[id(param)] = grad
+        self._notify(param, grad)
+
+    def _gsrc(self, s) -> GradSrc:
+        t, pl, pr, mode = s
+        g = GradSrc()
+        g.dxp = t.data_ptr()
+        g.f32 = int(t.dtype == torch.float32)
+        g.pad_l, g.pad_r, g.pad_mode = pl, pr, mode
+        return g
+
+    def _wgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, hb, Tout, src: Act, grads):
+        """dW through w2l_conv1d_wgrad, written in the parameter's own physical layout when possible."""
+        w = conv.weight
+        cout, cin, kw = w.shape
+        dev = w.device
+        N = src.N
+        direct = (pk.coutp == cout and pk.cinp == cin)
+        need_zero = bool(lib.w2l_wgrad_needs_zero(N, pk.cinp, pk.coutp, Tout, kw)) or self.precise
+        alloc = torch.zeros if need_zero else torch.empty
+        dw = alloc(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
+        row_off = src.pad_l - conv.pad_l
+        x_bstride = src.rows * src.CP
+        x_rows_total = N * src.rows - row_off
+        dy_bstride = dy_hi.shape[1] * dy_hi.shape[2]
+        st = stream_ptr()
+
+        def run(dy, x, acc):
+            check(lib.w2l_conv1d_wgrad(C.c_void_p(dy.data_ptr() + hb * pk.coutp * 2), dy_bstride,
+                                       C.c_void_p(x.data_ptr() + row_off * src.CP * 2), x_bstride, x_rows_total,
+                                       ptr(dw), N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, acc, st),
+                  'w2l_conv1d_wgrad')
+
+        if not self.precise:
+            run(dy_hi, src.hi, 0)
+        else:
+            run(dy_hi, src.hi, 1)
+            run(dy_hi, src.lo, 1)
+            run(dy_lo, src.hi, 1)
+        g = dw.permute(1, 2, 0)                     # logical [CoutP, CinP, Kw]
+        if not direct:
+            g = g[:cout, :cin, :]
+        self._set(grads, w, g)
+
+    def _dgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, hb, src: Act):
+        """dXpad (gradient wrt the conv's padded input) through the same implicit-GEMM kernel."""
+        if conv.stride != 1:
+            raise NotImplementedError('data gradient of a strided convolution (only the first layer is strided, '
+                                      'and the spectrogram needs no gradient)')
+        N = src.N
+        Tp = src.T + conv.pad_l + conv.pad_r
+        dev = dy_hi.device
+        dxp = torch.empty(N, Tp, pk.cinp, dtype=torch.float32 if self.precise else torch.bfloat16, device=dev)
+        rows = dy_hi.shape[1]
+        dyact = Act(dy_hi, dy_lo, N, rows, pk.coutp, pk.coutp, 0, 0, PAD_ZERO)
+        _igemm(dyact, 0, pk.dgr_hi, pk.dgr_lo, dxp, None, None, pk.coutp, pk.cinp, Tp, conv.kernel, 1, conv.dilation,
+               self.precise)
+        return (dxp, conv.pad_l, conv.pad_r, conv.pad_mode)

@@ -1,0 +1,130 @@
+"""Parameter holders with the reference's state-dict names, and the autograd bridge
+between a module tree and the StackEngine."""
+from __future__ import annotations
+
+import math
+import os
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .engine import ConvSpec, StackEngine
+
+
+def default_precision(cfg=None) -> str:
+    """'bf16' (bf16 operands, fp32 accumulate: the production mode) or 'fp32' (split-bf16,
+    three MFMA passes per product: the parity mode against the fp32 reference)."""
+    p = None
+    if cfg is not None:
+        try:
+            p = cfg.get('precision', None)
+        except Exception:
+            p = None
+    p = p or os.environ.get('W2L_PRECISION', 'bf16')
+    if p not in ('bf16', 'fp32'):
+        raise ValueError(f"precision must be 'bf16' or 'fp32', got {p!r}")
+    return p
+
+
+class Conv1d(nn.Module):
+    """Holds nn.Conv1d's parameters (wav2letter.py:35-36, jasper.py:96-105).  ``weight`` has the
+    logical shape [out, in/groups, k] of nn.Conv1d but is stored physically as [k, out, in]
+    (tap-major, channels contiguous): that is the layout the wgrad kernel writes and the
+    pack kernel reads coalesced.  state_dict() / load_state_dict() see the logical shape."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 init='torch_default'):
+        super().__init__()
+        k = kernel_size[0] if isinstance(kernel_size, (tuple, list)) else kernel_size
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = (k,)
+        self.stride = (stride,)
+        self.padding = (padding,)
+        self.dilation = (dilation,)
+        self.groups = groups
+        phys = torch.empty(k, out_channels, in_channels // groups)
+        self.weight = nn.Parameter(phys.permute(1, 2, 0))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters(init)
+
+    def reset_parameters(self, init='torch_default'):
+        # draw into a contiguous tensor so a given seed reproduces nn.Conv1d's values exactly
+        tmp = torch.empty(self.weight.shape)
+        if init == 'xavier_uniform':                      # jasper.py:29-36
+            nn.init.xavier_uniform_(tmp, gain=1.0)
+        else:                                             # nn.Conv1d default (wav2letter.py:35-36)
+            nn.init.kaiming_uniform_(tmp, a=math.sqrt(5))
+        with torch.no_grad():
+            self.weight.copy_(tmp)
+            if self.bias is not None:
+                fan_in = self.weight.shape[1] * self.weight.shape[2]
+                bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+                self.bias.copy_(torch.empty(self.bias.shape).uniform_(-bound, bound))
+
+    def extra_repr(self):
+        return (f'{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, '
+                f'padding={self.padding}, dilation={self.dilation}, bias={self.bias is not None}')
+
+    def forward(self, x):
+        raise RuntimeError('Conv1d is executed by the HIP step engine through its parent model')
+
+
+class BatchNorm1d(nn.Module):
+    """Holds nn.BatchNorm1d's parameters and buffers (wav2letter.py:37, jasper.py:363)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.affine = True
+        self.track_running_stats = True
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+    def extra_repr(self):
+        return f'{self.num_features}, eps={self.eps}, momentum={self.momentum}'
+
+    def forward(self, x):
+        raise RuntimeError('BatchNorm1d is executed by the HIP step engine through its parent model')
+
+
+def conv_spec(conv: Conv1d, bn: Optional[BatchNorm1d], pad_l: int, pad_r: int, pad_mode: int, name: str = '') -> ConvSpec:
+    if conv.groups != 1:
+        raise NotImplementedError('grouped / depthwise convolution is not built yet (jasper.py:319-330)')
+    spec = ConvSpec(weight=conv.weight, bias=conv.bias, kernel=conv.kernel_size[0], stride=conv.stride[0],
+                    dilation=conv.dilation[0], pad_l=pad_l, pad_r=pad_r, pad_mode=pad_mode, name=name)
+    if bn is not None:
+        spec.bn_weight, spec.bn_bias = bn.weight, bn.bias
+        spec.running_mean, spec.running_var = bn.running_mean, bn.running_var
+        spec.num_batches_tracked = bn.num_batches_tracked
+        spec.eps, spec.momentum = bn.eps, bn.momentum
+    return spec
+
+
+class _StackFn(torch.autograd.Function):
+    """One autograd node for the whole conv stack + classifier + (log_)softmax."""
+
+    @staticmethod
+    def forward(ctx, x, engine: StackEngine, lens, training: bool, softmax_mode: int, holder: dict, *params):
+        if x.requires_grad:
+            raise NotImplementedError('gradient wrt the input spectrogram is not implemented '
+                                      '(the first conv is strided; training does not need it)')
+        out, ectx = engine.forward(x, lens, training, softmax_mode)
+        ctx.engine, ctx.ectx = engine, ectx
+        holder['lens_out'] = ectx['lens_out']
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = ctx.engine.backward(ctx.ectx, g)
+        ctx.ectx = None
+        return (None, None, None, None, None, None, *grads)
+
+
+def run_stack(engine: StackEngine, x, lens, training: bool, softmax_mode: int = 0):
+    holder = {}
+    out = _StackFn.apply(x, engine, lens, training, softmax_mode, holder, *engine.parameters())
+    return out, holder.get('lens_out')
