@@ -3,6 +3,7 @@
 Tolerances: bf16-operand kernels are compared on bf16-rounded inputs (fp32 accumulate) at
 2e-3 relative to the output scale; fp32 elementwise kernels at 1e-5."""
 import ctypes as C
+import ctypes as C_
 import os
 
 import numpy as np
@@ -248,7 +249,8 @@ def test_log_softmax_and_argmax(L):
         g = torch.randn(N, T, Cn)
         ref.backward(g)
         gl = torch.empty(N, T, Cn, device='cuda')
-        L.check(L.lib.w2l_log_softmax_bwd(L.ptr(g.cuda()), L.ptr(out), N, T, Cn, mode, L.ptr(gl), L.stream_ptr()))
+        g_d = g.cuda()
+        L.check(L.lib.w2l_log_softmax_bwd(L.ptr(g_d), L.ptr(out), N, T, Cn, mode, L.ptr(gl), L.stream_ptr()))
         assert (gl.cpu() - lr.grad).abs().max() < 1e-5
     z = np.load(os.path.join(GOLD, 'greedy_cases.npz'), allow_pickle=True)
     probs = torch.from_numpy(z['probs']).cuda()
@@ -289,3 +291,92 @@ def test_ctc_vs_oracle_random(L, N, T, S):
     loss.backward()
     assert abs(float(loss) - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
     np.testing.assert_allclose(ld.grad.cpu().numpy(), lr.grad.numpy(), rtol=2e-3, atol=1e-6)
+
+
+def _bnact_desc(L, N, T, C, y, scale, shift, mean, invstd, act, p=0.0, mask=None, lens=None, y2=None, bn2=None):
+    d = L.BnActDesc()
+    d.N, d.T, d.C = N, T, C
+    d.y = y.data_ptr()
+    d.y_f32 = int(y.dtype == torch.float32)
+    d.scale = scale.data_ptr() if scale is not None else None
+    d.shift = shift.data_ptr() if shift is not None else None
+    d.mean = mean.data_ptr() if mean is not None else None
+    d.invstd = invstd.data_ptr() if invstd is not None else None
+    if y2 is not None:
+        d.y2 = y2.data_ptr()
+        d.scale2, d.shift2, d.mean2, d.invstd2 = (t.data_ptr() for t in bn2)
+    d.act = act
+    d.drop_p = p
+    d.seed, d.offset = 1234, 1
+    d.mask = mask.data_ptr() if mask is not None else None
+    d.lens = lens.data_ptr() if lens is not None else None
+    return d
+
+
+@pytest.mark.parametrize('N,T,C,pl,pr,mode,act,f32', [
+    (2, 150, 128, 12, 12, 1, 1, True), (2, 60, 128, 6, 6, 1, 1, True), (3, 100, 64, 4, 5, 1, 1, False),
+    (2, 75, 192, 28, 28, 1, 1, True), (2, 90, 64, 3, 3, 0, 2, True), (1, 33, 640, 0, 0, 1, 0, True)])
+def test_bn_act_fwd_bwd(L, N, T, C, pl, pr, mode, act, f32):
+    """BN(train) + activation forward into a padded buffer, and its backward from a gradient given in
+    the padded coordinates (reflect fold), against torch autograd on the CPU."""
+    g = torch.Generator().manual_seed(N * 100 + T)
+    y = torch.randn(N, C, T, generator=g) * 3 + 1
+    if not f32:
+        y = bf(y)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g)
+    yr = y.clone().requires_grad_(True)
+    z = F.batch_norm(yr, None, None, gamma, beta, True, 0.9, 1e-3)
+    a = z.clamp(0, 20) if act == 1 else (F.relu(z) if act == 2 else z)
+    ap = F.pad(a, (pl, pr), mode='reflect' if mode == 1 else 'constant') if (pl or pr) else a
+    gp = torch.randn(ap.shape, generator=g)
+    ap.backward(gp)
+    # device side
+    yd = y.transpose(1, 2).contiguous().cuda()
+    if not f32:
+        yd = yd.to(torch.bfloat16)
+    s1 = yd.float().sum((0, 1))
+    s2 = (yd.float() ** 2).sum((0, 1))
+    part = torch.stack([s1, s2]).unsqueeze(0).contiguous()
+    scale, shift, mean, invstd = (torch.empty(C, device='cuda') for _ in range(4))
+    rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    st = L.stream_ptr()
+    gam_d, bet_d = gamma.cuda(), beta.cuda()
+    L.check(L.lib.w2l_bn_finalize(L.ptr(part), 1, C, N * T, L.ptr(gam_d), L.ptr(bet_d), 1e-3, 0.9, L.ptr(rm),
+                                  L.ptr(rv), L.ptr(mean), L.ptr(invstd), L.ptr(scale), L.ptr(shift), st))
+    mref = y.mean((0, 2))
+    vref = y.var((0, 2), unbiased=True)
+    assert (rm.cpu() - 0.9 * mref).abs().max() < 1e-4 and relerr(rv.cpu(), 0.1 + 0.9 * vref) < 1e-4
+    d = _bnact_desc(L, N, T, C, yd, scale, shift, mean, invstd, act)
+    R = pl + T + pr
+    out_hi = torch.empty(N, R, C, dtype=torch.bfloat16, device='cuda')
+    out_lo = torch.empty_like(out_hi)
+    L.check(L.lib.w2l_bn_act_fwd(C_.byref(d), L.ptr(out_hi), L.ptr(out_lo), R, pl, pr, mode, st))
+    got = (out_hi.float() + out_lo.float()).cpu().transpose(1, 2)
+    assert relerr(got, ap.detach()) < 2e-5
+    # backward
+    gd = gp.transpose(1, 2).contiguous().cuda()
+    gs = L.GradSrc()
+    gs.dxp, gs.f32, gs.pad_l, gs.pad_r, gs.pad_mode = gd.data_ptr(), 1, pl, pr, mode
+    nb = L.lib.w2l_bn_bwd_blocks(N, T, C)
+    partial = torch.empty(nb, 4, C, device='cuda')
+    L.check(L.lib.w2l_bn_act_bwd_reduce(C_.byref(d), C_.byref(gs), None, L.ptr(partial), st))
+    sums = torch.empty(4, C, device='cuda')
+    L.check(L.lib.w2l_bn_bwd_finalize(L.ptr(partial), nb, C, L.ptr(sums), st))
+    hb, ha = 7, 70
+    dy_hi = torch.full((N, hb + T + ha, C), float('nan'), dtype=torch.bfloat16, device='cuda')
+    dy_lo = torch.empty_like(dy_hi)
+    L.check(L.lib.w2l_bn_act_bwd_apply(C_.byref(d), C_.byref(gs), None, L.ptr(sums), L.ptr(dy_hi), L.ptr(dy_lo), hb, ha, None,
+                                       None, 0, 0, st))
+    torch.cuda.synchronize()
+    # d beta / d gamma via autograd on the same graph
+    gam = gamma.clone().requires_grad_(True)
+    bet = beta.clone().requires_grad_(True)
+    z2 = F.batch_norm(y, None, None, gam, bet, True, 0.9, 1e-3)
+    a2 = z2.clamp(0, 20) if act == 1 else (F.relu(z2) if act == 2 else z2)
+    (F.pad(a2, (pl, pr), mode='reflect' if mode == 1 else 'constant') if (pl or pr) else a2).backward(gp)
+    assert relerr(sums[0].cpu(), bet.grad) < 1e-4, relerr(sums[0].cpu(), bet.grad)
+    assert relerr(sums[1].cpu(), gam.grad) < 1e-4
+    dy = (dy_hi.float() + dy_lo.float()).cpu()
+    assert (dy[:, :hb] == 0).all() and (dy[:, hb + T:] == 0).all()
+    assert relerr(dy[:, hb:hb + T].transpose(1, 2), yr.grad) < 1e-4, relerr(dy[:, hb:hb + T].transpose(1, 2), yr.grad)

@@ -85,7 +85,7 @@ __device__ __forceinline__ int pad_src_row(int r, int T, int pad_l, int pad_r, i
 template <bool F32>
 __device__ __forceinline__ uint32_t preact8(const w2l_bnact_t& d, int64_t row /* n*T+t */, int cg, int G, float z[8],
                                             float y1[8], float y2v[8], uint32_t thresh, float inv_keep,
-                                            bool write_mask) {
+                                            bool gen_mask, bool write_mask) {
     const int c = cg * 8;
     const int64_t off = row * d.C + c;
     load8<F32>(d.y, off, y1);
@@ -114,10 +114,10 @@ __device__ __forceinline__ uint32_t preact8(const w2l_bnact_t& d, int64_t row /*
     uint32_t bits = 0xFFu;
     if (d.drop_p > 0.f) {
         const int64_t gidx = row * G + cg;
-        if (write_mask) {
+        if (gen_mask) {      // forward: every row (halo copies too) regenerates its bits; the primary row records them
             bits = dropout_bits(d.seed, d.offset, (uint64_t)gidx, thresh);
-            d.mask[gidx] = (uint8_t)bits;
-        } else {
+            if (write_mask) d.mask[gidx] = (uint8_t)bits;
+        } else {             // backward: replay the recorded bits
             bits = d.mask[gidx];
         }
 #pragma unroll
@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(w2l_bnact_t d, bf16_raw
         for (int j = 0; j < 8; ++j) a[j] = 0.f;
         if (t >= 0 && (!d.lens || t < d.lens[n])) {
             float z[8], y1[8], y2v[8];
-            preact8<F32>(d, (int64_t)n * d.T + t, cg, G, z, y1, y2v, thresh, inv_keep, /*write_mask=*/r - pad_l == t);
+            preact8<F32>(d, (int64_t)n * d.T + t, cg, G, z, y1, y2v, thresh, inv_keep, /*gen_mask=*/true,
+                         /*write_mask=*/r - pad_l == t);
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] = activate(z[j], d.act);
         }
@@ -200,7 +201,7 @@ __device__ __forceinline__ void bwd_row(const w2l_bnact_t& d, const w2l_gradsrc_
 #pragma unroll
     for (int j = 0; j < 8; ++j) { o.g[j] = 0.f; o.xh1[j] = 0.f; o.xh2[j] = 0.f; y2v[j] = 0.f; }
     if (d.lens && t >= d.lens[n]) return;        // masked_fill: no gradient through zeroed frames
-    const uint32_t bits = preact8<F32>(d, (int64_t)n * d.T + t, cg, G, z, y1, y2v, 0, inv_keep, false);
+    const uint32_t bits = preact8<F32>(d, (int64_t)n * d.T + t, cg, G, z, y1, y2v, 0, inv_keep, false, false);
     float g[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = 0.f;

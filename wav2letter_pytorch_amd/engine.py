@@ -117,6 +117,7 @@ class _PackedW:
     dgr_lo: Optional[torch.Tensor]
     cinp: int
     coutp: int
+    src_ptr: int = 0
 
 
 @dataclass
@@ -141,7 +142,6 @@ class _UnitCtx:
     keep: list = field(default_factory=list)
 
 
-_pack_cache = {}
 _dropout_calls = 0
 
 
@@ -153,9 +153,13 @@ def _phys_strides(w: torch.Tensor):
 def pack_weights(conv: ConvSpec, precise: bool, need_dgrad: bool = True) -> _PackedW:
     """fp32 master weights -> bf16 GEMM operand layouts (cached per parameter version)."""
     w = conv.weight
-    key = (id(w), precise)
-    hit = _pack_cache.get(key)
-    if hit is not None and hit.version == w._version and hit.fwd_hi.device == w.device:
+    cache = getattr(w, '_w2l_pack', None)          # lives and dies with the Parameter object
+    if cache is None:
+        cache = {}
+        w._w2l_pack = cache
+    hit = cache.get(precise)
+    if (hit is not None and hit.version == w._version and hit.fwd_hi.device == w.device
+            and hit.src_ptr == w.data_ptr()):
         return hit
     cout, cin, kw = w.shape
     coutp, cinp = padded_channels(cout), padded_channels(cin)
@@ -167,8 +171,8 @@ def pack_weights(conv: ConvSpec, precise: bool, need_dgrad: bool = True) -> _Pac
     s_co, s_ci, s_kw = _phys_strides(w)
     check(lib.w2l_pack_weights(ptr(w), s_co, s_ci, s_kw, cout, cin, kw, coutp, cinp, ptr(fwd_hi), ptr(fwd_lo),
                                ptr(dgr_hi), ptr(dgr_lo), stream_ptr()), 'w2l_pack_weights')
-    pk = _PackedW(w._version, fwd_hi, fwd_lo, dgr_hi, dgr_lo, cinp, coutp)
-    _pack_cache[key] = pk
+    pk = _PackedW(w._version, fwd_hi, fwd_lo, dgr_hi, dgr_lo, cinp, coutp, w.data_ptr())
+    cache[precise] = pk
     return pk
 
 
@@ -451,6 +455,7 @@ class StackEngine:
                                                 st()), 'w2l_bn_act_bwd_reduce')
                 sums = torch.empty(4, coutp, dtype=torch.float32, device=dev)
                 check(lib.w2l_bn_bwd_finalize(ptr(partial), nb, coutp, ptr(sums), st()), 'w2l_bn_bwd_finalize')
+                uc.keep.append((partial, sums))
             main, res = u.main, u.res
             hb = (main.kernel - 1) * main.dilation
             need_dx_main = self._needs_grad(u.src)

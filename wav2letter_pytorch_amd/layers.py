@@ -114,6 +114,8 @@ class _StackFn(torch.autograd.Function):
                                       '(the first conv is strided; training does not need it)')
         out, ectx = engine.forward(x, lens, training, softmax_mode)
         ctx.engine, ctx.ectx = engine, ectx
+        if holder.get('keep_ctx'):
+            holder['ctx'] = ectx
         holder['lens_out'] = ectx['lens_out']
         return out
 
@@ -124,7 +126,10 @@ class _StackFn(torch.autograd.Function):
         return (None, None, None, None, None, None, *grads)
 
 
-def run_stack(engine: StackEngine, x, lens, training: bool, softmax_mode: int = 0):
-    holder = {}
+def run_stack(engine: StackEngine, x, lens, training: bool, softmax_mode: int = 0, keep_ctx: bool = False):
+    """Returns (out, lens_out[, engine ctx when keep_ctx: test hook that exposes the saved activations])."""
+    holder = {'keep_ctx': keep_ctx}
     out = _StackFn.apply(x, engine, lens, training, softmax_mode, holder, *engine.parameters())
+    if keep_ctx:
+        return out, holder.get('lens_out'), holder.get('ctx')
     return out, holder.get('lens_out')

@@ -100,7 +100,10 @@ class Wav2Letter(ConvCTCASR):
     def forward(self, x, input_lengths=None):
         """x [N, input_size, T] float -> (log_probs [N, T', n_labels], output_lengths or None)
         (wav2letter.py:84-92).  Lengths are not used inside the network (no masking)."""
-        x, _ = run_stack(self.engine(), x, None, self.training, softmax_mode=0)
+        if getattr(self, '_debug_keep_ctx', False):      # test hook: expose the engine's saved activations
+            x, _, self._last_ctx = run_stack(self.engine(), x, None, self.training, softmax_mode=0, keep_ctx=True)
+        else:
+            x, _ = run_stack(self.engine(), x, None, self.training, softmax_mode=0)
         if input_lengths is not None:
             output_lengths = self.compute_output_lengths(input_lengths)
         else:
