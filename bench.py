@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-frames/sec (fwd + CTC + bwd [+ SGD step]) of Wav2Letter, full
+21-layer table of configuration/model/wav2letter.yaml (mid_layers=20, 153 M params), bf16
+operands / fp32 accumulate, synthetic 64-mel x 1000-frame spectrograms, batch 32 per GPU.
+
+  python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement).  `roofline` is the
+dominant kernel (conv_igemm_kernel: forward + data-gradient convolutions) timed with HIP events
+on its launch stream in a separate instrumented pass of the same step; `cpu_baseline` is the
+CPU oracle (torch-CPU restatement of the reference path) timed on this host's cores."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
+
+
+def w2l_cfg(mid_layers, dropout=True):
+    from oracle.w2l_oracle import ENGLISH_LOWERCASE, W2L_LAYERS
+    from wav2letter_pytorch_amd.config import to_cfg
+    labels = ENGLISH_LOWERCASE
+    layers = [dict(output_size=c, kernel_size=k, stride=s, dilation=d, dropout=(p if dropout else 0.0))
+              for c, k, s, d, p in W2L_LAYERS]
+    return to_cfg(dict(name='wav2letter', mid_layers=mid_layers, input_size=64, labels=labels, precision='bf16',
+                       layers=layers,
+                       audio_conf=dict(window='hamming', window_stride=0.01, window_size=0.02, sample_rate=16000),
+                       decoder=dict(_target_='decoder.GreedyDecoder', labels=labels),
+                       optimizer=dict(_target_='torch.optim.SGD', lr=1e-5, momentum=0.9, nesterov=True, weight_decay=1e-5),
+                       scheduler=dict(_target_='torch.optim.lr_scheduler.ExponentialLR', gamma=0.999)))
+
+
+def cpu_baseline(budget_s=25.0):
+    """the oracle's training step (fp32, torch CPU ops = what the reference executes) on a bounded
+    sample of the same workload: W2L mid_layers=20, N=2, T=1000."""
+    from oracle import w2l_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    layers = [l[:4] + (0.0,) for l in O.W2L_LAYERS]
+    sd = O.init_wav2letter_state(layers, seed=0)
+    N, T = 2, 1000
+    x, il, tg, tl = O.synthetic_batch(N, T, seed=1234)
+    O.wav2letter_step(x, il, tg, tl, sd, layers)            # warm-up
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 8):
+        t0 = time.perf_counter()
+        O.wav2letter_step(x, il, tg, tl, sd, layers)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() > t_end and len(times) >= 3:
+            break
+    best = min(times)
+    return {'value': N * T / best, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': f'W2L mid_layers=20 fp32 N={N} T={T}, {len(times)} steps after 1 warm-up, best step {best:.3f}s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--frames', type=int, default=1000)
+    ap.add_argument('--mid-layers', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-optimizer', action='store_true')
+    ap.add_argument('--breakdown', action='store_true', help='print the per-kernel event timing table to stderr')
+    args = ap.parse_args()
+
+    from wav2letter_pytorch_amd import Wav2Letter, engine as E
+    from wav2letter_pytorch_amd.distributed import GradReducer, broadcast_parameters, init_process_group_from_env
+    import torch.distributed as dist
+    from oracle.w2l_oracle import synthetic_batch
+
+    rank, world = init_process_group_from_env()
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    torch.manual_seed(0)
+    model = Wav2Letter(w2l_cfg(args.mid_layers)).to(dev).train()
+    broadcast_parameters(model)
+    if world > 1:
+        model.grad_reducer = GradReducer()
+    opt, _ = model.configure_optimizers()
+    opt = opt[0]
+    N, T = args.batch, args.frames
+    x, il, tg, tl = synthetic_batch(N, T, seed=1234 + rank)
+    x = x.to(dev)
+    tg_d, tl_d = tg.to(dev), tl.to(dev)
+    ol = model.compute_output_lengths(il).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out, _ = model(x, None)
+        loss = model.criterion(out.transpose(0, 1), tg_d, ol, tl_d)
+        loss.backward()
+        if not args.no_optimizer:
+            opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    ms = elapsed / args.steps * 1e3
+    value = world * N * T / (elapsed / args.steps)
+
+    # ---- instrumented pass: HIP events around every conv kernel launch (same stream) ----
+    roof = None
+    if rank == 0:
+        E.KERNEL_TIMER = []
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        agg = {}
+        for name, flops, s, e in E.KERNEL_TIMER:
+            a = agg.setdefault(name, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += s.elapsed_time(e) * 1e-3
+            a[2] += 1
+        E.KERNEL_TIMER = None
+        name = 'conv_igemm_kernel'
+        fl, tt, cnt = agg[name]
+        ach = fl / tt / 1e12
+        roof = {'kernel': name, 'bound': 'mfma', 'achieved': round(ach, 1), 'peak': BF16_DENSE_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(ach / BF16_DENSE_PEAK_TFLOPS, 4), 'traffic': None,
+                'launches_per_step': cnt // 3, 'avg_launch_ms': round(tt / cnt * 1e3, 4),
+                'alg_gflop_per_launch': round(fl / cnt / 1e9, 2)}
+        if 'conv_wgrad_kernel' in agg:
+            fl2, tt2, cnt2 = agg['conv_wgrad_kernel']
+            roof['wgrad_kernel'] = {'achieved': round(fl2 / tt2 / 1e12, 1), 'frac': round(fl2 / tt2 / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4),
+                                    'avg_launch_ms': round(tt2 / cnt2 * 1e3, 4), 'launches_per_step': cnt2 // 3}
+            conv_ms = (tt + tt2) / 3 * 1e3
+            roof['conv_ms_per_step'] = round(conv_ms, 3)
+            roof['conv_stack_frac_of_peak'] = round((fl + fl2) / (tt + tt2) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)
+        if args.breakdown:
+            for k, (f, t_, c) in agg.items():
+                print(f'{k}: {c // 3} launches/step, {t_ / 3 * 1e3:.3f} ms/step, {f / t_ / 1e12:.1f} TFLOP/s', file=sys.stderr)
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+        line = {
+            'metric': 'audio-frames/sec/GPU (fwd+bwd+CTC), Wav2Letter 64-mel x 1000-frame bf16',
+            'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'Wav2Letter mid_layers={args.mid_layers} (configuration/model/wav2letter.yaml table), '
+                                   f'N={N}/GPU x T={T} x 64 mel, dropout on, fwd+CTC+bwd'
+                                   + ('' if args.no_optimizer else '+SGD(nesterov) step'),
+                       'global_batch': world * N, 'frames': T, 'parallelism': f'dp{world}',
+                       'value_is': 'whole-job frames/s (per-GPU = value / n_gpus)', 'loss': round(float(loss), 4)},
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

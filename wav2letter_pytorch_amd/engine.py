@@ -144,6 +144,25 @@ class _UnitCtx:
 
 _dropout_calls = 0
 
+# optional kernel timer (bench.py): list of (kernel_name, flops, start_event, end_event)
+KERNEL_TIMER: Optional[list] = None
+
+
+class _timed:
+    def __init__(self, name, flops):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if KERNEL_TIMER is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *a):
+        if KERNEL_TIMER is not None:
+            self.e.record()
+            KERNEL_TIMER.append((self.name, self.flops, self.s, self.e))
+
 
 def _phys_strides(w: torch.Tensor):
     """element strides (s_co, s_ci, s_kw) of the logical [Cout,Cin,Kw] weight"""
@@ -190,7 +209,7 @@ def _padded_vec(v: Optional[torch.Tensor], cp: int, fill: float) -> Optional[tor
     return out
 
 
-def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw, stride, dil, precise):
+def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw, stride, dil, precise, alg_flops=0.0):
     """y = conv(x) through w2l_conv1d_igemm; split-bf16 (3 launches, fp32 accumulate) when precise."""
     n = x.N
     bstride = x.rows * x.CP
@@ -202,8 +221,10 @@ def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw
 
     st = stream_ptr()
     if not precise:
-        check(lib.w2l_conv1d_igemm(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y), int(y.dtype == torch.float32), 0,
-                                   ptr(bias), ptr(stats), n, Cin, Cout, Tout, Kw, stride, dil, st), 'w2l_conv1d_igemm')
+        with _timed('conv_igemm_kernel', alg_flops):
+            check(lib.w2l_conv1d_igemm(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y), int(y.dtype == torch.float32),
+                                       0, ptr(bias), ptr(stats), n, Cin, Cout, Tout, Kw, stride, dil, st),
+                  'w2l_conv1d_igemm')
         return
     assert y.dtype == torch.float32
     check(lib.w2l_conv1d_igemm(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y), 1, 0, ptr(bias), None, n, Cin, Cout,
@@ -223,7 +244,9 @@ class StackEngine:
         self.head = head
         self.n_labels = n_labels
         self.precise = precise
-        self.grad_ready: Optional[Callable[[torch.Tensor, torch.Tensor], None]] = None
+        # callbacks for data-parallel overlap (distributed.GradReducer): grad_ready(param, grad, dense_storage)
+        self.grad_ready: Optional[Callable] = None
+        self.backward_done: Optional[Callable[[], None]] = None
 
     # ------------------------------------------------------------------ parameters
     def parameters(self) -> List[torch.Tensor]:
@@ -350,7 +373,7 @@ class StackEngine:
             stats = torch.empty(tiles, 2, pk.coutp, dtype=torch.float32, device=src.hi.device)
         bias = _padded_vec(conv.bias, pk.coutp, 0.0)
         _igemm(src, src.pad_l - conv.pad_l, pk.fwd_hi, pk.fwd_lo, y, bias, stats, pk.cinp, pk.coutp, Tout, conv.kernel,
-               conv.stride, conv.dilation, self.precise)
+               conv.stride, conv.dilation, self.precise, alg_flops=2.0 * N * Tout * conv.cout * conv.cin * conv.kernel)
         return y, stats, Tout
 
     def _bn_finalize(self, conv: ConvSpec, stats, count, cp, training):
@@ -500,19 +523,21 @@ class StackEngine:
                     self._set(grads, res.bias, torch.zeros(res.cout, dtype=torch.float32, device=dev))
                 if self._needs_grad(u.res_src):
                     act_grads[u.res_src].append(self._dgrad(res, pkr, dy2_hi, dy2_lo, hb2, rsrc))
+        if self.backward_done is not None:
+            self.backward_done()
         return [grads.get(id(p)) for p in self.parameters()]
 
     # ------------------------------------------------------------------ helpers
     def _needs_grad(self, act_index: int) -> bool:
         return act_index != 0          # the spectrogram needs no gradient in training (base_asr_models.py:78-85)
 
-    def _notify(self, param, grad):
+    def _notify(self, param, grad, storage=None):
         if self.grad_ready is not None:
-            self.grad_ready(param, grad)
+            self.grad_ready(param, grad, storage)
 
-    def _set(self, grads, param, grad):
+    def _set(self, grads, param, grad, storage=None):
         grads[id(param)] = grad
-        self._notify(param, grad)
+        self._notify(param, grad, storage)
 
     def _gsrc(self, s) -> GradSrc:
         t, pl, pr, mode = s
@@ -545,7 +570,8 @@ class StackEngine:
                   'w2l_conv1d_wgrad')
 
         if not self.precise:
-            run(dy_hi, src.hi, 0)
+            with _timed('conv_wgrad_kernel', 2.0 * N * Tout * cout * cin * kw):
+                run(dy_hi, src.hi, 0)
         else:
             run(dy_hi, src.hi, 1)
             run(dy_hi, src.lo, 1)
@@ -553,7 +579,7 @@ class StackEngine:
         g = dw.permute(1, 2, 0)                     # logical [CoutP, CinP, Kw]
         if not direct:
             g = g[:cout, :cin, :]
-        self._set(grads, w, g)
+        self._set(grads, w, g, storage=dw)
 
     def _dgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, hb, src: Act):
         """dXpad (gradient wrt the conv's padded input) through the same implicit-GEMM kernel."""
@@ -566,6 +592,7 @@ class StackEngine:
         dxp = torch.empty(N, Tp, pk.cinp, dtype=torch.float32 if self.precise else torch.bfloat16, device=dev)
         rows = dy_hi.shape[1]
         dyact = Act(dy_hi, dy_lo, N, rows, pk.coutp, pk.coutp, 0, 0, PAD_ZERO)
+        Tout = Tp - (conv.kernel - 1) * conv.dilation
         _igemm(dyact, 0, pk.dgr_hi, pk.dgr_lo, dxp, None, None, pk.coutp, pk.cinp, Tp, conv.kernel, 1, conv.dilation,
-               self.precise)
+               self.precise, alg_flops=2.0 * N * Tout * conv.cout * conv.cin * conv.kernel)
         return (dxp, conv.pad_l, conv.pad_r, conv.pad_mode)
