@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the conv kernels (forward igemm, dgrad igemm, wgrad) on the Wav2Letter
+table shapes (N=32, T=1000).  HIP-event timing on the launch stream; prints TFLOP/s per layer."""
+import argparse
+import ctypes as C
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wav2letter_pytorch_amd import _lib as L  # noqa: E402
+
+TABLE = ([(64, 256, 11, 2, 1)] + [(256, 256, 11, 1, 1)] * 3 + [(256, 384, 13, 1, 1)] + [(384, 384, 13, 1, 1)] * 2
+         + [(384, 512, 17, 1, 1)] + [(512, 512, 17, 1, 1)] * 2 + [(512, 640, 21, 1, 1)] + [(640, 640, 21, 1, 1)] * 2
+         + [(640, 768, 25, 1, 1)] + [(768, 768, 25, 1, 1)] * 2 + [(768, 896, 29, 1, 2)] + [(896, 896, 29, 1, 2)] * 2
+         + [(896, 1024, 1, 1, 1), (1024, 64, 1, 1, 1)])
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--layers', default='all')
+    ap.add_argument('--reps', type=int, default=10)
+    ap.add_argument('--n', type=int, default=32)
+    ap.add_argument('--t', type=int, default=1000)
+    args = ap.parse_args()
+    N = args.n
+    uniq = []
+    for sh in TABLE:
+        if sh not in uniq:
+            uniq.append(sh)
+    if args.layers != 'all':
+        uniq = [uniq[int(i)] for i in args.layers.split(',')]
+    st = L.stream_ptr()
+    tot = {'fwd': [0, 0], 'dgrad': [0, 0], 'wgrad': [0, 0]}
+    mult = {sh: TABLE.count(sh) for sh in uniq}
+    print(f'{"Cin":>5} {"Cout":>5} {"K":>3} s d | {"fwd ms":>8} {"TF":>6} | {"dgrad ms":>8} {"TF":>6} | {"wgrad ms":>8} {"TF":>6}')
+    for (cin, cout, kw, s, d) in uniq:
+        T = args.t if s == 2 else args.t // 2
+        p = (kw - 1) * d if s == 1 else 9
+        pl, pr = p // 2, p - p // 2
+        rows = T + pl + pr
+        Tout = (rows - (kw - 1) * d - 1) // s + 1
+        x = (torch.randn(N, rows, cin, device='cuda')).to(torch.bfloat16)
+        w = (torch.randn(kw, cout, cin, device='cuda') * 0.05).to(torch.bfloat16)
+        wd = (torch.randn(kw, cin, cout, device='cuda') * 0.05).to(torch.bfloat16)
+        y = torch.empty(N, Tout, cout, dtype=torch.bfloat16, device='cuda')
+        stats = torch.empty(L.lib.w2l_conv_stat_tiles(N, Tout), 2, cout, device='cuda')
+        hb = (kw - 1) * d
+        ha = max(hb, (Tout + 63) // 64 * 64 - Tout)
+        dy = torch.zeros(N, hb + Tout + ha, cout, dtype=torch.bfloat16, device='cuda')
+        dy[:, hb:hb + Tout] = torch.randn(N, Tout, cout, device='cuda').to(torch.bfloat16)
+        dx = torch.empty(N, rows, cin, dtype=torch.bfloat16, device='cuda')
+        dw = torch.zeros(kw, cout, cin, device='cuda')
+        flops = 2.0 * N * Tout * cout * cin * kw
+
+        def fwd():
+            L.check(L.lib.w2l_conv1d_igemm(L.ptr(x), rows * cin, N * rows, L.ptr(w), L.ptr(y), 0, 0, None, L.ptr(stats), N,
+                                           cin, cout, Tout, kw, s, d, st))
+
+        def dgrad():
+            L.check(L.lib.w2l_conv1d_igemm(L.ptr(dy), dy.shape[1] * cout, N * dy.shape[1], L.ptr(wd), L.ptr(dx), 0, 0, None,
+                                           None, N, cout, cin, rows, kw, 1, d, st))
+
+        def wgrad():
+            L.check(L.lib.w2l_conv1d_wgrad(C.c_void_p(dy.data_ptr() + hb * cout * 2), dy.shape[1] * cout, L.ptr(x),
+                                           rows * cin, N * rows, L.ptr(dw), N, cin, cout, Tout, kw, s, d, 0, st))
+
+        tf = timeit(fwd, args.reps)
+        td = timeit(dgrad, args.reps) if s == 1 else float('nan')
+        tw = timeit(wgrad, args.reps)
+        m = mult[(cin, cout, kw, s, d)]
+        for k, t in (('fwd', tf), ('dgrad', td), ('wgrad', tw)):
+            if t == t:
+                tot[k][0] += m * t
+                tot[k][1] += m * flops
+        print(f'{cin:5d} {cout:5d} {kw:3d} {s} {d} | {tf:8.3f} {flops / tf / 1e9:6.0f} | {td:8.3f} {flops / td / 1e9:6.0f} | '
+              f'{tw:8.3f} {flops / tw / 1e9:6.0f}   x{m}')
+    for k, (t, f) in tot.items():
+        if t:
+            print(f'{k}: {t:.3f} ms/step-equivalent, {f / t / 1e9:.0f} TFLOP/s')
+
+
+if __name__ == '__main__':
+    main()

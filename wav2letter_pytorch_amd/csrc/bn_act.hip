@@ -229,7 +229,7 @@ __device__ __forceinline__ void bwd_row(const w2l_bnact_t& d, const w2l_gradsrc_
     }
 }
 
-constexpr int BWD_ROWS_PER_BLOCK = 64;
+constexpr int BWD_ROWS_PER_BLOCK = 16;   // 1000 blocks at N*T = 16000: enough waves in flight to stream HBM
 
 // partial[blk][4][C]: sum g, sum g*xh1, sum g, sum g*xh2
 template <bool F32, bool GF32>
@@ -277,12 +277,22 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(w2l_bnact_t d, w
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* partial, int nblocks, int C, float* sums) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // over 4*C
-    if (i >= 4 * C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * 4 * C + i];
-    sums[i] = (float)s;
+// column sums of partial[nblocks][ncols]: 32 columns x 8 row-lanes per block, coalesced 128-byte rows
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int nblocks, int ncols, float* sums) {
+    __shared__ float red[8][33];
+    const int cx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cx;
+    float s = 0.f;
+    if (col < ncols)
+        for (int b = ly; b < nblocks; b += 8) s += partial[(int64_t)b * ncols + col];
+    red[ly][cx] = s;
+    __syncthreads();
+    if (ly == 0 && col < ncols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][cx];
+        sums[col] = t;
+    }
 }
 
 template <bool F32, bool GF32>
@@ -342,18 +352,30 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(w2l_bnact_t d, w2
 }
 
 // ---------------------------------------------------------------- statistics finalize (forward)
-__global__ void bn_finalize_kernel(const float* partial, int ntiles, int C, double count, const float* gamma,
-                                   const float* beta, float eps, float momentum, float* running_mean,
-                                   float* running_var, float* mean, float* invstd, float* scale, float* shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float m, istd;
-    if (partial) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int t = 0; t < ntiles; ++t) {
+// 32 channels x 8 tile-lanes per block: the per-tile partial sums are read as coalesced rows
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, int ntiles, int C, double count,
+                                                          const float* gamma, const float* beta, float eps, float momentum,
+                                                          float* running_mean, float* running_var, float* mean,
+                                                          float* invstd, float* scale, float* shift) {
+    __shared__ double red1[8][33], red2[8][33];
+    const int cx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    double s1 = 0.0, s2 = 0.0;
+    if (partial && c < C) {
+        for (int t = ly; t < ntiles; t += 8) {
             s1 += partial[(int64_t)t * 2 * C + c];
             s2 += partial[(int64_t)t * 2 * C + C + c];
         }
+    }
+    red1[ly][cx] = s1;
+    red2[ly][cx] = s2;
+    __syncthreads();
+    if (ly != 0 || c >= C) return;
+    float m, istd;
+    if (partial) {
+        s1 = 0.0; s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s1 += red1[k][cx]; s2 += red2[k][cx]; }
         const double mu = s1 / count;
         double var = s2 / count - mu * mu;           // biased: normalisation uses it
         if (var < 0.0) var = 0.0;
@@ -397,7 +419,7 @@ extern "C" int w2l_bn_finalize(const float* partial, int ntiles, int C, int64_t 
     W2L_CHECK_ARG(scale && shift && C > 0, "bn_finalize: null output");
     W2L_CHECK_ARG(partial || (running_mean && running_var), "bn_finalize: eval mode needs running stats");
     W2L_CHECK_ARG(!partial || (ntiles > 0 && count > 0), "bn_finalize: bad tile count");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, partial, ntiles, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, ntiles, C,
                        (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
     W2L_CHECK_LAUNCH();
     return 0;
@@ -455,8 +477,8 @@ extern "C" int w2l_bn_act_bwd_reduce(const w2l_bnact_t* d, const w2l_gradsrc_t* 
 
 extern "C" int w2l_bn_bwd_finalize(const float* partial, int nblocks, int C, float* sums, void* stream) {
     W2L_CHECK_ARG(partial && sums && nblocks > 0 && C > 0, "bn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((4 * C + 127) / 128), dim3(128), 0, (hipStream_t)stream, partial,
-                       nblocks, C, sums);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((4 * C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial,
+                       nblocks, 4 * C, sums);
     W2L_CHECK_LAUNCH();
     return 0;
 }

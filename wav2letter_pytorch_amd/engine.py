@@ -247,6 +247,10 @@ class StackEngine:
         # callbacks for data-parallel overlap (distributed.GradReducer): grad_ready(param, grad, dense_storage)
         self.grad_ready: Optional[Callable] = None
         self.backward_done: Optional[Callable[[], None]] = None
+        # weight gradients are off the backward critical path (only dgrad feeds the next layer): they run
+        # on a side HIP stream so their blocks fill the tail rounds of the dgrad / elementwise kernels
+        self.overlap_wgrad = True
+        self._side = None
 
     # ------------------------------------------------------------------ parameters
     def parameters(self) -> List[torch.Tensor]:
@@ -523,6 +527,13 @@ class StackEngine:
                     self._set(grads, res.bias, torch.zeros(res.cout, dtype=torch.float32, device=dev))
                 if self._needs_grad(u.res_src):
                     act_grads[u.res_src].append(self._dgrad(res, pkr, dy2_hi, dy2_lo, hb2, rsrc))
+        if getattr(self, '_side_used', False):
+            main = torch.cuda.current_stream(dev)
+            main.wait_stream(self._side)
+            for g in grads.values():
+                if g is not None and g.is_cuda:
+                    g.record_stream(main)
+            self._side_used = False
         if self.backward_done is not None:
             self.backward_done()
         return [grads.get(id(p)) for p in self.parameters()]
@@ -548,6 +559,24 @@ class StackEngine:
         return g
 
     def _wgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, hb, Tout, src: Act, grads):
+        """dW on the side stream (ordered after everything enqueued so far on the current stream)."""
+        if not self.overlap_wgrad or not dy_hi.is_cuda:
+            return self._wgrad_now(conv, pk, dy_hi, dy_lo, hb, Tout, src, grads)
+        main = torch.cuda.current_stream(dy_hi.device)
+        if self._side is None or self._side.device != dy_hi.device:
+            self._side = torch.cuda.Stream(device=dy_hi.device)
+        side = self._side
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            self._wgrad_now(conv, pk, dy_hi, dy_lo, hb, Tout, src, grads)
+        for t in (dy_hi, dy_lo, src.hi, src.lo):
+            if t is not None:
+                t.record_stream(side)
+        self._side_used = True
+
+    def _wgrad_now(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, hb, Tout, src: Act, grads):
         """dW through w2l_conv1d_wgrad, written in the parameter's own physical layout when possible."""
         w = conv.weight
         cout, cin, kw = w.shape
