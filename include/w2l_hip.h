@@ -46,11 +46,17 @@ int w2l_pack_weights(const float* w, int64_t s_co, int64_t s_ci, int64_t s_kw, i
 int w2l_nct_to_ntc(const float* x, int N, int C, int T, int CP, int pad_l, int pad_r, int pad_mode,
                    const int32_t* lens, void* out_hi, void* out_lo, void* stream);
 
-/* fp32 dense [N][T][C] -> zero-haloed bf16 [N][halo_b+T+halo_a][CP] (+ optional lo), and per-channel
+/* "Shared-halo" gradient layout used for every dy buffer: rows = halo + N*(T + halo):
+ *   [halo zero rows][utt 0: T rows][halo zero rows][utt 1: T rows] ... [utt N-1][halo zero rows]
+ * One zero gap serves as trailing halo of utterance n and leading halo of n+1, so the data-gradient
+ * convolution can run over the whole buffer as ONE long sequence (no per-utterance tile rounding) while
+ * the weight-gradient kernel still sees zero rows after each utterance.
+ *
+ * fp32 dense [N][T][C] -> shared-halo bf16 [halo + N*(T+halo)][CP] (+ optional lo), and per-channel
  * column sums colsum[CP] (bias gradient of an un-normalised conv: the 1x1 classifier,
  * wav2letter.py:69, jasper.py:432-433). */
-int w2l_pad_cast(const float* g, int N, int T, int C, int CP, int halo_b, int halo_a, void* out_hi, void* out_lo,
-                 float* colsum, void* stream);
+int w2l_pad_cast(const float* g, int N, int T, int C, int CP, int halo, void* out_hi, void* out_lo, float* colsum,
+                 void* stream);
 
 /* ---- Conv1d as implicit GEMM on MFMA (nn.Conv1d fwd: wav2letter.py:42, jasper.py:127;
  *      its dgrad: autograd of the same call sites) ---------------------------------
@@ -66,9 +72,13 @@ int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_rows_total, co
                      int accumulate, const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout,
                      int Kw, int stride, int dil, void* stream);
 
+/* tuning hook: force block-shape candidate idx (>= 0) for every later w2l_conv1d_igemm call; -1 = automatic */
+void w2l_conv_force_tile_config(int idx);
+
 /* Conv1d weight gradient (autograd of the same call sites):
  * dw[kw][co][ci] (+)= sum_{n,t} dy[n][t][co] * xp[n][t*stride + kw*dil][ci]
- * dy: zero-haloed bf16, pointer at valid row 0, rows [Tout, roundup(Tout,64)) must be zero.
+ * dy: bf16, pointer at utterance 0 row 0, dy_bstride elements between utterances; rows
+ * [Tout, roundup(Tout,64)) of every utterance must be zero (shared-halo layout with halo >= that).
  * dw fp32 [Kw][Cout][Cin].  accumulate=1 adds to dw (fp32 atomics).  With accumulate=0 the
  * library may still split the (n,t) reduction over blocks and combine with atomics: when
  * w2l_wgrad_needs_zero() != 0 the caller must zero-fill dw first. */
@@ -112,9 +122,11 @@ int w2l_bn_act_fwd(const w2l_bnact_t* d, void* out_hi, void* out_lo, int out_row
                    int pad_mode, void* stream);
 
 typedef struct {
-    const void* dxp;        /* gradient wrt the padded activation buffer [N][pad_l+T+pad_r][C], bf16 or fp32 */
+    const void* dxp;        /* gradient wrt the padded activation buffer [N][rows][C], bf16 or fp32; the first
+                               pad_l+T+pad_r rows of each utterance are valid */
     int32_t f32;
     int32_t pad_l, pad_r, pad_mode;   /* fold reflected halo rows back (mode 1) or skip the halo (mode 0) */
+    int32_t rows;           /* rows per utterance in dxp (>= pad_l+T+pad_r) */
 } w2l_gradsrc_t;
 
 /* sums over (n,t) of g and g*xhat per channel for each branch:
@@ -124,12 +136,11 @@ int w2l_bn_act_bwd_reduce(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w
                           void* stream);
 /* partial -> sums [4][C] (sum_g = d beta, sum_gx = d gamma) */
 int w2l_bn_bwd_finalize(const float* partial, int nblocks, int C, float* sums, void* stream);
-/* dy = scale*(g - sum_g/M - xhat*sum_gx/M) into zero-haloed buffers [N][halo_b+T+halo_a][C] (hi[,lo]);
+/* dy = scale*(g - sum_g/M - xhat*sum_gx/M) into shared-halo buffers [halo + N*(T+halo)][C] (hi[,lo]);
  * dy2 likewise for the residual branch (NULL if none).  The conv bias gradient under BatchNorm is
  * sum(dy) == 0 identically (the reference's value is fp32 rounding noise); it is not computed. */
 int w2l_bn_act_bwd_apply(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2, const float* sums,
-                         void* dy_hi, void* dy_lo, int halo_b, int halo_a, void* dy2_hi, void* dy2_lo, int halo2_b,
-                         int halo2_a, void* stream);
+                         void* dy_hi, void* dy_lo, int halo, void* dy2_hi, void* dy2_lo, int halo2, void* stream);
 
 /* ---- log_softmax + CTC (wav2letter.py:86-87, jasper.py:469-473, base_asr_models.py:23,81,90) ---- */
 /* logits fp32 [N][T][CP] (first C valid) -> out fp32 [N][T][C]; mode 0 log_softmax, 1 softmax */

@@ -357,17 +357,17 @@ def test_bn_act_fwd_bwd(L, N, T, C, pl, pr, mode, act, f32):
     # backward
     gd = gp.transpose(1, 2).contiguous().cuda()
     gs = L.GradSrc()
-    gs.dxp, gs.f32, gs.pad_l, gs.pad_r, gs.pad_mode = gd.data_ptr(), 1, pl, pr, mode
+    gs.dxp, gs.f32, gs.pad_l, gs.pad_r, gs.pad_mode, gs.rows = gd.data_ptr(), 1, pl, pr, mode, pl + T + pr
     nb = L.lib.w2l_bn_bwd_blocks(N, T, C)
     partial = torch.empty(nb, 4, C, device='cuda')
     L.check(L.lib.w2l_bn_act_bwd_reduce(C_.byref(d), C_.byref(gs), None, L.ptr(partial), st))
     sums = torch.empty(4, C, device='cuda')
     L.check(L.lib.w2l_bn_bwd_finalize(L.ptr(partial), nb, C, L.ptr(sums), st))
-    hb, ha = 7, 70
-    dy_hi = torch.full((N, hb + T + ha, C), float('nan'), dtype=torch.bfloat16, device='cuda')
-    dy_lo = torch.empty_like(dy_hi)
-    L.check(L.lib.w2l_bn_act_bwd_apply(C_.byref(d), C_.byref(gs), None, L.ptr(sums), L.ptr(dy_hi), L.ptr(dy_lo), hb, ha, None,
-                                       None, 0, 0, st))
+    h = 13                                            # shared-halo layout: h + N*(T+h) rows
+    dy_hi = torch.full((h + N * (T + h), C), float('nan'), dtype=torch.bfloat16, device='cuda')
+    dy_lo = torch.full_like(dy_hi, float('nan'))
+    L.check(L.lib.w2l_bn_act_bwd_apply(C_.byref(d), C_.byref(gs), None, L.ptr(sums), L.ptr(dy_hi), L.ptr(dy_lo), h, None,
+                                       None, 0, st))
     torch.cuda.synchronize()
     # d beta / d gamma via autograd on the same graph
     gam = gamma.clone().requires_grad_(True)
@@ -378,5 +378,7 @@ def test_bn_act_fwd_bwd(L, N, T, C, pl, pr, mode, act, f32):
     assert relerr(sums[0].cpu(), bet.grad) < 1e-4, relerr(sums[0].cpu(), bet.grad)
     assert relerr(sums[1].cpu(), gam.grad) < 1e-4
     dy = (dy_hi.float() + dy_lo.float()).cpu()
-    assert (dy[:, :hb] == 0).all() and (dy[:, hb + T:] == 0).all()
-    assert relerr(dy[:, hb:hb + T].transpose(1, 2), yr.grad) < 1e-4, relerr(dy[:, hb:hb + T].transpose(1, 2), yr.grad)
+    assert (dy[:h] == 0).all()
+    dyu = dy[h:].view(N, T + h, C)
+    assert (dyu[:, T:] == 0).all()
+    assert relerr(dyu[:, :T].transpose(1, 2), yr.grad) < 1e-4, relerr(dyu[:, :T].transpose(1, 2), yr.grad)

@@ -35,6 +35,7 @@ def main():
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--n', type=int, default=32)
     ap.add_argument('--t', type=int, default=1000)
+    ap.add_argument('--sweep', action='store_true', help='time every igemm block-shape candidate per layer')
     args = ap.parse_args()
     N = args.n
     uniq = []
@@ -59,10 +60,11 @@ def main():
         y = torch.empty(N, Tout, cout, dtype=torch.bfloat16, device='cuda')
         stats = torch.empty(L.lib.w2l_conv_stat_tiles(N, Tout), 2, cout, device='cuda')
         hb = (kw - 1) * d
-        ha = max(hb, (Tout + 63) // 64 * 64 - Tout)
-        dy = torch.zeros(N, hb + Tout + ha, cout, dtype=torch.bfloat16, device='cuda')
-        dy[:, hb:hb + Tout] = torch.randn(N, Tout, cout, device='cuda').to(torch.bfloat16)
-        dx = torch.empty(N, rows, cin, dtype=torch.bfloat16, device='cuda')
+        h = max(hb, (Tout + 63) // 64 * 64 - Tout)          # shared-halo layout
+        per = Tout + h
+        dy = torch.zeros(h + N * per, cout, dtype=torch.bfloat16, device='cuda')
+        dy[h:].view(N, per, cout)[:, :Tout] = torch.randn(N, Tout, cout, device='cuda').to(torch.bfloat16)
+        dx = torch.empty(N * per, cin, dtype=torch.bfloat16, device='cuda')
         dw = torch.zeros(kw, cout, cin, device='cuda')
         flops = 2.0 * N * Tout * cout * cin * kw
 
@@ -71,13 +73,26 @@ def main():
                                            cin, cout, Tout, kw, s, d, st))
 
         def dgrad():
-            L.check(L.lib.w2l_conv1d_igemm(L.ptr(dy), dy.shape[1] * cout, N * dy.shape[1], L.ptr(wd), L.ptr(dx), 0, 0, None,
-                                           None, N, cout, cin, rows, kw, 1, d, st))
+            L.check(L.lib.w2l_conv1d_igemm(C.c_void_p(dy.data_ptr() + (h - hb) * cout * 2), dy.shape[0] * cout,
+                                           dy.shape[0] - (h - hb), L.ptr(wd), L.ptr(dx), 0, 0, None, None, 1, cout, cin,
+                                           N * per, kw, 1, d, st))
 
         def wgrad():
-            L.check(L.lib.w2l_conv1d_wgrad(C.c_void_p(dy.data_ptr() + hb * cout * 2), dy.shape[1] * cout, L.ptr(x),
+            L.check(L.lib.w2l_conv1d_wgrad(C.c_void_p(dy.data_ptr() + h * cout * 2), per * cout, L.ptr(x),
                                            rows * cin, N * rows, L.ptr(dw), N, cin, cout, Tout, kw, s, d, 0, st))
 
+        if args.sweep:
+            res = []
+            for ci in range(10):
+                L.lib.w2l_conv_force_tile_config(ci)
+                try:
+                    a = timeit(fwd, args.reps)
+                    b = timeit(dgrad, args.reps) if s == 1 else float('nan')
+                except Exception as ex:      # config does not fit LDS
+                    a = b = float('nan')
+                res.append(f'cfg{ci}: fwd {flops / a / 1e9:5.0f} dgr {flops / b / 1e9:5.0f}')
+            L.lib.w2l_conv_force_tile_config(-1)
+            print('      ' + ' | '.join(res))
         tf = timeit(fwd, args.reps)
         td = timeit(dgrad, args.reps) if s == 1 else float('nan')
         tw = timeit(wgrad, args.reps)

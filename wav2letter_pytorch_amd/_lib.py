@@ -36,7 +36,7 @@ class BnActDesc(C.Structure):
 class GradSrc(C.Structure):
     """w2l_gradsrc_t (include/w2l_hip.h)."""
     _fields_ = [('dxp', c_p), ('f32', C.c_int32), ('pad_l', C.c_int32), ('pad_r', C.c_int32),
-                ('pad_mode', C.c_int32)]
+                ('pad_mode', C.c_int32), ('rows', C.c_int32)]
 
 
 _SIGNATURES = {
@@ -44,9 +44,10 @@ _SIGNATURES = {
     'w2l_abi_version': (c_i, []),
     'w2l_pack_weights': (c_i, [c_p, c_i64, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     'w2l_nct_to_ntc': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
-    'w2l_pad_cast': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    'w2l_pad_cast': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     'w2l_conv_stat_tiles': (c_i, [c_i, c_i]),
     'w2l_conv1d_igemm': (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'w2l_conv_force_tile_config': (None, [c_i]),
     'w2l_wgrad_needs_zero': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'w2l_conv1d_wgrad': (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'w2l_bn_finalize': (c_i, [c_p, c_i, c_i, c_i64, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
@@ -55,7 +56,7 @@ _SIGNATURES = {
     'w2l_bn_act_bwd_reduce': (c_i, [C.POINTER(BnActDesc), C.POINTER(GradSrc), C.POINTER(GradSrc), c_p, c_p]),
     'w2l_bn_bwd_finalize': (c_i, [c_p, c_i, c_i, c_p, c_p]),
     'w2l_bn_act_bwd_apply': (c_i, [C.POINTER(BnActDesc), C.POINTER(GradSrc), C.POINTER(GradSrc), c_p, c_p, c_p, c_i,
-                                   c_i, c_p, c_p, c_i, c_i, c_p]),
+                                   c_p, c_p, c_i, c_p]),
     'w2l_log_softmax_fwd': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'w2l_log_softmax_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     'w2l_ctc_workspace_bytes': (c_i64, [c_i, c_i, c_i]),

@@ -168,8 +168,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(w2l_bnact_t d, bf16_raw
 // ---------------------------------------------------------------- backward helpers
 template <bool GF32>
 __device__ __forceinline__ void add_grad8(const w2l_gradsrc_t& s, int n, int t, int T, int C, int cg, float g[8]) {
-    const int R = s.pad_l + T + s.pad_r;
-    const int64_t base = (int64_t)n * R;
+    const int64_t base = (int64_t)n * s.rows;
     float v[8];
     load8<GF32>(s.dxp, (base + t + s.pad_l) * C + cg * 8, v);
 #pragma unroll
@@ -295,59 +294,71 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
     }
 }
 
+// work items: [0, nvalid): one (n, t, channel-group) each -> compute dy (and dy2) and store into the
+// shared-halo buffers; [nvalid, nvalid + z1): zero rows of dy; then z2 zero rows of dy2.
 template <bool F32, bool GF32>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(w2l_bnact_t d, w2l_gradsrc_t g1, w2l_gradsrc_t g2,
                                                                 int has_g2, const float* sums, bf16_raw* dy_hi,
-                                                                bf16_raw* dy_lo, int hb, int ha, bf16_raw* dy2_hi,
-                                                                bf16_raw* dy2_lo, int hb2, int ha2, float inv_keep) {
+                                                                bf16_raw* dy_lo, int h1, bf16_raw* dy2_hi,
+                                                                bf16_raw* dy2_lo, int h2, float inv_keep) {
     const int G = d.C >> 3;
-    const int T = d.T;
-    const int lo_u = -(hb > hb2 ? hb : hb2);
-    const int hi_u = T + (ha > ha2 ? ha : ha2);
-    const int U = hi_u - lo_u;
-    const int R1 = hb + T + ha, R2 = hb2 + T + ha2;
-    const float invM = 1.f / ((float)d.N * (float)T);
-    const int64_t total = (int64_t)d.N * U * G;
+    const int T = d.T, N = d.N;
+    const float invM = 1.f / ((float)N * (float)T);
+    const int64_t nvalid = (int64_t)N * T * G;
+    const int64_t z1 = (int64_t)h1 * (N + 1) * G;
+    const int64_t z2 = dy2_hi ? (int64_t)h2 * (N + 1) * G : 0;
+    const int64_t total = nvalid + z1 + z2;
     for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+        if (it >= nvalid) {                       // zero-fill a halo row group
+            int64_t k = it - nvalid;
+            bf16_raw* hi = dy_hi; bf16_raw* lo = dy_lo; int h = h1;
+            if (k >= z1) { k -= z1; hi = dy2_hi; lo = dy2_lo; h = h2; }
+            const int cg = (int)(k % G);
+            const int64_t hr = k / G;              // index among the (N+1)*h halo rows
+            const int gap = (int)(hr / h), r = (int)(hr - (int64_t)gap * h);
+            const int64_t row = (int64_t)gap * (T + h) + r;
+            float z[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = 0.f;
+            store8_split(hi, lo, row * d.C + cg * 8, z);
+            continue;
+        }
         const int cg = (int)(it % G);
-        const int64_t urow = it / G;
-        const int n = (int)(urow / U);
-        const int t = (int)(urow - (int64_t)n * U) + lo_u;
+        const int64_t vrow = it / G;
+        const int n = (int)(vrow / T);
+        const int t = (int)(vrow - (int64_t)n * T);
         float o1[8], o2[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { o1[j] = 0.f; o2[j] = 0.f; }
-        if (t >= 0 && t < T) {
-            BwdRow o;
-            bwd_row<F32, GF32>(d, g1, has_g2 ? &g2 : nullptr, n, t, cg, G, inv_keep, o);
-            const int c = cg * 8;
-            if (d.mean) {
-                float sg[8], sgx[8], sc[8];
-                loadp8(sums, c, sg);
-                loadp8(sums + d.C, c, sgx);
-                loadp8(d.scale, c, sc);
+        BwdRow o;
+        bwd_row<F32, GF32>(d, g1, has_g2 ? &g2 : nullptr, n, t, cg, G, inv_keep, o);
+        const int c = cg * 8;
+        if (d.mean) {
+            float sg[8], sgx[8], sc[8];
+            loadp8(sums, c, sg);
+            loadp8(sums + d.C, c, sgx);
+            loadp8(d.scale, c, sc);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o1[j] = sc[j] * (o.g[j] - sg[j] * invM - o.xh1[j] * sgx[j] * invM);
+            for (int j = 0; j < 8; ++j) o1[j] = sc[j] * (o.g[j] - sg[j] * invM - o.xh1[j] * sgx[j] * invM);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o1[j] = o.g[j] * (d.scale ? d.scale[c + j] : 1.f);
+        }
+        store8_split(dy_hi, dy_lo, ((int64_t)h1 + (int64_t)n * (T + h1) + t) * d.C + c, o1);
+        if (dy2_hi) {
+            if (d.mean2) {
+                float sg[8], sgx[8], sc[8];
+                loadp8(sums + 2 * d.C, c, sg);
+                loadp8(sums + 3 * d.C, c, sgx);
+                loadp8(d.scale2, c, sc);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o2[j] = sc[j] * (o.g[j] - sg[j] * invM - o.xh2[j] * sgx[j] * invM);
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o1[j] = o.g[j] * (d.scale ? d.scale[c + j] : 1.f);
+                for (int j = 0; j < 8; ++j) o2[j] = o.g[j] * (d.scale2 ? d.scale2[c + j] : 1.f);
             }
-            if (d.y2) {
-                if (d.mean2) {
-                    float sg[8], sgx[8], sc[8];
-                    loadp8(sums + 2 * d.C, c, sg);
-                    loadp8(sums + 3 * d.C, c, sgx);
-                    loadp8(d.scale2, c, sc);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o2[j] = sc[j] * (o.g[j] - sg[j] * invM - o.xh2[j] * sgx[j] * invM);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o2[j] = o.g[j] * (d.scale2 ? d.scale2[c + j] : 1.f);
-                }
-            }
+            store8_split(dy2_hi, dy2_lo, ((int64_t)h2 + (int64_t)n * (T + h2) + t) * d.C + c, o2);
         }
-        const int r1 = t + hb, r2 = t + hb2;
-        if (dy_hi && r1 >= 0 && r1 < R1) store8_split(dy_hi, dy_lo, ((int64_t)n * R1 + r1) * d.C + cg * 8, o1);
-        if (dy2_hi && r2 >= 0 && r2 < R2) store8_split(dy2_hi, dy2_lo, ((int64_t)n * R2 + r2) * d.C + cg * 8, o2);
     }
 }
 
@@ -462,6 +473,8 @@ extern "C" int w2l_bn_act_bwd_reduce(const w2l_bnact_t* d, const w2l_gradsrc_t* 
     if (int e = check_desc(d, "bn_act_bwd_reduce")) return e;
     W2L_CHECK_ARG(g1 && g1->dxp && partial, "bn_act_bwd_reduce: null pointer");
     W2L_CHECK_ARG(!g2 || g2->f32 == g1->f32, "bn_act_bwd_reduce: gradient sources must share a dtype");
+    W2L_CHECK_ARG(g1->rows >= g1->pad_l + d->T + g1->pad_r && (!g2 || g2->rows >= g2->pad_l + d->T + g2->pad_r),
+                  "bn_act_bwd_reduce: gradient source has too few rows per utterance");
     const int G = d->C / 8;
     W2L_CHECK_ARG(G <= 256, "bn_act_bwd_reduce: C too large");
     const int RPB = 256 / G;
@@ -484,22 +497,24 @@ extern "C" int w2l_bn_bwd_finalize(const float* partial, int nblocks, int C, flo
 }
 
 extern "C" int w2l_bn_act_bwd_apply(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2,
-                                    const float* sums, void* dy_hi, void* dy_lo, int halo_b, int halo_a, void* dy2_hi,
-                                    void* dy2_lo, int halo2_b, int halo2_a, void* stream) {
+                                    const float* sums, void* dy_hi, void* dy_lo, int halo, void* dy2_hi, void* dy2_lo,
+                                    int halo2, void* stream) {
     if (int e = check_desc(d, "bn_act_bwd_apply")) return e;
     W2L_CHECK_ARG(g1 && g1->dxp && dy_hi, "bn_act_bwd_apply: null pointer");
     W2L_CHECK_ARG(!d->mean || sums, "bn_act_bwd_apply: BatchNorm backward needs the reduced sums");
     W2L_CHECK_ARG(!g2 || g2->f32 == g1->f32, "bn_act_bwd_apply: gradient sources must share a dtype");
-    W2L_CHECK_ARG(halo_b >= 0 && halo_a >= 0 && halo2_b >= 0 && halo2_a >= 0, "bn_act_bwd_apply: negative halo");
-    const int hbm = halo_b > halo2_b ? halo_b : halo2_b, ham = halo_a > halo2_a ? halo_a : halo2_a;
-    if (!dy2_hi) { halo2_b = 0; halo2_a = 0; }
-    const int U = (dy2_hi ? hbm : halo_b) + d->T + (dy2_hi ? ham : halo_a);
-    const int blocks = elementwise_blocks((int64_t)d->N * U * (d->C / 8));
+    W2L_CHECK_ARG(halo >= 0 && halo2 >= 0, "bn_act_bwd_apply: negative halo");
+    W2L_CHECK_ARG(g1->rows >= g1->pad_l + d->T + g1->pad_r && (!g2 || g2->rows >= g2->pad_l + d->T + g2->pad_r),
+                  "bn_act_bwd_apply: gradient source has too few rows per utterance");
+    const int G = d->C / 8;
+    const int64_t items = (int64_t)d->N * d->T * G + (int64_t)halo * (d->N + 1) * G +
+                          (dy2_hi ? (int64_t)halo2 * (d->N + 1) * G : 0);
+    const int blocks = elementwise_blocks(items);
     const float inv_keep = 1.f / (1.f - d->drop_p);
     w2l_gradsrc_t g2v = g2 ? *g2 : *g1;
     W2L_DISPATCH_BWD(bn_act_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d, *g1, g2v, g2 ? 1 : 0,
-                     sums, (bf16_raw*)dy_hi, (bf16_raw*)dy_lo, halo_b, halo_a, (bf16_raw*)dy2_hi, (bf16_raw*)dy2_lo,
-                     halo2_b, halo2_a, inv_keep);
+                     sums, (bf16_raw*)dy_hi, (bf16_raw*)dy_lo, halo, (bf16_raw*)dy2_hi, (bf16_raw*)dy2_lo, halo2,
+                     inv_keep);
     W2L_CHECK_LAUNCH();
     return 0;
 }

@@ -40,14 +40,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base
                                      (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmParams p) {
-    static_assert(BM == 128 && BN == 128, "2x2 waves of 64x64");
+// MW x NW waves, each owning MS x NS MFMA tiles of 16x16: block tile BM = 16*MW*MS (co) x BN = 16*NW*NS (t)
+template <int MW, int NW, int MS, int NS>
+__global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8 ? 2 : 2)) void conv_igemm_kernel(IgemmParams p) {
+    constexpr int BM = 16 * MW * MS, BN = 16 * NW * NS, NWAVES = MW * NW, NT = 64 * NWAVES;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NW, wn = wave % NW;
 
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = tile / p.ncols;
@@ -69,11 +70,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmParams p) {
     // ---- staging helpers (each wave-instruction writes 8 LDS rows = 1 KiB) ----
     const int srow = lane >> 3;                    // row within the 8-row group
     const int schunk = lane & 7;                   // LDS chunk this lane fills
-    const int gchunk = schunk ^ srow;              // source chunk (rows are 8-aligned per group: row&7 == srow)
+    const int gchunk = schunk ^ srow;              // source chunk (groups are 8-row aligned: row&7 == srow)
     auto stage_w = [&](char* dst, int kw, int c) {
-#pragma unroll
-        for (int i = 0; i < BM / 32; ++i) {        // 4 groups per wave
-            const int grp = wave * (BM / 32) + i;
+        for (int grp = wave; grp < BM / 8; grp += NWAVES) {
             int co = m0 + grp * 8 + srow;
             co = co < p.Cout ? co : p.Cout - 1;
             const bf16_raw* src = p.w + ((int64_t)kw * p.Cout + co) * Cin + c * BK + gchunk * 8;
@@ -82,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmParams p) {
     };
     auto stage_x = [&](char* dst, int c) {
         const int ngrp = xrows >> 3;
-        for (int grp = wave; grp < ngrp; grp += 4) {
+        for (int grp = wave; grp < ngrp; grp += NWAVES) {
             int64_t r = xrow0 + grp * 8 + srow;
             r = r < p.x_max_row ? r : p.x_max_row;
             const bf16_raw* src = p.x + r * Cin + c * BK + gchunk * 8;
@@ -90,25 +89,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmParams p) {
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[MS][NS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MS; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = Cin / BK;
     const int nsteps = nchunks * Kw;
 
     // per-lane read offsets
     const int fr = lane & 15, fq = lane >> 4;
-    int a_off[4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) a_off[mi] = (wm * 64 + mi * 16 + fr) * ROWB;
+    const int a_base = (wm * MS * 16 + fr) * ROWB;
     const int a_sw0 = ((fq) ^ (fr & 7)) << 4;          // k-substep 0: chunk fq
     const int a_sw1 = ((4 + fq) ^ (fr & 7)) << 4;      // k-substep 1: chunk 4+fq
-    int b_row[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) b_row[ni] = (wn * 64 + ni * 16 + fr) * s;
+    const int b_row0 = (wn * NS * 16 + fr) * s;
 
     stage_x(xbuf0, 0);
     stage_w(wbuf0, 0, 0);
@@ -129,19 +124,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmParams p) {
         const int shift = kw * d;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[4], b[4];
+            bf16x8 a[MS], b[NS];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-                a[mi] = *reinterpret_cast<const bf16x8*>(wb + a_off[mi] + (ks ? a_sw1 : a_sw0));
+            for (int mi = 0; mi < MS; ++mi)
+                a[mi] = *reinterpret_cast<const bf16x8*>(wb + a_base + mi * 16 * ROWB + (ks ? a_sw1 : a_sw0));
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int j = b_row[ni] + shift;
+            for (int ni = 0; ni < NS; ++ni) {
+                const int j = b_row0 + ni * 16 * s + shift;
                 b[ni] = *reinterpret_cast<const bf16x8*>(xb + j * ROWB + (((ks * 4 + fq) ^ (j & 7)) << 4));
             }
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MS; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < NS; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
         kw = kw_n;
@@ -149,20 +144,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmParams p) {
     }
 
     // ---- epilogue: bias, optional accumulate, store, BatchNorm partial statistics ----
-    // acc[mi][ni][r] = y[co = m0 + wm*64 + mi*16 + fq*4 + r][t = t0 + wn*64 + ni*16 + fr]
+    // acc[mi][ni][r] = y[co = m0 + (wm*MS+mi)*16 + fq*4 + r][t = t0 + (wn*NS+ni)*16 + fr]
     const int Cout = p.Cout, Tout = p.Tout;
-    float s1[4][4], s2[4][4];
+    float s1[MS][4], s2[MS][4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int co = m0 + wm * 64 + mi * 16 + fq * 4;
+    for (int mi = 0; mi < MS; ++mi) {
+        const int co = m0 + (wm * MS + mi) * 16 + fq * 4;
         const bool co_ok = co < Cout;
         f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
         if (p.bias && co_ok) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s1[mi][r] = 0.f; s2[mi][r] = 0.f; }
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int t = t0 + wn * 64 + ni * 16 + fr;
+        for (int ni = 0; ni < NS; ++ni) {
+            const int t = t0 + (wn * NS + ni) * 16 + fr;
             const bool ok = co_ok && t < Tout;
             f32x4 v = acc[mi][ni] + bias4;
             const int64_t off = ((int64_t)n * Tout + t) * Cout + co;
@@ -184,9 +179,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmParams p) {
     }
     if (p.stats) {
         __syncthreads();                               // main-loop LDS is dead from here
-        float* red = reinterpret_cast<float*>(smem);   // [2 wn][2][BM]
+        float* red = reinterpret_cast<float*>(smem);   // [NW][2][BM]
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MS; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float a = s1[mi][r], b = s2[mi][r];
@@ -196,21 +191,81 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmParams p) {
                     b += __shfl_xor(b, m, 64);
                 }
                 if (fr == 0) {
-                    const int cl = wm * 64 + mi * 16 + fq * 4 + r;
+                    const int cl = (wm * MS + mi) * 16 + fq * 4 + r;
                     red[(wn * 2 + 0) * BM + cl] = a;
                     red[(wn * 2 + 1) * BM + cl] = b;
                 }
             }
         __syncthreads();
-        if (tid < BM && m0 + tid < Cout) {
-            float* dst = p.stats + (int64_t)col * 2 * Cout;
-            dst[m0 + tid] = red[0 * BM + tid] + red[2 * BM + tid];
-            dst[Cout + m0 + tid] = red[1 * BM + tid] + red[3 * BM + tid];
+        for (int cl = tid; cl < BM; cl += NT) {
+            if (m0 + cl < Cout) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { a += red[(w * 2 + 0) * BM + cl]; b += red[(w * 2 + 1) * BM + cl]; }
+                float* dst = p.stats + (int64_t)col * 2 * Cout;
+                dst[m0 + cl] = a;
+                dst[Cout + m0 + cl] = b;
+            }
         }
     }
 }
 
+struct TileCfg { int mw, nw, ms, ns; float eff; };
+// candidate block shapes (BM = 16*mw*ms output channels x BN = 16*nw*ns time rows) with their measured
+// relative MFMA efficiency at full occupancy (tools/bench_conv.py --sweep, MI355X)
+constexpr TileCfg kCfgs[] = {
+    {2, 2, 2, 4, 0.80f}, {2, 2, 3, 4, 0.92f}, {2, 2, 4, 4, 0.94f}, {2, 2, 5, 4, 1.00f},   // BN 128, 4 waves
+    {4, 2, 3, 4, 0.84f}, {4, 2, 4, 4, 0.88f},                                               // BN 128, 8 waves
+    {2, 3, 2, 3, 0.78f}, {2, 3, 3, 3, 0.90f}, {2, 3, 4, 3, 0.93f}, {2, 3, 5, 3, 0.97f},   // BN 144, 6 waves
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+template <int MW, int NW, int MS, int NS>
+int launch_cfg(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream) {
+    auto kern = conv_igemm_kernel<MW, NW, MS, NS>;
+    W2L_CHECK_HIP(w2l_allow_big_lds((const void*)kern));
+    hipLaunchKernelGGL(kern, dim3(tiles_m * p.ncols), dim3(64 * MW * NW), lds, stream, p);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
+
+static int g_force_cfg = -1;
+extern "C" void w2l_conv_force_tile_config(int idx) { g_force_cfg = idx; }
+
+static inline int cfg_xrows(const TileCfg& c, int stride, int Kw, int dil) {
+    const int bn = 16 * c.nw * c.ns;
+    return ((bn - 1) * stride + (Kw - 1) * dil + 1 + 7) & ~7;
+}
+
+// pick the block shape: whole rounds of resident blocks on the 256 CUs, larger tiles preferred
+static int choose_cfg(int N, int Cout, int Tout, int Kw, int stride, int dil, bool need_bn128) {
+    int best = -1;
+    double best_cost = 1e30;
+    for (int i = 0; i < kNumCfgs; ++i) {
+        const TileCfg& c = kCfgs[i];
+        const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
+        if (need_bn128 && bn != 128) continue;
+        if (g_force_cfg >= 0 && g_force_cfg < kNumCfgs && i != g_force_cfg) continue;
+        const size_t lds = 2 * (size_t)bm * ROWB + 2 * (size_t)cfg_xrows(c, stride, Kw, dil) * ROWB;
+        if (lds > 160 * 1024) continue;
+        const int waves = c.mw * c.nw;
+        int per_cu = (int)((160 * 1024) / lds);
+        const int wave_cap = 16 / waves;                 // <= 16 waves per CU at the VGPR budget of these kernels
+        if (per_cu > wave_cap) per_cu = wave_cap;
+        if (per_cu < 1) continue;
+        const long blocks = (long)((Cout + bm - 1) / bm) * N * ((Tout + bn - 1) / bn);
+        const long slots = 256L * per_cu;
+        const long rounds = (blocks + slots - 1) / slots;
+        // time ~ rounds x (work per block) x (blocks sharing a CU) / efficiency
+        double eff = c.eff * (per_cu * waves >= 8 ? 1.0 : 0.75);
+        double cost = (double)rounds * bm * bn * per_cu / eff;
+        cost *= 1.0 + 1e-3 * i;                          // stable tie-break
+        if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+    return best;
+}
 
 extern "C" int w2l_conv_stat_tiles(int N, int Tout) { return N * ((Tout + 127) / 128); }
 
@@ -223,7 +278,6 @@ extern "C" int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_row
     W2L_CHECK_ARG(Cout % 64 == 0 && Cout > 0, "conv1d_igemm: Cout=%d must be a positive multiple of 64", Cout);
     W2L_CHECK_ARG(x_bstride % Cin == 0, "conv1d_igemm: x_bstride must be a multiple of Cin");
     W2L_CHECK_ARG(!(accumulate && !y_f32), "conv1d_igemm: accumulate needs fp32 output");
-    constexpr int BM = 128, BN = 128;
     IgemmParams p;
     p.x = (const bf16_raw*)xp;
     p.w = (const bf16_raw*)w;
@@ -233,22 +287,32 @@ extern "C" int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_row
     p.x_rows_per_utt = x_bstride / Cin;
     p.x_max_row = x_rows_total - 1;
     p.N = N; p.Cin = Cin; p.Cout = Cout; p.Tout = Tout; p.Kw = Kw; p.stride = stride; p.dil = dil;
-    p.tiles_t = (Tout + BN - 1) / BN;
-    p.ncols = N * p.tiles_t;
-    const int xr = (BN - 1) * stride + (Kw - 1) * dil + 1;
-    p.xrows_lds = (xr + 7) & ~7;
     p.y_f32 = y_f32; p.accumulate = accumulate;
     // the last valid output row must only need rows that exist in the padded buffer
     const int64_t need = (int64_t)(N - 1) * p.x_rows_per_utt + (int64_t)(Tout - 1) * stride + (int64_t)(Kw - 1) * dil;
     W2L_CHECK_ARG(need <= p.x_max_row, "conv1d_igemm: padded input too small (need row %lld, have %lld)",
                   (long long)need, (long long)p.x_max_row);
-    const int tiles_m = (Cout + BM - 1) / BM;
-    const size_t lds = 2 * BM * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
-    W2L_CHECK_ARG(lds <= 160 * 1024, "conv1d_igemm: window of %d rows does not fit LDS", p.xrows_lds);
-    auto kern = conv_igemm_kernel<BM, BN>;
-    W2L_CHECK_HIP(w2l_allow_big_lds((const void*)kern));
-    dim3 grid(tiles_m * p.ncols), block(256);
-    hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, p);
-    W2L_CHECK_LAUNCH();
-    return 0;
+    // BatchNorm partial statistics are laid out per 128-row column tile (w2l_conv_stat_tiles)
+    const int ci = choose_cfg(N, Cout, Tout, Kw, stride, dil, stats_partial != nullptr);
+    W2L_CHECK_ARG(ci >= 0, "conv1d_igemm: no block shape fits LDS (Kw=%d dil=%d stride=%d)", Kw, dil, stride);
+    const TileCfg& c = kCfgs[ci];
+    const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
+    p.tiles_t = (Tout + bn - 1) / bn;
+    p.ncols = N * p.tiles_t;
+    p.xrows_lds = cfg_xrows(c, stride, Kw, dil);
+    const int tiles_m = (Cout + bm - 1) / bm;
+    const size_t lds = 2 * (size_t)bm * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
+    hipStream_t st = (hipStream_t)stream;
+    switch (ci) {
+        case 0: return launch_cfg<2, 2, 2, 4>(p, tiles_m, lds, st);
+        case 1: return launch_cfg<2, 2, 3, 4>(p, tiles_m, lds, st);
+        case 2: return launch_cfg<2, 2, 4, 4>(p, tiles_m, lds, st);
+        case 3: return launch_cfg<2, 2, 5, 4>(p, tiles_m, lds, st);
+        case 4: return launch_cfg<4, 2, 3, 4>(p, tiles_m, lds, st);
+        case 5: return launch_cfg<4, 2, 4, 4>(p, tiles_m, lds, st);
+        case 6: return launch_cfg<2, 3, 2, 3>(p, tiles_m, lds, st);
+        case 7: return launch_cfg<2, 3, 3, 3>(p, tiles_m, lds, st);
+        case 8: return launch_cfg<2, 3, 4, 3>(p, tiles_m, lds, st);
+        default: return launch_cfg<2, 3, 5, 3>(p, tiles_m, lds, st);
+    }
 }

@@ -75,16 +75,19 @@ __global__ void nct_to_ntc_kernel(const float* x, int C, int T, int CP, int R, i
     }
 }
 
-__global__ void pad_cast_kernel(const float* g, int T, int C, int CP, int R, int halo_b, bf16_raw* out_hi,
-                                bf16_raw* out_lo, int64_t total) {
+// shared-halo layout: row = halo + n*(T+halo) + t
+__global__ void pad_cast_kernel(const float* g, int T, int C, int CP, int halo, bf16_raw* out_hi, bf16_raw* out_lo,
+                                int64_t total) {
+    const int P = T + halo;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % CP);
-        const int64_t row = i / CP;
-        const int r = (int)(row % R);
-        const int64_t n = row / R;
-        const int t = r - halo_b;
+        const int64_t q = i / CP - halo;
         float v = 0.f;
-        if (t >= 0 && t < T && c < C) v = g[(n * T + t) * C + c];
+        if (q >= 0) {
+            const int64_t n = q / P;
+            const int t = (int)(q - n * P);
+            if (t < T && c < C) v = g[(n * T + t) * C + c];
+        }
         put_split(out_hi, out_lo, i, v);
     }
 }
@@ -133,14 +136,13 @@ extern "C" int w2l_nct_to_ntc(const float* x, int N, int C, int T, int CP, int p
     return 0;
 }
 
-extern "C" int w2l_pad_cast(const float* g, int N, int T, int C, int CP, int halo_b, int halo_a, void* out_hi,
-                            void* out_lo, float* colsum, void* stream) {
+extern "C" int w2l_pad_cast(const float* g, int N, int T, int C, int CP, int halo, void* out_hi, void* out_lo,
+                            float* colsum, void* stream) {
     W2L_CHECK_ARG(g && out_hi, "pad_cast: null pointer");
-    W2L_CHECK_ARG(N > 0 && T > 0 && C > 0 && CP >= C && halo_b >= 0 && halo_a >= 0, "pad_cast: bad sizes");
-    const int R = halo_b + T + halo_a;
-    const int64_t total = (int64_t)N * R * CP;
+    W2L_CHECK_ARG(N > 0 && T > 0 && C > 0 && CP >= C && halo >= 0, "pad_cast: bad sizes");
+    const int64_t total = ((int64_t)halo + (int64_t)N * (T + halo)) * CP;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pad_cast_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, T, C, CP, R, halo_b,
+    hipLaunchKernelGGL(pad_cast_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, T, C, CP, halo,
                        (bf16_raw*)out_hi, (bf16_raw*)out_lo, total);
     W2L_CHECK_LAUNCH();
     if (colsum) {

@@ -445,19 +445,19 @@ class StackEngine:
               'w2l_log_softmax_bwd')
         head = self.head
         pk = pack_weights(head, precise)
-        tail = roundup(Th, 64) - Th
-        dy_hi = torch.empty(N, Th + tail, pk.coutp, dtype=torch.bfloat16, device=dev)
+        hh = roundup(Th, 64) - Th                    # shared-halo layout (include/w2l_hip.h): halo + N*(T+halo) rows
+        dy_hi = torch.empty(hh + N * (Th + hh), pk.coutp, dtype=torch.bfloat16, device=dev)
         dy_lo = torch.empty_like(dy_hi) if precise else None
         colsum = torch.empty(pk.coutp, dtype=torch.float32, device=dev)
-        check(lib.w2l_pad_cast(ptr(glog), N, Th, L, pk.coutp, 0, tail, ptr(dy_hi), ptr(dy_lo), ptr(colsum), st()),
+        check(lib.w2l_pad_cast(ptr(glog), N, Th, L, pk.coutp, hh, ptr(dy_hi), ptr(dy_lo), ptr(colsum), st()),
               'w2l_pad_cast')
         last = acts[-1]
-        self._wgrad(head, pk, dy_hi, dy_lo, 0, Th, last, grads)
+        self._wgrad(head, pk, dy_hi, dy_lo, hh, Th, last, grads)
         if head.bias is not None:
             grads[id(head.bias)] = colsum[: head.cout]
             self._notify(head.bias, grads[id(head.bias)])
         act_grads: List[List[tuple]] = [[] for _ in acts]
-        act_grads[len(acts) - 1].append(self._dgrad(head, pk, dy_hi, dy_lo, 0, last))
+        act_grads[len(acts) - 1].append(self._dgrad(head, pk, dy_hi, dy_lo, hh, Th, last))
 
         # ---- units in reverse
         for uc in reversed(ctx['units']):
@@ -484,20 +484,19 @@ class StackEngine:
                 check(lib.w2l_bn_bwd_finalize(ptr(partial), nb, coutp, ptr(sums), st()), 'w2l_bn_bwd_finalize')
                 uc.keep.append((partial, sums))
             main, res = u.main, u.res
-            hb = (main.kernel - 1) * main.dilation
             need_dx_main = self._needs_grad(u.src)
-            ha = max(hb, roundup(Tout, 64) - Tout)
-            dy_hi = torch.empty(N, hb + Tout + ha, coutp, dtype=torch.bfloat16, device=dev)
+            tail = roundup(Tout, 64) - Tout              # wgrad walks each utterance in 64-row steps over zero rows
+            h1 = max((main.kernel - 1) * main.dilation, tail)
+            dy_hi = torch.empty(h1 + N * (Tout + h1), coutp, dtype=torch.bfloat16, device=dev)
             dy_lo = torch.empty_like(dy_hi) if precise else None
             dy2_hi = dy2_lo = None
-            hb2 = ha2 = 0
+            h2 = 0
             if res is not None:
-                hb2 = (res.kernel - 1) * res.dilation
-                ha2 = max(hb2, roundup(Tout, 64) - Tout)
-                dy2_hi = torch.empty(N, hb2 + Tout + ha2, coutp, dtype=torch.bfloat16, device=dev)
+                h2 = max((res.kernel - 1) * res.dilation, tail)
+                dy2_hi = torch.empty(h2 + N * (Tout + h2), coutp, dtype=torch.bfloat16, device=dev)
                 dy2_lo = torch.empty_like(dy2_hi) if precise else None
             check(lib.w2l_bn_act_bwd_apply(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(sums), ptr(dy_hi),
-                                           ptr(dy_lo), hb, ha, ptr(dy2_hi), ptr(dy2_lo), hb2, ha2, st()),
+                                           ptr(dy_lo), h1, ptr(dy2_hi), ptr(dy2_lo), h2, st()),
                   'w2l_bn_act_bwd_apply')
             # release the consumed gradient buffers early
             act_grads[oi] = []
@@ -511,22 +510,23 @@ class StackEngine:
             # main branch
             pkm = pack_weights(main, precise)
             src = acts[u.src]
-            self._wgrad(main, pkm, dy_hi, dy_lo, hb, Tout, src, grads)
+            self._wgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, grads)
             if main.bias is not None:
                 if main.has_bn:      # sum(dy) == 0 identically under BatchNorm
                     self._set(grads, main.bias, torch.zeros(main.cout, dtype=torch.float32, device=dev))
                 else:
-                    self._set(grads, main.bias, dy_hi[:, hb:hb + Tout, : main.cout].float().sum((0, 1)))
+                    dyv = dy_hi[h1:].view(N, Tout + h1, coutp)[:, :Tout, : main.cout]
+                    self._set(grads, main.bias, dyv.float().sum((0, 1)))
             if need_dx_main:
-                act_grads[u.src].append(self._dgrad(main, pkm, dy_hi, dy_lo, hb, src))
+                act_grads[u.src].append(self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src))
             if res is not None:
                 pkr = pack_weights(res, precise)
                 rsrc = acts[u.res_src]
-                self._wgrad(res, pkr, dy2_hi, dy2_lo, hb2, Tout, rsrc, grads)
+                self._wgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc, grads)
                 if res.bias is not None:
                     self._set(grads, res.bias, torch.zeros(res.cout, dtype=torch.float32, device=dev))
                 if self._needs_grad(u.res_src):
-                    act_grads[u.res_src].append(self._dgrad(res, pkr, dy2_hi, dy2_lo, hb2, rsrc))
+                    act_grads[u.res_src].append(self._dgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc))
         if getattr(self, '_side_used', False):
             main = torch.cuda.current_stream(dev)
             main.wait_stream(self._side)
@@ -551,17 +551,17 @@ class StackEngine:
         self._notify(param, grad, storage)
 
     def _gsrc(self, s) -> GradSrc:
-        t, pl, pr, mode = s
+        t, pl, pr, mode, rows = s
         g = GradSrc()
         g.dxp = t.data_ptr()
         g.f32 = int(t.dtype == torch.float32)
-        g.pad_l, g.pad_r, g.pad_mode = pl, pr, mode
+        g.pad_l, g.pad_r, g.pad_mode, g.rows = pl, pr, mode, rows
         return g
 
-    def _wgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, hb, Tout, src: Act, grads):
+    def _wgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, grads):
         """dW on the side stream (ordered after everything enqueued so far on the current stream)."""
         if not self.overlap_wgrad or not dy_hi.is_cuda:
-            return self._wgrad_now(conv, pk, dy_hi, dy_lo, hb, Tout, src, grads)
+            return self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads)
         main = torch.cuda.current_stream(dy_hi.device)
         if self._side is None or self._side.device != dy_hi.device:
             self._side = torch.cuda.Stream(device=dy_hi.device)
@@ -570,13 +570,13 @@ class StackEngine:
         ev.record(main)
         side.wait_event(ev)
         with torch.cuda.stream(side):
-            self._wgrad_now(conv, pk, dy_hi, dy_lo, hb, Tout, src, grads)
+            self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads)
         for t in (dy_hi, dy_lo, src.hi, src.lo):
             if t is not None:
                 t.record_stream(side)
         self._side_used = True
 
-    def _wgrad_now(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, hb, Tout, src: Act, grads):
+    def _wgrad_now(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, grads):
         """dW through w2l_conv1d_wgrad, written in the parameter's own physical layout when possible."""
         w = conv.weight
         cout, cin, kw = w.shape
@@ -589,11 +589,11 @@ class StackEngine:
         row_off = src.pad_l - conv.pad_l
         x_bstride = src.rows * src.CP
         x_rows_total = N * src.rows - row_off
-        dy_bstride = dy_hi.shape[1] * dy_hi.shape[2]
+        dy_bstride = (Tout + halo) * pk.coutp          # shared-halo layout: utterance n starts at row halo + n*(Tout+halo)
         st = stream_ptr()
 
         def run(dy, x, acc):
-            check(lib.w2l_conv1d_wgrad(C.c_void_p(dy.data_ptr() + hb * pk.coutp * 2), dy_bstride,
+            check(lib.w2l_conv1d_wgrad(C.c_void_p(dy.data_ptr() + halo * pk.coutp * 2), dy_bstride,
                                        C.c_void_p(x.data_ptr() + row_off * src.CP * 2), x_bstride, x_rows_total,
                                        ptr(dw), N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, acc, st),
                   'w2l_conv1d_wgrad')
@@ -610,18 +610,23 @@ class StackEngine:
             g = g[:cout, :cin, :]
         self._set(grads, w, g, storage=dw)
 
-    def _dgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, hb, src: Act):
-        """dXpad (gradient wrt the conv's padded input) through the same implicit-GEMM kernel."""
+    def _dgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act):
+        """dXpad (gradient wrt the conv's padded input) through the same implicit-GEMM kernel, run over
+        the shared-halo dy buffer as ONE sequence of N*(Tout+halo) rows: tiles never straddle a partially
+        filled per-utterance remainder.  Row v of utterance n lands at output row n*(Tout+halo) + v."""
         if conv.stride != 1:
             raise NotImplementedError('data gradient of a strided convolution (only the first layer is strided, '
                                       'and the spectrogram needs no gradient)')
         N = src.N
         Tp = src.T + conv.pad_l + conv.pad_r
+        hb = (conv.kernel - 1) * conv.dilation
+        assert Tp == Tout + hb and halo >= hb
         dev = dy_hi.device
-        dxp = torch.empty(N, Tp, pk.cinp, dtype=torch.float32 if self.precise else torch.bfloat16, device=dev)
-        rows = dy_hi.shape[1]
-        dyact = Act(dy_hi, dy_lo, N, rows, pk.coutp, pk.coutp, 0, 0, PAD_ZERO)
-        Tout = Tp - (conv.kernel - 1) * conv.dilation
-        _igemm(dyact, 0, pk.dgr_hi, pk.dgr_lo, dxp, None, None, pk.coutp, pk.cinp, Tp, conv.kernel, 1, conv.dilation,
-               self.precise, alg_flops=2.0 * N * Tout * conv.cout * conv.cin * conv.kernel)
-        return (dxp, conv.pad_l, conv.pad_r, conv.pad_mode)
+        per = Tout + halo
+        flat_rows = N * per
+        dxp = torch.empty(flat_rows, pk.cinp, dtype=torch.float32 if self.precise else torch.bfloat16, device=dev)
+        total = dy_hi.shape[0]
+        dyact = Act(dy_hi, dy_lo, 1, total, pk.coutp, pk.coutp, 0, 0, PAD_ZERO)
+        _igemm(dyact, halo - hb, pk.dgr_hi, pk.dgr_lo, dxp, None, None, pk.coutp, pk.cinp, flat_rows, conv.kernel, 1,
+               conv.dilation, self.precise, alg_flops=2.0 * N * Tout * conv.cout * conv.cin * conv.kernel)
+        return (dxp, conv.pad_l, conv.pad_r, conv.pad_mode, per)
