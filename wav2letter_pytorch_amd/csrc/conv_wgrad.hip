@@ -7,8 +7,11 @@
 // the MFMA fragments (8 consecutive k per lane) are column reads of the LDS
 // images: they are fetched with ds_read_b64_tr_b16, CDNA4's transposing LDS
 // read, from row-major [t][channel] tiles that LDS-DMA fills straight from HBM.
-// One block owns a [128 co x 128 ci] tile of one tap and a slice of the (n,t)
-// range (split-K); partial tiles are combined with fp32 atomics.
+// One block owns a [128 co x 128 ci] tile of KWB adjacent taps and a slice of the
+// (n,t) range (split-K; partial tiles are combined with fp32 atomics).  The taps
+// share the dy tile and read the same staged x window at row offsets tap*d, which
+// halves the L2->LDS traffic per FLOP -- the kernel is fabric-bound, not MFMA-bound,
+// with one tap per block (11.6 GB of tile reads for an 896x896x29 layer).
 //
 // Replaces the weight-gradient half of aten::convolution_backward for the
 // nn.Conv1d call sites wav2letter.py:35-36,42 / jasper.py:96-105,127.
@@ -21,6 +24,8 @@ constexpr int BNC = 128;      // ci per block
 constexpr int BT = 64;        // t rows per K step
 constexpr int ROWB = 256;     // bytes per LDS row (128 bf16)
 
+constexpr int KWB_DEFAULT = 2;   // taps per block
+
 struct WgradParams {
     const bf16_raw* dy;
     const bf16_raw* x;
@@ -29,7 +34,7 @@ struct WgradParams {
     int64_t x_rows_per_utt;
     int64_t x_max_row;
     int N, Cin, Cout, Tout, Kw, stride, dil;
-    int tiles_m, tiles_n, tsteps, total_steps, steps_per_split, atomic;
+    int tiles_m, tiles_n, kgroups, tsteps, total_steps, steps_per_split, atomic;
     int xrows_lds;
 };
 
@@ -46,6 +51,7 @@ __device__ __forceinline__ bf16x4 tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
 }
 
+template <int KWB>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
@@ -58,12 +64,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     const int tm = tile % p.tiles_m;
     tile /= p.tiles_m;
     const int tn = tile % p.tiles_n;
-    const int kw = tile / p.tiles_n;
+    const int kw0 = (tile / p.tiles_n) * KWB;      // first tap of this block's group
+    const int ntaps = (p.Kw - kw0) < KWB ? (p.Kw - kw0) : KWB;
     const int split = blockIdx.y;
     const int m0 = tm * BM, c0 = tn * BNC;
-    const int s = p.stride;
-    const int shift = kw * p.dil;
-    const int xrows = p.xrows_lds;                 // (BT-1)*s + 1 rounded up to 4
+    const int s = p.stride, d = p.dil;
+    const int shift = kw0 * d;
+    const int xrows = p.xrows_lds;                 // (BT-1)*s + (KWB-1)*d + 1 rounded up to 4
 
     char* abuf0 = smem;                            // dy tile  [BT][128 co]
     char* abuf1 = smem + BT * ROWB;
@@ -100,11 +107,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[KWB][4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int tp = 0; tp < KWB; ++tp)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[tp][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int step_begin = split * p.steps_per_split;
     int step_end = step_begin + p.steps_per_split;
@@ -132,61 +141,90 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         const char* bb = par ? bbuf1 : bbuf0;
 #pragma unroll
         for (int ks = 0; ks < BT / 32; ++ks) {
-            bf16x8 a[4], b[4];
+            bf16x8 a[4];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int k = ks * 32 + kgrp * 8 + h * 4 + q;      // t row this lane addresses
-                const int ra = k;
-                const int rb = k * s;
-                const int ka = row_key(ra) << 5, kb = row_key(rb) << 5;
+                const int ra = ks * 32 + kgrp * 8 + h * 4 + q;     // t row this lane addresses
+                const int ka = row_key(ra) << 5;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const bf16x4 va = tr_read(ab + ra * ROWB + (a_col[i] ^ ka));
-                    const bf16x4 vb = tr_read(bb + rb * ROWB + (b_col[i] ^ kb));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        a[i][h * 4 + e] = va[e];
-                        b[i][h * 4 + e] = vb[e];
-                    }
+                    for (int e = 0; e < 4; ++e) a[i][h * 4 + e] = va[e];
                 }
             }
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int tp = 0; tp < KWB; ++tp) {
+                if (tp < ntaps) {                                   // wave-uniform
+                    bf16x8 b[4];
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                    for (int h = 0; h < 2; ++h) {
+                        const int rb = (ks * 32 + kgrp * 8 + h * 4 + q) * s + tp * d;
+                        const int kb = row_key(rb) << 5;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const bf16x4 vb = tr_read(bb + rb * ROWB + (b_col[i] ^ kb));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) b[i][h * 4 + e] = vb[e];
+                        }
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+                            acc[tp][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[tp][mi][ni], 0, 0, 0);
+                }
+            }
         }
     }
 
-    // ---- epilogue: acc[mi][ni][r] = dw[kw][co = m0+wm*64+mi*16+fq*4+r][ci = c0+wn*64+ni*16+fr] ----
+    // ---- epilogue: acc[tp][mi][ni][r] = dw[kw0+tp][co = m0+wm*64+mi*16+fq*4+r][ci = c0+wn*64+ni*16+fr] ----
     const int fr = lane & 15, fq = lane >> 4;
-    float* base = p.dw + (int64_t)kw * p.Cout * p.Cin;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int tp = 0; tp < KWB; ++tp) {
+        if (tp >= ntaps) break;
+        float* base = p.dw + (int64_t)(kw0 + tp) * p.Cout * p.Cin;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int ci = c0 + wn * 64 + ni * 16 + fr;
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = m0 + wm * 64 + mi * 16 + fq * 4 + r;
-                if (co < p.Cout && ci < p.Cin) {
-                    float* dst = base + (int64_t)co * p.Cin + ci;
-                    if (p.atomic) atomicAdd(dst, acc[mi][ni][r]);
-                    else *dst = acc[mi][ni][r];
+            for (int ni = 0; ni < 4; ++ni) {
+                const int ci = c0 + wn * 64 + ni * 16 + fr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = m0 + wm * 64 + mi * 16 + fq * 4 + r;
+                    if (co < p.Cout && ci < p.Cin) {
+                        float* dst = base + (int64_t)co * p.Cin + ci;
+                        if (p.atomic) atomicAdd(dst, acc[tp][mi][ni][r]);
+                        else *dst = acc[tp][mi][ni][r];
+                    }
                 }
             }
-        }
+    }
 }
 
+// Split the (n,t) reduction over `splits` blocks per tile so that the grid fills whole rounds of the
+// 512 resident blocks (256 CUs x 2): cost = rounds x steps-per-block (+ the fp32 atomic traffic of the
+// extra partial tiles, ~1.3 TB/s chip-wide).  Non-power-of-two splits are allowed.
 int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out) {
-    const int tiles = ((Cout + BM - 1) / BM) * ((Cin + BNC - 1) / BNC) * Kw;
+    const int kwb = Kw > 1 ? KWB_DEFAULT : 1;
+    const int tiles = ((Cout + BM - 1) / BM) * ((Cin + BNC - 1) / BNC) * ((Kw + kwb - 1) / kwb);
     const int tsteps = (Tout + BT - 1) / BT;
     const int total = N * tsteps;
     if (tsteps_out) *tsteps_out = tsteps;
-    // aim for >= 512 blocks (256 CUs x 2 resident blocks), keep >= 8 K-steps per block
-    int splits = 1;
-    while (tiles * splits < 512 && total / (splits * 2) >= 8) splits *= 2;
-    return splits;
+    const double t_step_us = 2.7 * kwb / 2.0;                       // one 64-row K step of a block sharing its CU
+    const double out_us = (double)Cout * Cin * Kw * 4.0 / 1.3e6;    // one full pass of fp32 atomics over dw
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 32 && s <= total; ++s) {
+        const int steps = (total + s - 1) / s;
+        if (s > 1 && steps < 4) break;
+        const long blocks = (long)tiles * s;
+        const long rounds = (blocks + 511) / 512;
+        double per_step = t_step_us * (blocks <= 256 ? 0.6 : 1.0);  // a block alone on its CU runs faster
+        double cost = rounds * steps * per_step + (s > 1 ? 0.5 * out_us * s : 0.0);
+        if (cost < best_cost * 0.97) { best_cost = cost; best = s; }
+    }
+    return best;
 }
 
 }  // namespace
@@ -217,12 +255,19 @@ extern "C" int w2l_conv1d_wgrad(const void* dy, int64_t dy_bstride, const void* 
     p.total_steps = N * p.tsteps;
     p.steps_per_split = (p.total_steps + splits - 1) / splits;
     p.atomic = (splits > 1) || accumulate;
-    const int xr = (BT - 1) * stride + 1;
+    const int kwb = Kw > 1 ? KWB_DEFAULT : 1;
+    p.kgroups = (Kw + kwb - 1) / kwb;
+    const int xr = (BT - 1) * stride + (kwb - 1) * dil + 1;
     p.xrows_lds = (xr + 3) & ~3;
     const size_t lds = 2 * BT * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
-    W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel));
-    dim3 grid(p.tiles_m * p.tiles_n * Kw, splits), block(256);
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, block, lds, (hipStream_t)stream, p);
+    dim3 grid(p.tiles_m * p.tiles_n * p.kgroups, splits), block(256);
+    if (kwb == 2) {
+        W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<2>));
+        hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, block, lds, (hipStream_t)stream, p);
+    } else {
+        W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<1>));
+        hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, block, lds, (hipStream_t)stream, p);
+    }
     W2L_CHECK_LAUNCH();
     return 0;
 }
