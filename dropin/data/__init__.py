@@ -1,0 +1,1 @@
+from wav2letter_pytorch_amd.data import label_sets  # noqa: F401
