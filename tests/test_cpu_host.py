@@ -1,0 +1,232 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/w2l_hip.h declares,
+the host-side mirror of the reference interface (module tree, state-dict names, pad rule, config
+loader, decoder string logic, Levenshtein), the loud failure on CPU tensors, and the data-parallel
+reducer over gloo with world_size 2.  No kernel is launched here."""
+import ast
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def test_abi_exports_every_declared_symbol():
+    from wav2letter_pytorch_amd import _lib
+    text = open(os.path.join(ROOT, 'include', 'w2l_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    declared = set(re.findall(r'\b(w2l_[a-z0-9_]+)\s*\(', text))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(_lib.lib, name), f'{name} declared in the header but not exported'
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert _lib.lib.w2l_abi_version() == 1
+
+
+def _cfg(mid_layers=20, **kw):
+    from wav2letter_pytorch_amd.config import to_cfg
+    from wav2letter_pytorch_amd.data import label_sets
+    sys.path.insert(0, ROOT)
+    from oracle.w2l_oracle import W2L_LAYERS
+    labels = label_sets.labels_map['english_lowercase']
+    d = dict(name='wav2letter', mid_layers=mid_layers, input_size=64, labels=labels,
+             layers=[dict(output_size=c, kernel_size=k, stride=s, dilation=dl, dropout=p) for c, k, s, dl, p in W2L_LAYERS],
+             audio_conf=dict(window='hamming', window_stride=0.01, window_size=0.02, sample_rate=16000),
+             decoder=dict(_target_='decoder.GreedyDecoder', labels=labels),
+             optimizer=dict(_target_='torch.optim.SGD', lr=1e-5, momentum=0.9, nesterov=True, weight_decay=1e-5),
+             scheduler=dict(_target_='torch.optim.lr_scheduler.ExponentialLR', gamma=0.999))
+    d.update(kw)
+    return to_cfg(d)
+
+
+def test_label_sets_match_reference_semantics():
+    from wav2letter_pytorch_amd.data import label_sets
+    lab = label_sets.labels_map['english_lowercase']
+    assert len(lab) == 29 and lab[0] == '_' and lab[-1] == ' ' and lab[1] == "'" and lab[2] == 'a'
+    assert label_sets.labels_map['english'][2] == 'A' and len(label_sets.labels_map['hebrew']) == 29
+
+
+def test_wav2letter_module_surface_full_table():
+    from wav2letter_pytorch_amd import Wav2Letter
+    m = Wav2Letter(_cfg(20))
+    sd = m.state_dict()
+    n_params = sum(p.numel() for p in m.parameters())
+    from oracle.w2l_oracle import W2L_LAYERS
+    cin, expect = 64, 0
+    for c, k, _, _, _ in W2L_LAYERS:
+        expect += c * cin * k + c + 2 * c       # conv weight + bias, BN gamma + beta
+        cin = c
+    expect += 29 * cin + 29
+    assert n_params == expect and round(n_params / 1e6, 2) == 153.07          # 153.07 M params
+    assert m.scaling_factor == 2 and m.mid_layers == 20 and m.input_size == 64
+    assert torch.equal(m.compute_output_lengths(torch.tensor([1000, 801])), torch.tensor([500, 400]))
+    keys = list(sd.keys())
+    assert keys[0] == 'conv1ds.conv1d_0.conv1.weight' and 'conv1ds.conv1d_0.batch_norm.num_batches_tracked' in sd
+    assert 'conv1ds.conv1d_20.conv1.bias' in sd and 'conv1ds.conv1d_20.batch_norm.weight' not in sd
+    assert sd['conv1ds.conv1d_16.conv1.weight'].shape == (896, 768, 29)
+    pads = [(b.pad_l, b.pad_r) for b in m.conv1ds.children()]
+    assert pads[0] == (4, 5) and pads[1] == (5, 5) and pads[16] == (28, 28) and pads[19] == (0, 0) and pads[20] == (0, 0)
+    bn = m.conv1ds.conv1d_3.batch_norm
+    assert bn.momentum == 0.9 and bn.eps == 0.001
+    eng = m.engine()
+    assert len(eng.units) == 20 and len(eng.parameters()) == len(list(m.parameters()))
+    assert m.example_input_array[0].shape == (4, 64, 200)
+    opt, sch = m.configure_optimizers()
+    assert isinstance(opt[0], torch.optim.SGD) and opt[0].defaults['nesterov']
+    # default shipped truncation: mid_layers = 1
+    m1 = Wav2Letter(_cfg(1))
+    assert sum(p.numel() for p in m1.parameters()) == 256 * 64 * 11 + 256 + 512 + 29 * 256 + 29
+
+
+def test_weight_layout_and_checkpoint_roundtrip(tmp_path):
+    from wav2letter_pytorch_amd import Wav2Letter
+    z = np.load(os.path.join(GOLD, 'w2l_ml3.npz'), allow_pickle=True)
+    meta = ast.literal_eval(str(z['meta']))
+    m = Wav2Letter(_cfg(3, layers=meta['layers']))
+    w = m.conv1ds.conv1d_1.conv1.weight
+    assert w.shape == (96, 96, 11) and w.stride() == (96, 1, 96 * 96)      # logical [out,in,k], stored tap-major
+    sd = {k[3:]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith('p0/')}
+    m.load_state_dict(sd)                                                  # a reference state dict loads as is
+    for k, v in m.state_dict().items():
+        assert torch.equal(v.contiguous(), sd[k]), k
+    torch.save(m.state_dict(), tmp_path / 'ck.pt')
+    m2 = Wav2Letter(_cfg(3, layers=meta['layers']))
+    m2.load_state_dict(torch.load(tmp_path / 'ck.pt'))
+    assert torch.equal(m2.conv1ds.conv1d_1.conv1.weight, w)
+    # same seed -> same initial values as nn.Conv1d would draw into a contiguous tensor
+    torch.manual_seed(3)
+    a = Wav2Letter(_cfg(1))
+    torch.manual_seed(3)
+    ref = torch.nn.Conv1d(64, 256, 11, stride=2)
+    # (the model draws the decoder/example input first, so only distribution bounds are compared)
+    bound = 1 / (64 * 11) ** 0.5
+    assert float(a.conv1ds.conv1d_0.conv1.weight.abs().max()) <= bound + 1e-6
+    assert float(ref.weight.abs().max()) <= bound + 1e-6
+
+
+def test_cpu_tensors_fail_loudly():
+    from wav2letter_pytorch_amd import Wav2Letter, CTCLoss
+    from wav2letter_pytorch_amd._lib import W2LError
+    m = Wav2Letter(_cfg(1))
+    with pytest.raises(W2LError):
+        m(torch.randn(2, 64, 50), torch.tensor([50, 50]))
+    with pytest.raises(W2LError):
+        CTCLoss(0, 'mean', True)(torch.randn(10, 2, 29).log_softmax(-1), torch.ones(2, 3, dtype=torch.int32),
+                                 torch.tensor([10, 10]), torch.tensor([3, 3]))
+    with pytest.raises(RuntimeError):
+        m.conv1ds.conv1d_0(torch.randn(1, 64, 20))
+    with pytest.raises(NotImplementedError):
+        CTCLoss(reduction='sum')
+
+
+def test_decoder_host_logic_and_levenshtein():
+    from wav2letter_pytorch_amd.decoder import GreedyDecoder
+    z = np.load(os.path.join(GOLD, 'greedy_cases.npz'), allow_pickle=True)
+    dec = GreedyDecoder(list(z['labels']), blank_index=0)
+    strings, offsets = dec.convert_to_strings(torch.from_numpy(z['argmax']), z['sizes'], remove_repetitions=True,
+                                              return_offsets=True)
+    assert [s[0] for s in strings] == list(z['strings'])
+    for o, ref in zip(offsets, z['offsets']):
+        assert o[0].tolist() == list(ref)
+    for (a, b), c, w in zip(z['pairs'], z['cer'], z['wer']):
+        assert dec.cer_ratio(str(a), str(b)) == tuple(c)
+        assert dec.wer_ratio(str(a), str(b)) == tuple(w)
+    assert GreedyDecoder('english_lowercase').space_index == 28
+    assert dec.cer('', 'abc') == 3 and dec.wer('a b', '') == 2
+
+
+def test_config_loader_hydra_tree(tmp_path):
+    """defaults list, `# @package model` groups, ${a.b} interpolation, key=value and group overrides
+    (the structure of configuration/config.yaml:1-28, rebuilt here from Python dicts)"""
+    import yaml
+    from wav2letter_pytorch_amd.config import instantiate, load_config
+    (tmp_path / 'model').mkdir()
+    (tmp_path / 'audio').mkdir()
+    (tmp_path / 'optimizer').mkdir()
+    (tmp_path / 'config.yaml').write_text(yaml.safe_dump({
+        'defaults': [{'audio': 'standard_16k'}, {'optimizer': 'exp_lr_optimizer'}, {'model': 'wav2letter'}],
+        'data': {'train_manifest': '???', 'batch_size': 4, 'mel_spec': '${model.input_size}', 'audio_conf': '${model.audio_conf}'},
+        'model': {'input_size': 64, 'labels': 'english_lowercase',
+                  'decoder': {'_target_': 'decoder.GreedyDecoder', 'labels': '${model.labels}'}},
+        'trainer': {'default_root_dir': '.', 'max_epochs': 5, 'gpus': 0},
+        'hydra': {'run': {'dir': '${trainer.default_root_dir}'}}}))
+    (tmp_path / 'audio' / 'standard_16k.yaml').write_text('# @package model\naudio_conf:\n  window: hamming\n  sample_rate: 16000\n  window_size: 0.02\n')
+    (tmp_path / 'optimizer' / 'exp_lr_optimizer.yaml').write_text(
+        '# @package model\noptimizer:\n  _target_: torch.optim.SGD\n  lr: 1e-5\n  momentum: 0.9\n  nesterov: True\n'
+        'scheduler:\n  _target_: torch.optim.lr_scheduler.ExponentialLR\n  gamma: 0.999\n')
+    (tmp_path / 'model' / 'wav2letter.yaml').write_text(
+        '# @package model\nname: wav2letter\nmid_layers: 1\nlayers:\n - output_size: 256\n   kernel_size: 11\n   stride: 2\n   dilation: 1\n   dropout: 0.2\n')
+    (tmp_path / 'model' / 'jasper.yaml').write_text('# @package model\nname: jasper\nmid_layers: 1\njasper_blocks: []\n')
+    cfg = load_config(str(tmp_path), ['model.mid_layers=3', 'trainer.gpus=1'])
+    assert cfg.model.name == 'wav2letter' and cfg.model.mid_layers == 3 and cfg.trainer.gpus == 1
+    assert cfg.data.mel_spec == 64 and cfg.data.audio_conf.sample_rate == 16000
+    assert cfg.model.decoder.labels == 'english_lowercase' and cfg.model.layers[:1][0].kernel_size == 11
+    assert cfg.model.get('print_decoded_prob', 0) == 0
+    assert load_config(str(tmp_path), ['model=jasper']).model.name == 'jasper'
+    dec = instantiate(cfg.model.decoder)
+    assert type(dec).__name__ == 'GreedyDecoder' and len(dec.labels) == 29
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = instantiate(cfg.model.optimizer, params=[p])
+    assert isinstance(opt, torch.optim.SGD)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from wav2letter_pytorch_amd.distributed import GradReducer, broadcast_parameters, init_process_group_from_env
+    r, w = init_process_group_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)
+    lin = torch.nn.Linear(5, 3)
+    conv_w = torch.nn.Parameter(torch.randn(4, 6, 8).permute(1, 2, 0))       # tap-major strided parameter
+    mod = torch.nn.Module()
+    mod.lin, mod.w = lin, conv_w
+    broadcast_parameters(mod)
+    red = GradReducer(small_bytes=64)
+    g = torch.Generator().manual_seed(7 + rank)
+    big = torch.randn(4, 6, 8, generator=g)                                   # dense storage of a conv gradient
+    view = big.permute(1, 2, 0)
+    smalls = [torch.randn(3, generator=g), torch.randn(5, generator=g)]
+    red.on_grad(conv_w, view, big)
+    for t in smalls:
+        red.on_grad(None, t)
+    red.finish()
+    q.put((rank, mod.lin.weight.detach().clone(), conv_w.detach().clone(), big.clone(), [t.clone() for t in smalls]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_gloo_world2():
+    """N>1 path on CPU: identical replicas after broadcast, gradients averaged (large tensor on its own,
+    small ones through the flattened bucket), strided gradient views reduced through their dense storage"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0, c0, big0, s0), (_, w1, c1, big1, s1) = res
+    assert torch.equal(w0, w1) and torch.equal(c0, c1)                        # broadcast made the replicas identical
+    assert torch.equal(big0, big1)
+    exp = [torch.randn(4, 6, 8, generator=torch.Generator().manual_seed(7 + r)) for r in range(2)]
+    assert torch.allclose(big0, (exp[0] + exp[1]) / 2, atol=1e-6)
+    for a, b in zip(s0, s1):
+        assert torch.equal(a, b)

@@ -80,13 +80,32 @@ def _interpolate(node, root):
     return node
 
 
+_FLOAT_RE = re.compile(r'^[-+]?(\d+\.?\d*|\.\d+)([eE][-+]?\d+)?$')
+
+
+def _yaml_load(text):
+    """yaml.safe_load plus OmegaConf's number rule: `1e-5` (no dot) is a float, not a string
+    (optimizer/exp_lr_optimizer.yaml:4 relies on it)."""
+    import yaml
+
+    def fix(node):
+        if isinstance(node, dict):
+            return {k: fix(v) for k, v in node.items()}
+        if isinstance(node, list):
+            return [fix(v) for v in node]
+        if isinstance(node, str) and _FLOAT_RE.match(node) and not node.isdigit():
+            return float(node)
+        return node
+
+    return fix(yaml.safe_load(text))
+
+
 def load_config(config_dir: str, overrides=()):
     """Hydra-less loader for the reference's config tree (configuration/config.yaml:1-28):
     defaults list, ``# @package model`` groups, ``${a.b}`` interpolation, ``a.b=c`` overrides
     (``model=jasper`` style group overrides select the group file)."""
-    import yaml
     with open(os.path.join(config_dir, 'config.yaml')) as f:
-        root = yaml.safe_load(f)
+        root = _yaml_load(f.read())
     defaults = root.pop('defaults', [])
     groups = {}
     for d in defaults:
@@ -104,7 +123,7 @@ def load_config(config_dir: str, overrides=()):
         path = os.path.join(config_dir, g, name + '.yaml')
         with open(path) as f:
             text = f.read()
-        node = yaml.safe_load(text) or {}
+        node = _yaml_load(text) or {}
         m = re.search(r'#\s*@package\s+(\S+)', text)
         pkg = m.group(1) if m else g
         dst = merged.setdefault(pkg, {})
@@ -115,7 +134,7 @@ def load_config(config_dir: str, overrides=()):
         parts = k.split('.')
         for p in parts[:-1]:
             cur = cur.setdefault(p, {})
-        cur[parts[-1]] = yaml.safe_load(v)
+        cur[parts[-1]] = _yaml_load(v)
     merged.pop('hydra', None)
     _interpolate(merged, merged)
     return to_cfg(merged)
