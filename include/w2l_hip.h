@@ -130,12 +130,13 @@ typedef struct {
 } w2l_gradsrc_t;
 
 /* sums over (n,t) of g and g*xhat per channel for each branch:
- * partial [nblocks][4][C] = {sum g, sum g*xhat1, sum g (branch2), sum g*xhat2}; nblocks = w2l_bn_bwd_blocks(). */
+ * partial [nblocks][ncomp][C] = {sum g, sum g*xhat1 [, sum g (branch2), sum g*xhat2]}; ncomp = 4 with a residual
+ * branch (d->y2 != NULL), else 2; nblocks = w2l_bn_bwd_blocks(). */
 int w2l_bn_bwd_blocks(int N, int T, int C);
 int w2l_bn_act_bwd_reduce(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2, float* partial,
                           void* stream);
-/* partial -> sums [4][C] (sum_g = d beta, sum_gx = d gamma) */
-int w2l_bn_bwd_finalize(const float* partial, int nblocks, int C, float* sums, void* stream);
+/* partial -> sums [ncomp][C] (sum_g = d beta, sum_gx = d gamma), written at the front of a [4][C] buffer */
+int w2l_bn_bwd_finalize(const float* partial, int nblocks, int C, int ncomp, float* sums, void* stream);
 /* dy = scale*(g - sum_g/M - xhat*sum_gx/M) into shared-halo buffers [halo + N*(T+halo)][C] (hi[,lo]);
  * dy2 likewise for the residual branch (NULL if none).  The conv bias gradient under BatchNorm is
  * sum(dy) == 0 identically (the reference's value is fp32 rounding noise); it is not computed. */

@@ -359,10 +359,10 @@ def test_bn_act_fwd_bwd(L, N, T, C, pl, pr, mode, act, f32):
     gs = L.GradSrc()
     gs.dxp, gs.f32, gs.pad_l, gs.pad_r, gs.pad_mode, gs.rows = gd.data_ptr(), 1, pl, pr, mode, pl + T + pr
     nb = L.lib.w2l_bn_bwd_blocks(N, T, C)
-    partial = torch.empty(nb, 4, C, device='cuda')
+    partial = torch.empty(nb, 2, C, device='cuda')
     L.check(L.lib.w2l_bn_act_bwd_reduce(C_.byref(d), C_.byref(gs), None, L.ptr(partial), st))
     sums = torch.empty(4, C, device='cuda')
-    L.check(L.lib.w2l_bn_bwd_finalize(L.ptr(partial), nb, C, L.ptr(sums), st))
+    L.check(L.lib.w2l_bn_bwd_finalize(L.ptr(partial), nb, C, 2, L.ptr(sums), st))
     h = 13                                            # shared-halo layout: h + N*(T+h) rows
     dy_hi = torch.full((h + N * (T + h), C), float('nan'), dtype=torch.bfloat16, device='cuda')
     dy_lo = torch.full_like(dy_hi, float('nan'))

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Times the BatchNorm/activation kernels alone (no overlap) on W2L layer shapes."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wav2letter_pytorch_amd import _lib as L  # noqa: E402
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e3
+
+
+def main():
+    N, T = 32, 500
+    st = L.stream_ptr()
+    for Cn, pl, p in [(256, 5, 0.2), (512, 8, 0.2), (896, 28, 0.4), (1024, 0, 0.4)]:
+        y = torch.randn(N, T, Cn, device='cuda').to(torch.bfloat16)
+        scale, shift, mean, invstd = (torch.rand(Cn, device='cuda') + 0.5 for _ in range(4))
+        mask = torch.empty(N * T * Cn // 8, dtype=torch.uint8, device='cuda')
+        d = L.BnActDesc()
+        d.N, d.T, d.C = N, T, Cn
+        d.y, d.y_f32 = y.data_ptr(), 0
+        d.scale, d.shift, d.mean, d.invstd = (t.data_ptr() for t in (scale, shift, mean, invstd))
+        d.act, d.drop_p, d.seed, d.offset, d.mask = 1, p, 1, 1, mask.data_ptr()
+        R = T + 2 * pl
+        out = torch.empty(N, R, Cn, dtype=torch.bfloat16, device='cuda')
+        g = torch.randn(N, R, Cn, device='cuda').to(torch.bfloat16)
+        gs = L.GradSrc()
+        gs.dxp, gs.f32, gs.pad_l, gs.pad_r, gs.pad_mode, gs.rows = g.data_ptr(), 0, pl, pl, 1, R
+        nb = L.lib.w2l_bn_bwd_blocks(N, T, Cn)
+        partial = torch.empty(nb, 2, Cn, device='cuda')
+        sums = torch.empty(4, Cn, device='cuda')
+        h = 28
+        dy = torch.empty(h + N * (T + h), Cn, dtype=torch.bfloat16, device='cuda')
+        t_f = timeit(lambda: L.check(L.lib.w2l_bn_act_fwd(C.byref(d), L.ptr(out), None, R, pl, pl, 1, st)))
+        t_r = timeit(lambda: L.check(L.lib.w2l_bn_act_bwd_reduce(C.byref(d), C.byref(gs), None, L.ptr(partial), st)))
+        t_z = timeit(lambda: L.check(L.lib.w2l_bn_bwd_finalize(L.ptr(partial), nb, Cn, 2, L.ptr(sums), st)))
+        t_a = timeit(lambda: L.check(L.lib.w2l_bn_act_bwd_apply(C.byref(d), C.byref(gs), None, L.ptr(sums), L.ptr(dy), None, h,
+                                                                None, None, 0, st)))
+        el = N * T * Cn
+        print(f'C={Cn:5d}: fwd {t_f:7.1f} us ({el * 4 / t_f / 1e6:5.2f} TB/s)  reduce {t_r:7.1f} us ({el * 4 / t_r / 1e6:5.2f} TB/s)  '
+              f'finalize {t_z:6.1f} us  apply {t_a:7.1f} us ({el * 6 / t_a / 1e6:5.2f} TB/s)')
+
+
+if __name__ == '__main__':
+    main()

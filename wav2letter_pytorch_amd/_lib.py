@@ -54,7 +54,7 @@ _SIGNATURES = {
     'w2l_bn_act_fwd': (c_i, [C.POINTER(BnActDesc), c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'w2l_bn_bwd_blocks': (c_i, [c_i, c_i, c_i]),
     'w2l_bn_act_bwd_reduce': (c_i, [C.POINTER(BnActDesc), C.POINTER(GradSrc), C.POINTER(GradSrc), c_p, c_p]),
-    'w2l_bn_bwd_finalize': (c_i, [c_p, c_i, c_i, c_p, c_p]),
+    'w2l_bn_bwd_finalize': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     'w2l_bn_act_bwd_apply': (c_i, [C.POINTER(BnActDesc), C.POINTER(GradSrc), C.POINTER(GradSrc), c_p, c_p, c_p, c_i,
                                    c_p, c_p, c_i, c_p]),
     'w2l_log_softmax_fwd': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),

@@ -80,36 +80,31 @@ __device__ __forceinline__ int pad_src_row(int r, int T, int pad_l, int pad_r, i
     return (t >= 0 && t < T) ? t : -1;
 }
 
-// pre-activation value z = dropout(bn(y) [+ bn2(y2)]) for 8 channels, and which of them pass
-// the activation's gradient.  Returns keep bits (after dropout).
-template <bool F32>
-__device__ __forceinline__ uint32_t preact8(const w2l_bnact_t& d, int64_t row /* n*T+t */, int cg, int G, float z[8],
-                                            float y1[8], float y2v[8], uint32_t thresh, float inv_keep,
-                                            bool gen_mask, bool write_mask) {
-    const int c = cg * 8;
-    const int64_t off = row * d.C + c;
+// per-channel constants of one BatchNorm branch for the 8 channels of a group
+struct Chan {
+    float sc[8], sh[8], m[8], is[8];
+};
+__device__ __forceinline__ void load_chan(Chan& ch, const float* scale, const float* shift, const float* mean,
+                                          const float* invstd, int c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ch.sc[j] = 1.f; ch.sh[j] = 0.f; ch.m[j] = 0.f; ch.is[j] = 0.f; }
+    if (scale) { loadp8(scale, c, ch.sc); loadp8(shift, c, ch.sh); }
+    if (mean) { loadp8(mean, c, ch.m); loadp8(invstd, c, ch.is); }
+}
+
+// pre-activation value z = dropout(bn(y) [+ bn2(y2)]) for 8 channels; returns the keep bits
+template <bool F32, bool HAS2>
+__device__ __forceinline__ uint32_t preact8(const w2l_bnact_t& d, const Chan& c1, const Chan& c2, int64_t row /* n*T+t */,
+                                            int cg, int G, float z[8], float y1[8], float y2v[8], uint32_t thresh,
+                                            float inv_keep, bool gen_mask, bool write_mask) {
+    const int64_t off = row * d.C + cg * 8;
     load8<F32>(d.y, off, y1);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) z[j] = y1[j];
-    if (d.scale) {
-        float sc[8], sh[8];
-        loadp8(d.scale, c, sc);
-        loadp8(d.shift, c, sh);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) z[j] = y1[j] * sc[j] + sh[j];
-    }
-    if (d.y2) {
+    for (int j = 0; j < 8; ++j) z[j] = y1[j] * c1.sc[j] + c1.sh[j];
+    if (HAS2) {
         load8<F32>(d.y2, off, y2v);
-        if (d.scale2) {
-            float sc[8], sh[8];
-            loadp8(d.scale2, c, sc);
-            loadp8(d.shift2, c, sh);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) z[j] += y2v[j] * sc[j] + sh[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) z[j] += y2v[j];
-        }
+        for (int j = 0; j < 8; ++j) z[j] += y2v[j] * c2.sc[j] + c2.sh[j];
     }
     uint32_t bits = 0xFFu;
     if (d.drop_p > 0.f) {
@@ -139,29 +134,32 @@ __device__ __forceinline__ bool act_pass(float z, int act) {
 }
 
 // ---------------------------------------------------------------- forward
-template <bool F32>
+template <bool F32, bool HAS2>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(w2l_bnact_t d, bf16_raw* out_hi, bf16_raw* out_lo, int R,
                                                           int pad_l, int pad_r, int pad_mode, uint32_t thresh,
                                                           float inv_keep) {
     const int G = d.C >> 3;
-    const int64_t total = (int64_t)d.N * R * G;
-    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
-        const int cg = (int)(it % G);
-        const int64_t orow = it / G;
-        const int n = (int)(orow / R);
-        const int r = (int)(orow - (int64_t)n * R);
+    const unsigned total = (unsigned)d.N * R * G;            // < 2^31 (checked by the launcher): 32-bit index math
+    for (unsigned it = blockIdx.x * 256u + threadIdx.x; it < total; it += gridDim.x * 256u) {
+        const unsigned orow = it / (unsigned)G;
+        const int cg = (int)(it - orow * G);
+        const int n = (int)(orow / (unsigned)R);
+        const int r = (int)(orow - (unsigned)n * R);
         const int t = pad_src_row(r, d.T, pad_l, pad_r, pad_mode);
         float a[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = 0.f;
         if (t >= 0 && (!d.lens || t < d.lens[n])) {
             float z[8], y1[8], y2v[8];
-            preact8<F32>(d, (int64_t)n * d.T + t, cg, G, z, y1, y2v, thresh, inv_keep, /*gen_mask=*/true,
+            Chan c1, c2;
+            load_chan(c1, d.scale, d.shift, nullptr, nullptr, cg * 8);
+            if (HAS2) load_chan(c2, d.scale2, d.shift2, nullptr, nullptr, cg * 8);
+            preact8<F32, HAS2>(d, c1, c2, (int64_t)n * d.T + t, cg, G, z, y1, y2v, thresh, inv_keep, /*gen_mask=*/true,
                          /*write_mask=*/r - pad_l == t);
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] = activate(z[j], d.act);
         }
-        store8_split(out_hi, out_lo, orow * d.C + cg * 8, a);
+        store8_split(out_hi, out_lo, (int64_t)orow * d.C + cg * 8, a);
     }
 }
 
@@ -193,45 +191,35 @@ struct BwdRow {
     float xh2[8];
 };
 
-template <bool F32, bool GF32>
-__device__ __forceinline__ void bwd_row(const w2l_bnact_t& d, const w2l_gradsrc_t& g1, const w2l_gradsrc_t* g2, int n,
-                                        int t, int cg, int G, float inv_keep, BwdRow& o) {
+template <bool F32, bool GF32, bool HAS2>
+__device__ __forceinline__ void bwd_row(const w2l_bnact_t& d, const Chan& c1, const Chan& c2, const w2l_gradsrc_t& g1,
+                                        const w2l_gradsrc_t& g2, int has_g2, int n, int t, int cg, int G, float inv_keep,
+                                        BwdRow& o) {
     float z[8], y1[8], y2v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { o.g[j] = 0.f; o.xh1[j] = 0.f; o.xh2[j] = 0.f; y2v[j] = 0.f; }
     if (d.lens && t >= d.lens[n]) return;        // masked_fill: no gradient through zeroed frames
-    const uint32_t bits = preact8<F32>(d, (int64_t)n * d.T + t, cg, G, z, y1, y2v, 0, inv_keep, false, false);
+    const uint32_t bits = preact8<F32, HAS2>(d, c1, c2, (int64_t)n * d.T + t, cg, G, z, y1, y2v, 0, inv_keep, false, false);
     float g[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = 0.f;
     add_grad8<GF32>(g1, n, t, d.T, d.C, cg, g);
-    if (g2) add_grad8<GF32>(*g2, n, t, d.T, d.C, cg, g);
-    const int c = cg * 8;
+    if (has_g2) add_grad8<GF32>(g2, n, t, d.T, d.C, cg, g);
+    const float gk = d.drop_p > 0.f ? inv_keep : 1.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const bool keep = (bits >> j) & 1u;
-        o.g[j] = (keep && act_pass(z[j], d.act)) ? g[j] * (d.drop_p > 0.f ? inv_keep : 1.f) : 0.f;
-    }
-    if (d.mean) {
-        float m[8], is[8];
-        loadp8(d.mean, c, m);
-        loadp8(d.invstd, c, is);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.xh1[j] = (y1[j] - m[j]) * is[j];
-    }
-    if (d.y2 && d.mean2) {
-        float m[8], is[8];
-        loadp8(d.mean2, c, m);
-        loadp8(d.invstd2, c, is);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.xh2[j] = (y2v[j] - m[j]) * is[j];
+        o.g[j] = (keep && act_pass(z[j], d.act)) ? g[j] * gk : 0.f;
+        o.xh1[j] = (y1[j] - c1.m[j]) * c1.is[j];           // is == 0 when the branch has no BatchNorm
+        if (HAS2) o.xh2[j] = (y2v[j] - c2.m[j]) * c2.is[j];
     }
 }
 
-constexpr int BWD_ROWS_PER_BLOCK = 16;   // 1000 blocks at N*T = 16000: enough waves in flight to stream HBM
+constexpr int BWD_ROWS_PER_BLOCK = 32;   // 500 blocks at N*T = 16000
 
-// partial[blk][4][C]: sum g, sum g*xh1, sum g, sum g*xh2
-template <bool F32, bool GF32>
+// partial[blk][ncomp][C]: sum g, sum g*xh1 [, sum g, sum g*xh2 when there is a residual branch].
+// A thread owns one channel group for the whole block: per-channel constants live in registers.
+template <bool F32, bool GF32, bool HAS2>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(w2l_bnact_t d, w2l_gradsrc_t g1, w2l_gradsrc_t g2,
                                                                  int has_g2, float* partial, float inv_keep) {
     extern __shared__ float red[];               // [RPB][3][C]
@@ -239,21 +227,29 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(w2l_bnact_t d, w
     const int RPB = 256 / G;
     const int tid = threadIdx.x;
     const int rr = tid / G, cg = tid - rr * G;
+    constexpr int ncomp = HAS2 ? 4 : 2;
     const int64_t rows = (int64_t)d.N * d.T;
     const int64_t row0 = (int64_t)blockIdx.x * BWD_ROWS_PER_BLOCK;
     float s0[8], s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
     if (rr < RPB) {
-        for (int64_t row = row0 + rr; row < row0 + BWD_ROWS_PER_BLOCK && row < rows; row += RPB) {
-            const int n = (int)(row / d.T), t = (int)(row - (int64_t)n * d.T);
+        Chan c1, c2;
+        load_chan(c1, d.scale, d.shift, d.mean, d.invstd, cg * 8);
+        if (HAS2) load_chan(c2, d.scale2, d.shift2, d.mean2, d.invstd2, cg * 8);
+        int64_t rend = row0 + BWD_ROWS_PER_BLOCK;
+        if (rend > rows) rend = rows;
+        int n = (int)((row0 + rr) / d.T), t = (int)((row0 + rr) - (int64_t)n * d.T);
+#pragma unroll 2
+        for (int64_t row = row0 + rr; row < rend; row += RPB, t += RPB) {
+            while (t >= d.T) { t -= d.T; ++n; }
             BwdRow o;
-            bwd_row<F32, GF32>(d, g1, has_g2 ? &g2 : nullptr, n, t, cg, G, inv_keep, o);
+            bwd_row<F32, GF32, HAS2>(d, c1, c2, g1, g2, has_g2, n, t, cg, G, inv_keep, o);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 s0[j] += o.g[j];
                 s1[j] += o.g[j] * o.xh1[j];
-                s2[j] += o.g[j] * o.xh2[j];
+                if (HAS2) s2[j] += o.g[j] * o.xh2[j];
             }
         }
 #pragma unroll
@@ -271,8 +267,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(w2l_bnact_t d, w
             b += red[(k * 3 + 1) * d.C + c];
             e += red[(k * 3 + 2) * d.C + c];
         }
-        float* dst = partial + (int64_t)blockIdx.x * 4 * d.C;
-        dst[c] = a; dst[d.C + c] = b; dst[2 * d.C + c] = a; dst[3 * d.C + c] = e;
+        float* dst = partial + (int64_t)blockIdx.x * ncomp * d.C;
+        dst[c] = a; dst[d.C + c] = b;
+        if (ncomp == 4) { dst[2 * d.C + c] = a; dst[3 * d.C + c] = e; }
     }
 }
 
@@ -296,7 +293,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
 
 // work items: [0, nvalid): one (n, t, channel-group) each -> compute dy (and dy2) and store into the
 // shared-halo buffers; [nvalid, nvalid + z1): zero rows of dy; then z2 zero rows of dy2.
-template <bool F32, bool GF32>
+template <bool F32, bool GF32, bool HAS2>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(w2l_bnact_t d, w2l_gradsrc_t g1, w2l_gradsrc_t g2,
                                                                 int has_g2, const float* sums, bf16_raw* dy_hi,
                                                                 bf16_raw* dy_lo, int h1, bf16_raw* dy2_hi,
@@ -304,18 +301,18 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(w2l_bnact_t d, w2
     const int G = d.C >> 3;
     const int T = d.T, N = d.N;
     const float invM = 1.f / ((float)N * (float)T);
-    const int64_t nvalid = (int64_t)N * T * G;
-    const int64_t z1 = (int64_t)h1 * (N + 1) * G;
-    const int64_t z2 = dy2_hi ? (int64_t)h2 * (N + 1) * G : 0;
-    const int64_t total = nvalid + z1 + z2;
-    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+    const unsigned nvalid = (unsigned)N * T * G;             // all < 2^31 (checked by the launcher)
+    const unsigned z1 = (unsigned)h1 * (N + 1) * G;
+    const unsigned z2 = dy2_hi ? (unsigned)h2 * (N + 1) * G : 0u;
+    const unsigned total = nvalid + z1 + z2;
+    for (unsigned it = blockIdx.x * 256u + threadIdx.x; it < total; it += gridDim.x * 256u) {
         if (it >= nvalid) {                       // zero-fill a halo row group
-            int64_t k = it - nvalid;
+            unsigned k = it - nvalid;
             bf16_raw* hi = dy_hi; bf16_raw* lo = dy_lo; int h = h1;
             if (k >= z1) { k -= z1; hi = dy2_hi; lo = dy2_lo; h = h2; }
-            const int cg = (int)(k % G);
-            const int64_t hr = k / G;              // index among the (N+1)*h halo rows
-            const int gap = (int)(hr / h), r = (int)(hr - (int64_t)gap * h);
+            const unsigned hr = k / (unsigned)G;   // index among the (N+1)*h halo rows
+            const int cg = (int)(k - hr * G);
+            const int gap = (int)(hr / (unsigned)h), r = (int)(hr - (unsigned)gap * h);
             const int64_t row = (int64_t)gap * (T + h) + r;
             float z[8];
 #pragma unroll
@@ -323,39 +320,40 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(w2l_bnact_t d, w2
             store8_split(hi, lo, row * d.C + cg * 8, z);
             continue;
         }
-        const int cg = (int)(it % G);
-        const int64_t vrow = it / G;
-        const int n = (int)(vrow / T);
-        const int t = (int)(vrow - (int64_t)n * T);
+        const unsigned vrow = it / (unsigned)G;
+        const int cg = (int)(it - vrow * G);
+        const int n = (int)(vrow / (unsigned)T);
+        const int t = (int)(vrow - (unsigned)n * T);
         float o1[8], o2[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { o1[j] = 0.f; o2[j] = 0.f; }
         BwdRow o;
-        bwd_row<F32, GF32>(d, g1, has_g2 ? &g2 : nullptr, n, t, cg, G, inv_keep, o);
         const int c = cg * 8;
+        Chan c1, c2;
+        load_chan(c1, d.scale, d.shift, d.mean, d.invstd, c);
+        if (HAS2) load_chan(c2, d.scale2, d.shift2, d.mean2, d.invstd2, c);
+        bwd_row<F32, GF32, HAS2>(d, c1, c2, g1, g2, has_g2, n, t, cg, G, inv_keep, o);
         if (d.mean) {
-            float sg[8], sgx[8], sc[8];
+            float sg[8], sgx[8];
             loadp8(sums, c, sg);
             loadp8(sums + d.C, c, sgx);
-            loadp8(d.scale, c, sc);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o1[j] = sc[j] * (o.g[j] - sg[j] * invM - o.xh1[j] * sgx[j] * invM);
+            for (int j = 0; j < 8; ++j) o1[j] = c1.sc[j] * (o.g[j] - sg[j] * invM - o.xh1[j] * sgx[j] * invM);
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o1[j] = o.g[j] * (d.scale ? d.scale[c + j] : 1.f);
+            for (int j = 0; j < 8; ++j) o1[j] = o.g[j] * c1.sc[j];
         }
         store8_split(dy_hi, dy_lo, ((int64_t)h1 + (int64_t)n * (T + h1) + t) * d.C + c, o1);
-        if (dy2_hi) {
+        if (HAS2 && dy2_hi) {
             if (d.mean2) {
-                float sg[8], sgx[8], sc[8];
+                float sg[8], sgx[8];
                 loadp8(sums + 2 * d.C, c, sg);
                 loadp8(sums + 3 * d.C, c, sgx);
-                loadp8(d.scale2, c, sc);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o2[j] = sc[j] * (o.g[j] - sg[j] * invM - o.xh2[j] * sgx[j] * invM);
+                for (int j = 0; j < 8; ++j) o2[j] = c2.sc[j] * (o.g[j] - sg[j] * invM - o.xh2[j] * sgx[j] * invM);
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o2[j] = o.g[j] * (d.scale2 ? d.scale2[c + j] : 1.f);
+                for (int j = 0; j < 8; ++j) o2[j] = o.g[j] * c2.sc[j];
             }
             store8_split(dy2_hi, dy2_lo, ((int64_t)h2 + (int64_t)n * (T + h2) + t) * d.C + c, o2);
         }
@@ -444,13 +442,14 @@ extern "C" int w2l_bn_act_fwd(const w2l_bnact_t* d, void* out_hi, void* out_lo, 
                   pad_l, pad_r, d->T);
     const uint32_t thresh = (uint32_t)(d->drop_p * 65536.f);
     const float inv_keep = 1.f / (1.f - d->drop_p);
+    W2L_CHECK_ARG((int64_t)d->N * out_rows * (d->C / 8) < (1LL << 31), "bn_act_fwd: tensor too large for 32-bit indexing");
     const int blocks = elementwise_blocks((int64_t)d->N * out_rows * (d->C / 8));
-    if (d->y_f32)
-        hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d,
-                           (bf16_raw*)out_hi, (bf16_raw*)out_lo, out_rows, pad_l, pad_r, pad_mode, thresh, inv_keep);
-    else
-        hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d,
-                           (bf16_raw*)out_hi, (bf16_raw*)out_lo, out_rows, pad_l, pad_r, pad_mode, thresh, inv_keep);
+#define W2L_FWD(F, H)                                                                                        \
+    hipLaunchKernelGGL((bn_act_fwd_kernel<F, H>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d,          \
+                       (bf16_raw*)out_hi, (bf16_raw*)out_lo, out_rows, pad_l, pad_r, pad_mode, thresh, inv_keep)
+    if (d->y_f32) { if (d->y2) W2L_FWD(true, true); else W2L_FWD(true, false); }
+    else { if (d->y2) W2L_FWD(false, true); else W2L_FWD(false, false); }
+#undef W2L_FWD
     W2L_CHECK_LAUNCH();
     return 0;
 }
@@ -460,12 +459,17 @@ extern "C" int w2l_bn_bwd_blocks(int N, int T, int C) {
     return (int)(((int64_t)N * T + BWD_ROWS_PER_BLOCK - 1) / BWD_ROWS_PER_BLOCK);
 }
 
+#define W2L_DISPATCH_BWD2(KERNEL, H2, ...)                                                                 \
+    do {                                                                                                   \
+        if (d->y_f32 && g1->f32) hipLaunchKernelGGL((KERNEL<true, true, H2>), __VA_ARGS__);                \
+        else if (d->y_f32) hipLaunchKernelGGL((KERNEL<true, false, H2>), __VA_ARGS__);                     \
+        else if (g1->f32) hipLaunchKernelGGL((KERNEL<false, true, H2>), __VA_ARGS__);                      \
+        else hipLaunchKernelGGL((KERNEL<false, false, H2>), __VA_ARGS__);                                  \
+    } while (0)
 #define W2L_DISPATCH_BWD(KERNEL, ...)                                                                      \
     do {                                                                                                   \
-        if (d->y_f32 && g1->f32) hipLaunchKernelGGL((KERNEL<true, true>), __VA_ARGS__);                    \
-        else if (d->y_f32) hipLaunchKernelGGL((KERNEL<true, false>), __VA_ARGS__);                         \
-        else if (g1->f32) hipLaunchKernelGGL((KERNEL<false, true>), __VA_ARGS__);                          \
-        else hipLaunchKernelGGL((KERNEL<false, false>), __VA_ARGS__);                                      \
+        if (d->y2) W2L_DISPATCH_BWD2(KERNEL, true, __VA_ARGS__);                                           \
+        else W2L_DISPATCH_BWD2(KERNEL, false, __VA_ARGS__);                                                \
     } while (0)
 
 extern "C" int w2l_bn_act_bwd_reduce(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2,
@@ -488,10 +492,10 @@ extern "C" int w2l_bn_act_bwd_reduce(const w2l_bnact_t* d, const w2l_gradsrc_t* 
     return 0;
 }
 
-extern "C" int w2l_bn_bwd_finalize(const float* partial, int nblocks, int C, float* sums, void* stream) {
-    W2L_CHECK_ARG(partial && sums && nblocks > 0 && C > 0, "bn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((4 * C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial,
-                       nblocks, 4 * C, sums);
+extern "C" int w2l_bn_bwd_finalize(const float* partial, int nblocks, int C, int ncomp, float* sums, void* stream) {
+    W2L_CHECK_ARG(partial && sums && nblocks > 0 && C > 0 && (ncomp == 2 || ncomp == 4), "bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((ncomp * C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial,
+                       nblocks, ncomp * C, sums);
     W2L_CHECK_LAUNCH();
     return 0;
 }
@@ -509,6 +513,7 @@ extern "C" int w2l_bn_act_bwd_apply(const w2l_bnact_t* d, const w2l_gradsrc_t* g
     const int G = d->C / 8;
     const int64_t items = (int64_t)d->N * d->T * G + (int64_t)halo * (d->N + 1) * G +
                           (dy2_hi ? (int64_t)halo2 * (d->N + 1) * G : 0);
+    W2L_CHECK_ARG(items < (1LL << 31), "bn_act_bwd_apply: tensor too large for 32-bit indexing");
     const int blocks = elementwise_blocks(items);
     const float inv_keep = 1.f / (1.f - d->drop_p);
     w2l_gradsrc_t g2v = g2 ? *g2 : *g1;

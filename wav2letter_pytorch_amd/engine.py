@@ -477,11 +477,12 @@ class StackEngine:
             sums = None
             if u.main.has_bn or (u.res is not None and u.res.has_bn):
                 nb = lib.w2l_bn_bwd_blocks(N, Tout, coutp)
-                partial = torch.empty(nb, 4, coutp, dtype=torch.float32, device=dev)
+                ncomp = 4 if u.res is not None else 2
+                partial = torch.empty(nb, ncomp, coutp, dtype=torch.float32, device=dev)
                 check(lib.w2l_bn_act_bwd_reduce(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(partial),
                                                 st()), 'w2l_bn_act_bwd_reduce')
                 sums = torch.empty(4, coutp, dtype=torch.float32, device=dev)
-                check(lib.w2l_bn_bwd_finalize(ptr(partial), nb, coutp, ptr(sums), st()), 'w2l_bn_bwd_finalize')
+                check(lib.w2l_bn_bwd_finalize(ptr(partial), nb, coutp, ncomp, ptr(sums), st()), 'w2l_bn_bwd_finalize')
                 uc.keep.append((partial, sums))
             main, res = u.main, u.res
             need_dx_main = self._needs_grad(u.src)
