@@ -1,0 +1,23 @@
+#!/bin/bash
+# PMC counters for the conv kernels on one layer shape (separate passes; no tracing domains besides kernel-trace)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+L=${1:-11}
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_WAVES" \
+           "GRBM_GUI_ACTIVE GRBM_COUNT" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+  tag=$(echo $set | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_$L/$tag -- python3 tools/bench_conv.py --layers $L --reps 3 > /dev/null 2>&1
+done
+python3 - <<PY
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob('gpurun_out/pmc_$L/*/*/*counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name'][:48]
+        agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
+for k, d in agg.items():
+    if 'conv' not in k: continue
+    print(k)
+    for c, v in sorted(d.items()):
+        print('   %-28s mean %.4g  (n=%d)' % (c, sum(v)/len(v), len(v)))
+PY

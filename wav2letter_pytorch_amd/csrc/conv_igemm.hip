@@ -41,8 +41,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base
 }
 
 // MW x NW waves, each owning MS x NS MFMA tiles of 16x16: block tile BM = 16*MW*MS (co) x BN = 16*NW*NS (t)
-template <int MW, int NW, int MS, int NS>
-__global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8 ? 2 : 2)) void conv_igemm_kernel(IgemmParams p) {
+// S = conv stride (compile time: the fragment reads then use immediate LDS offsets)
+template <int MW, int NW, int MS, int NS, int S>
+__global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams p) {
     constexpr int BM = 16 * MW * MS, BN = 16 * NW * NS, NWAVES = MW * NW, NT = 64 * NWAVES;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8 ? 2 : 2)) void conv_ige
     const int m0 = tm * BM;
     const int t0 = tt * BN;
 
-    const int s = p.stride, d = p.dil, Kw = p.Kw, Cin = p.Cin;
+    constexpr int s = S;
+    const int d = p.dil, Kw = p.Kw, Cin = p.Cin;
     const int xrows = p.xrows_lds;                 // multiple of 8
     char* wbuf0 = smem;
     char* wbuf1 = smem + BM * ROWB;
@@ -67,16 +69,29 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8 ? 2 : 2)) void conv_ige
 
     const int64_t xrow0 = (int64_t)n * p.x_rows_per_utt + (int64_t)t0 * s;
 
-    // ---- staging helpers (each wave-instruction writes 8 LDS rows = 1 KiB) ----
+    // ---- staging (each wave-instruction writes 8 LDS rows = 1 KiB by LDS-DMA) ----
+    // The main loop is issue-bound (VALU + MFMA share a SIMD's issue port), so everything that does not
+    // change from step to step is hoisted: a weight tile's source address is a wave-uniform slab base
+    // (tap, chunk) plus a per-lane 32-bit offset computed once.
     const int srow = lane >> 3;                    // row within the 8-row group
     const int schunk = lane & 7;                   // LDS chunk this lane fills
     const int gchunk = schunk ^ srow;              // source chunk (groups are 8-row aligned: row&7 == srow)
+    constexpr int WGROUPS = BM / 8;
+    constexpr int W_PER_WAVE = (WGROUPS + NWAVES - 1) / NWAVES;
+    unsigned w_voff[W_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < W_PER_WAVE; ++i) {
+        int co = m0 + (wave + i * NWAVES) * 8 + srow;
+        co = co < p.Cout ? co : p.Cout - 1;
+        w_voff[i] = ((unsigned)co * (unsigned)Cin + (unsigned)gchunk * 8u) * 2u;
+    }
+    const int64_t w_tap_bytes = (int64_t)p.Cout * Cin * 2;
     auto stage_w = [&](char* dst, int kw, int c) {
-        for (int grp = wave; grp < BM / 8; grp += NWAVES) {
-            int co = m0 + grp * 8 + srow;
-            co = co < p.Cout ? co : p.Cout - 1;
-            const bf16_raw* src = p.w + ((int64_t)kw * p.Cout + co) * Cin + c * BK + gchunk * 8;
-            glds16(src, dst + grp * 1024);
+        const char* slab = reinterpret_cast<const char*>(p.w) + kw * w_tap_bytes + c * (BK * 2);   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < W_PER_WAVE; ++i) {
+            const int grp = wave + i * NWAVES;
+            if (grp < WGROUPS) glds16(slab + w_voff[i], dst + grp * 1024);
         }
     };
     auto stage_x = [&](char* dst, int c) {
@@ -98,12 +113,11 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8 ? 2 : 2)) void conv_ige
     const int nchunks = Cin / BK;
     const int nsteps = nchunks * Kw;
 
-    // per-lane read offsets
+    // per-lane fragment offsets (constant over the whole K loop)
     const int fr = lane & 15, fq = lane >> 4;
-    const int a_base = (wm * MS * 16 + fr) * ROWB;
-    const int a_sw0 = ((fq) ^ (fr & 7)) << 4;          // k-substep 0: chunk fq
-    const int a_sw1 = ((4 + fq) ^ (fr & 7)) << 4;      // k-substep 1: chunk 4+fq
-    const int b_row0 = (wn * NS * 16 + fr) * s;
+    const int a_lane0 = (wm * MS * 16 + fr) * ROWB + (((fq) ^ (fr & 7)) << 4);        // k-substep 0: chunk fq
+    const int a_lane1 = (wm * MS * 16 + fr) * ROWB + (((4 + fq) ^ (fr & 7)) << 4);    // k-substep 1: chunk 4+fq
+    const int b_row0 = (wn * NS * 16 + fr) * s;      // tile rows ni*16*s further down share (row & 7): NS reads per base
 
     stage_x(xbuf0, 0);
     stage_w(wbuf0, 0, 0);
@@ -121,18 +135,22 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8 ? 2 : 2)) void conv_ige
         }
         const char* wb = (step & 1) ? wbuf1 : wbuf0;
         const char* xb = (c & 1) ? xbuf1 : xbuf0;
-        const int shift = kw * d;
+        const char* A0 = wb + a_lane0;
+        const char* A1 = wb + a_lane1;
+        const int tsh = b_row0 + kw * d;             // LDS row of this lane's first B tile for this tap
+        const int sw0 = ((fq ^ (tsh & 7)) << 4);
+        const char* Bb = xb + (tsh << 7);
+        const char* B0 = Bb + sw0;
+        const char* B1 = Bb + (sw0 ^ 64);            // chunk 4+fq == (chunk fq) ^ 4
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 a[MS], b[NS];
 #pragma unroll
             for (int mi = 0; mi < MS; ++mi)
-                a[mi] = *reinterpret_cast<const bf16x8*>(wb + a_base + mi * 16 * ROWB + (ks ? a_sw1 : a_sw0));
+                a[mi] = *reinterpret_cast<const bf16x8*>((ks ? A1 : A0) + mi * 16 * ROWB);
 #pragma unroll
-            for (int ni = 0; ni < NS; ++ni) {
-                const int j = b_row0 + ni * 16 * s + shift;
-                b[ni] = *reinterpret_cast<const bf16x8*>(xb + j * ROWB + (((ks * 4 + fq) ^ (j & 7)) << 4));
-            }
+            for (int ni = 0; ni < NS; ++ni)
+                b[ni] = *reinterpret_cast<const bf16x8*>((ks ? B1 : B0) + ni * 16 * S * ROWB);
 #pragma unroll
             for (int mi = 0; mi < MS; ++mi)
 #pragma unroll
@@ -222,7 +240,19 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 template <int MW, int NW, int MS, int NS>
 int launch_cfg(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream) {
-    auto kern = conv_igemm_kernel<MW, NW, MS, NS>;
+    if (p.stride == 2) {
+        if constexpr (MW == 2 && NW == 2 && MS == 4 && NS == 4) {
+            auto kern2 = conv_igemm_kernel<2, 2, 4, 4, 2>;
+            W2L_CHECK_HIP(w2l_allow_big_lds((const void*)kern2));
+            hipLaunchKernelGGL(kern2, dim3(tiles_m * p.ncols), dim3(256), lds, stream, p);
+            W2L_CHECK_LAUNCH();
+            return 0;
+        } else {
+            w2l_set_error("conv1d_igemm: stride 2 is only built for the 128x128 block shape");
+            return 1;
+        }
+    }
+    auto kern = conv_igemm_kernel<MW, NW, MS, NS, 1>;
     W2L_CHECK_HIP(w2l_allow_big_lds((const void*)kern));
     hipLaunchKernelGGL(kern, dim3(tiles_m * p.ncols), dim3(64 * MW * NW), lds, stream, p);
     W2L_CHECK_LAUNCH();
@@ -247,6 +277,7 @@ static int choose_cfg(int N, int Cout, int Tout, int Kw, int stride, int dil, bo
         const TileCfg& c = kCfgs[i];
         const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
         if (need_bn128 && bn != 128) continue;
+        if (stride != 1 && i != 2) continue;          // strided convs (first layer only) use the 128x128 shape
         if (g_force_cfg >= 0 && g_force_cfg < kNumCfgs && i != g_force_cfg) continue;
         const size_t lds = 2 * (size_t)bm * ROWB + 2 * (size_t)cfg_xrows(c, stride, Kw, dil) * ROWB;
         if (lds > 160 * 1024) continue;
@@ -273,7 +304,8 @@ extern "C" int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_row
                                 int y_f32, int accumulate, const float* bias, float* stats_partial, int N, int Cin,
                                 int Cout, int Tout, int Kw, int stride, int dil, void* stream) {
     W2L_CHECK_ARG(xp && w && y, "conv1d_igemm: null pointer");
-    W2L_CHECK_ARG(N > 0 && Tout > 0 && Kw > 0 && stride > 0 && dil > 0, "conv1d_igemm: bad sizes");
+    W2L_CHECK_ARG(N > 0 && Tout > 0 && Kw > 0 && (stride == 1 || stride == 2) && dil > 0,
+                  "conv1d_igemm: bad sizes (stride must be 1 or 2)");
     W2L_CHECK_ARG(Cin % 64 == 0 && Cin > 0, "conv1d_igemm: Cin=%d must be a positive multiple of 64", Cin);
     W2L_CHECK_ARG(Cout % 64 == 0 && Cout > 0, "conv1d_igemm: Cout=%d must be a positive multiple of 64", Cout);
     W2L_CHECK_ARG(x_bstride % Cin == 0, "conv1d_igemm: x_bstride must be a multiple of Cin");
