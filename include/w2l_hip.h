@@ -39,6 +39,14 @@ int w2l_pack_weights(const float* w, int64_t s_co, int64_t s_ci, int64_t s_kw, i
                      int CoutP, int CinP, void* w_fwd_hi, void* w_fwd_lo, void* w_dgr_hi, void* w_dgr_lo,
                      void* stream);
 
+/* torch.optim.SGD(momentum, nesterov, weight_decay; dampening 0) -- configuration/optimizer/exp_lr_optimizer.yaml:2-7
+ * -- fused with w2l_pack_weights for a tap-major conv weight: p, g, m are dense fp32 [Kw][Cout][Cin];
+ * first_step != 0 initialises the momentum buffer with the (decayed) gradient as torch does.  The bf16
+ * outputs are the operands of the next step (no channel padding: Cout, Cin multiples of 64). */
+int w2l_sgd_pack(float* p, const float* g, float* m, int first_step, float lr, float momentum, float weight_decay,
+                 int nesterov, int Cout, int Cin, int Kw, void* w_fwd_hi, void* w_fwd_lo, void* w_dgr_hi,
+                 void* w_dgr_lo, void* stream);
+
 /* input spectrogram fp32 [N][C][T] -> padded NTC bf16 [N][pad_l+T+pad_r][CP];
  * pad_mode 1 = reflect (nn.ReflectionPad1d, wav2letter.py:28-34,41), 0 = zeros
  * (Conv1d padding=, jasper.py:96-105).  lens (optional, [N] int32): rows t >= lens[n]

@@ -167,3 +167,33 @@ def test_headline_shapes_properties_bf16():
         assert torch.isfinite(p.grad).all(), k
         if not (k.endswith('conv1.bias') and not k.startswith('conv1ds.conv1d_3.')):
             assert float(p.grad.abs().max()) > 0, k
+
+
+def test_fused_sgd_matches_torch_sgd():
+    """FusedSGD (w2l_sgd_pack for conv weights) == torch.optim.SGD(nesterov, momentum, weight decay) over 3 steps,
+    and the bf16 operands it emits are the ones the next forward uses (pack cache coherent)."""
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd.optim import FusedSGD
+    layers = [(128, 11, 2, 1, 0.0), (128, 13, 1, 2, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=4)
+    ma = build_w2l(layers, sd, 'bf16').train()
+    mb = build_w2l(layers, sd, 'bf16').train()
+    kw = dict(lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-3)
+    oa = FusedSGD.from_sgd(torch.optim.SGD(ma.parameters(), **kw))
+    ob = torch.optim.SGD(mb.parameters(), **kw)
+    x, il, tg, tl = O.synthetic_batch(2, 160, seed=11, s_lo=5, s_hi=15)
+    for it in range(3):
+        for m, o in ((ma, oa), (mb, ob)):
+            o.zero_grad(set_to_none=True)
+            out, ol = m(x.cuda(), il)
+            m.criterion(out.transpose(0, 1), tg, ol, tl).backward()
+            o.step()
+        for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert scale_err(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()) < 2e-5, (it, k)
+    wa = ma.conv1ds.conv1d_1.conv1.weight
+    pk = wa._w2l_pack[False]
+    assert pk.version == wa._version
+    ref = wa.detach().permute(2, 0, 1).to(torch.bfloat16)
+    assert torch.equal(pk.fwd_hi, ref)
+    assert torch.equal(pk.dgr_hi, wa.detach().flip(2).permute(2, 1, 0).to(torch.bfloat16).contiguous())
+    assert isinstance(ma.configure_optimizers()[0][0], FusedSGD)

@@ -79,6 +79,9 @@ class ConvCTCASR(_Base):
     # PyTorch Lightning methods
     def configure_optimizers(self):
         optimizer = instantiate(self._cfg.optimizer, params=self.parameters())
+        if type(optimizer) is torch.optim.SGD and next(self.parameters()).is_cuda:
+            from .optim import FusedSGD            # same update rule and state dict; conv weights update in one fused pass
+            optimizer = FusedSGD.from_sgd(optimizer)
         scheduler = instantiate(self._cfg.scheduler, optimizer=optimizer)
         return [optimizer], [scheduler]
 

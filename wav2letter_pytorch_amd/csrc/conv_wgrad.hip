@@ -77,33 +77,37 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     char* bbuf0 = smem + 2 * BT * ROWB;            // x window [xrows][128 ci]
     char* bbuf1 = bbuf0 + xrows * ROWB;
 
-    // staging: one wave-instruction fills 4 rows of 256 B
+    // ---- staging: one wave-instruction fills 4 rows of 256 B by LDS-DMA.  The K loop is issue-bound, so
+    // per-lane offsets are computed once; a step only adds wave-uniform bases (scalar) to them.
     const int srow = lane >> 4;                    // 0..3
     const int schunk = lane & 15;                  // LDS 16-byte chunk
-    auto stage = [&](char* adst, char* bdst, int step) {
-        const int n = step / p.tsteps;
-        const int t0 = (step - n * p.tsteps) * BT;
-        // dy rows t0..t0+63 (rows >= Tout are zero by contract)
-        const bf16_raw* abase = p.dy + ((int64_t)n * p.dy_rows_per_utt + t0) * p.Cout;
+    unsigned a_voff[BT / 16];                      // byte offset of this lane's 16 B inside the step's dy tile
 #pragma unroll
-        for (int i = 0; i < BT / 16; ++i) {
-            const int grp = wave * (BT / 16) + i;
-            const int r = grp * 4 + srow;
-            const int g = schunk ^ (row_key(r) << 1);
-            int co = m0 + g * 8;
-            co = co < p.Cout ? co : p.Cout - 8;
-            glds16(abase + (int64_t)r * p.Cout + co, adst + grp * 1024);
-        }
-        const int64_t xrow0 = (int64_t)n * p.x_rows_per_utt + (int64_t)t0 * s + shift;
+    for (int i = 0; i < BT / 16; ++i) {
+        const int r = (wave * (BT / 16) + i) * 4 + srow;
+        const int g = schunk ^ (row_key(r) << 1);
+        int co = m0 + g * 8;
+        co = co < p.Cout ? co : p.Cout - 8;
+        a_voff[i] = ((unsigned)r * (unsigned)p.Cout + (unsigned)co) * 2u;
+    }
+    const unsigned x_max_row = (unsigned)p.x_max_row;          // rows * Cin * 2 < 2^32 is checked by the launcher
+    auto stage = [&](char* adst, char* bdst, int n, int ts) {
+        const int t0 = ts * BT;
+        // dy rows t0..t0+63 (rows >= Tout are zero by contract)
+        const char* abase = reinterpret_cast<const char*>(p.dy) + ((int64_t)n * p.dy_rows_per_utt + t0) * p.Cout * 2;
+#pragma unroll
+        for (int i = 0; i < BT / 16; ++i) glds16(abase + a_voff[i], adst + (wave * (BT / 16) + i) * 1024);
+        const unsigned xrow0 = (unsigned)(n * p.x_rows_per_utt) + (unsigned)(t0 * s + shift);
         const int ngrp = xrows >> 2;
         for (int grp = wave; grp < ngrp; grp += 4) {
             const int r = grp * 4 + srow;
             const int g = schunk ^ (row_key(r) << 1);
-            int64_t fr = xrow0 + r;
-            fr = fr < p.x_max_row ? fr : p.x_max_row;
+            unsigned fr = xrow0 + (unsigned)r;
+            fr = fr < x_max_row ? fr : x_max_row;
             int ci = c0 + g * 8;
             ci = ci < p.Cin ? ci : p.Cin - 8;
-            glds16(p.x + fr * p.Cin + ci, bdst + grp * 1024);
+            const unsigned voff = (fr * (unsigned)p.Cin + (unsigned)ci) * 2u;
+            glds16(reinterpret_cast<const char*>(p.x) + voff, bdst + grp * 1024);
         }
     };
 
@@ -119,55 +123,65 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     int step_end = step_begin + p.steps_per_split;
     if (step_end > p.total_steps) step_end = p.total_steps;
 
-    // tr-read lane geometry: within a 16-lane group, lane 4q+pp supplies row q, columns 4pp..4pp+3
+    // ---- tr-read lane geometry: within a 16-lane group, lane 4q+pp supplies row q, columns 4pp..4pp+3.
+    // LDS row of fragment (ks, h) = ks*32 + h*4 + (kgrp*8 + q) [+ tap*d for the x window]; the swizzle key only
+    // depends on the lane part (and, for x, on the carry of h*4 into bit 3), so every address is
+    //   buffer base + per-lane constant + compile-time immediate.
     const int l16 = lane & 15;
     const int q = l16 >> 2, pp = l16 & 3;
     const int kgrp = lane >> 4;                    // k octet of this lane group
-    // column byte offsets (before swizzle) for the A / B sub-tiles of this wave
-    int a_col[4], b_col[4];
+    const int lrow = kgrp * 8 + q;
+    int a_lane[4], b_lane[KWB][2][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        a_col[i] = (wm * 64 + i * 16 + pp * 4) * 2;
-        b_col[i] = (wn * 64 + i * 16 + pp * 4) * 2;
+        const int acol = (wm * 64 + i * 16 + pp * 4) * 2;
+        a_lane[i] = lrow * ROWB + (acol ^ (row_key(lrow) << 5));
+#pragma unroll
+        for (int tp = 0; tp < KWB; ++tp)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rb = (lrow + h * 4) * s + tp * d;                   // row at ks = 0
+                const int bcol = (wn * 64 + i * 16 + pp * 4) * 2;
+                b_lane[tp][h][i] = rb * ROWB + (bcol ^ (row_key(rb) << 5));   // ks*32*s rows further: same key (multiple of 16)
+            }
     }
 
-    if (step_begin < step_end) stage(abuf0, bbuf0, step_begin);
+    int n_cur = step_begin / p.tsteps;
+    int ts_cur = step_begin - n_cur * p.tsteps;
+    if (step_begin < step_end) stage(abuf0, bbuf0, n_cur, ts_cur);
     for (int step = step_begin; step < step_end; ++step) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int par = (step - step_begin) & 1;
-        if (step + 1 < step_end) stage(par ? abuf0 : abuf1, par ? bbuf0 : bbuf1, step + 1);
+        int ts_n = ts_cur + 1, n_n = n_cur;
+        if (ts_n == p.tsteps) { ts_n = 0; ++n_n; }
+        if (step + 1 < step_end) stage(par ? abuf0 : abuf1, par ? bbuf0 : bbuf1, n_n, ts_n);
+        n_cur = n_n; ts_cur = ts_n;
         const char* ab = par ? abuf1 : abuf0;
         const char* bb = par ? bbuf1 : bbuf0;
 #pragma unroll
         for (int ks = 0; ks < BT / 32; ++ks) {
             bf16x8 a[4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int ra = ks * 32 + kgrp * 8 + h * 4 + q;     // t row this lane addresses
-                const int ka = row_key(ra) << 5;
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const bf16x4 va = tr_read(ab + ra * ROWB + (a_col[i] ^ ka));
+                    const bf16x4 va = tr_read(ab + a_lane[i] + (ks * 32 + h * 4) * ROWB);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) a[i][h * 4 + e] = va[e];
                 }
-            }
 #pragma unroll
             for (int tp = 0; tp < KWB; ++tp) {
                 if (tp < ntaps) {                                   // wave-uniform
                     bf16x8 b[4];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int rb = (ks * 32 + kgrp * 8 + h * 4 + q) * s + tp * d;
-                        const int kb = row_key(rb) << 5;
+                    for (int h = 0; h < 2; ++h)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const bf16x4 vb = tr_read(bb + rb * ROWB + (b_col[i] ^ kb));
+                            const bf16x4 vb = tr_read(bb + b_lane[tp][h][i] + ks * 32 * s * ROWB);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) b[i][h * 4 + e] = vb[e];
                         }
-                    }
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -241,6 +255,7 @@ extern "C" int w2l_conv1d_wgrad(const void* dy, int64_t dy_bstride, const void* 
     W2L_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && Cin > 0 && Cout > 0,
                   "conv1d_wgrad: channels (%d,%d) must be positive multiples of 64", Cin, Cout);
     W2L_CHECK_ARG(dy_bstride % Cout == 0 && x_bstride % Cin == 0, "conv1d_wgrad: batch strides must be whole rows");
+    W2L_CHECK_ARG(x_rows_total * (int64_t)Cin * 2 < (1LL << 32), "conv1d_wgrad: activation buffer exceeds 32-bit byte offsets");
     WgradParams p;
     p.dy = (const bf16_raw*)dy;
     p.x = (const bf16_raw*)xp;

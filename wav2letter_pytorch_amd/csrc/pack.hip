@@ -45,6 +45,45 @@ __global__ void pack_weights_kernel(const float* w, int64_t s_co, int64_t s_ci, 
     }
 }
 
+// Fused SGD(momentum, nesterov, weight decay) update of a tap-major conv weight [Kw][Cout][Cin] (fp32 master,
+// gradient and momentum buffer in the same dense layout) that also emits the bf16 GEMM operands of the NEXT
+// step: w_fwd (same layout) and w_dgr [Kw][Cin][Cout] with taps flipped (transposed through LDS).  One pass:
+// read p, g, m; write p, m, 2 x bf16 -- instead of torch's multi-pass foreach update plus a separate pack.
+// Update rule = torch.optim.SGD (dampening 0): g += wd*p; m = first ? g : mu*m + g; g = nesterov ? g + mu*m : m;
+// p -= lr*g.
+__global__ void sgd_pack_kernel(float* p, const float* g, float* m, int first, float lr, float mu, float wd,
+                                int nesterov, int Cout, int Cin, int Kw, bf16_raw* fwd_hi, bf16_raw* fwd_lo,
+                                bf16_raw* dgr_hi, bf16_raw* dgr_lo) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, kw = blockIdx.z;
+    for (int j = ty; j < 32; j += 8) {
+        const int co = co0 + j, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) {
+            const int64_t off = ((int64_t)kw * Cout + co) * Cin + ci;
+            float pv = p[off];
+            float gv = g[off] + wd * pv;
+            float mv = first ? gv : mu * m[off] + gv;
+            m[off] = mv;
+            gv = nesterov ? gv + mu * mv : mv;
+            pv -= lr * gv;
+            p[off] = pv;
+            v = pv;
+            if (fwd_hi) put_split(fwd_hi, fwd_lo, off, pv);
+        }
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    if (dgr_hi) {
+        for (int j = ty; j < 32; j += 8) {
+            const int ci = ci0 + j, co = co0 + tx;
+            if (co < Cout && ci < Cin)
+                put_split(dgr_hi, dgr_lo, ((int64_t)(Kw - 1 - kw) * Cin + ci) * Cout + co, tile[tx][j]);
+        }
+    }
+}
+
 // padded row r of an utterance -> source frame t, or -1 for a zero row
 __device__ __forceinline__ int pad_src_row(int r, int T, int pad_l, int pad_r, int pad_mode) {
     int t = r - pad_l;
@@ -118,6 +157,20 @@ extern "C" int w2l_pack_weights(const float* w, int64_t s_co, int64_t s_ci, int6
     dim3 grid((CinP + 31) / 32, (CoutP + 31) / 32, Kw), block(32, 8);
     hipLaunchKernelGGL(pack_weights_kernel, grid, block, 0, (hipStream_t)stream, w, s_co, s_ci, s_kw, Cout, Cin, Kw,
                        CoutP, CinP, (bf16_raw*)w_fwd_hi, (bf16_raw*)w_fwd_lo, (bf16_raw*)w_dgr_hi, (bf16_raw*)w_dgr_lo);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int w2l_sgd_pack(float* p, const float* g, float* m, int first_step, float lr, float momentum,
+                            float weight_decay, int nesterov, int Cout, int Cin, int Kw, void* w_fwd_hi, void* w_fwd_lo,
+                            void* w_dgr_hi, void* w_dgr_lo, void* stream) {
+    W2L_CHECK_ARG(p && g && m, "sgd_pack: null pointer");
+    W2L_CHECK_ARG(Cout > 0 && Cin > 0 && Kw > 0, "sgd_pack: bad sizes");
+    W2L_CHECK_ARG(!(w_fwd_lo && !w_fwd_hi) && !(w_dgr_lo && !w_dgr_hi), "sgd_pack: lo without hi");
+    dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, Kw), block(32, 8);
+    hipLaunchKernelGGL(sgd_pack_kernel, grid, block, 0, (hipStream_t)stream, p, g, m, first_step, lr, momentum,
+                       weight_decay, nesterov, Cout, Cin, Kw, (bf16_raw*)w_fwd_hi, (bf16_raw*)w_fwd_lo,
+                       (bf16_raw*)w_dgr_hi, (bf16_raw*)w_dgr_lo);
     W2L_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,109 @@
+"""FusedSGD: torch.optim.SGD semantics (the reference's optimizer, configuration/optimizer/
+exp_lr_optimizer.yaml:2-7) with the conv-weight update fused with the bf16 operand packing of the
+next step (w2l_sgd_pack).  Non-conv parameters (biases, BatchNorm affine) use torch's own foreach
+update.  State-dict layout is torch.optim.SGD's (``momentum_buffer`` per parameter)."""
+from __future__ import annotations
+
+import torch
+
+from . import engine as E
+from ._lib import check, lib, ptr, stream_ptr
+
+
+def _is_tap_major(t: torch.Tensor) -> bool:
+    """logical [Cout, Cin, Kw] view of a dense [Kw, Cout, Cin] storage"""
+    if t.dim() != 3:
+        return False
+    co, ci, kw = t.shape
+    return t.stride() == (ci, 1, co * ci)
+
+
+class FusedSGD(torch.optim.SGD):
+    @classmethod
+    def from_sgd(cls, opt: torch.optim.SGD) -> 'FusedSGD':
+        new = cls.__new__(cls)
+        new.__dict__.update(opt.__dict__)
+        return new
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            lr, mu, wd = group['lr'], group['momentum'], group['weight_decay']
+            nesterov, dampening, maximize = group['nesterov'], group['dampening'], group.get('maximize', False)
+            fused_ok = mu != 0 and dampening == 0 and not maximize
+            rest = []
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                g = p.grad
+                if (fused_ok and p.is_cuda and p.dtype == torch.float32 and _is_tap_major(p) and g.stride() == p.stride()
+                        and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0):
+                    self._fused_conv(p, g, lr, mu, wd, nesterov)
+                else:
+                    rest.append(p)
+            if rest:
+                self._plain(rest, lr, mu, wd, nesterov, dampening, maximize)
+        return loss
+
+    def _fused_conv(self, p, g, lr, mu, wd, nesterov):
+        state = self.state[p]
+        first = 'momentum_buffer' not in state or state['momentum_buffer'] is None
+        if first:
+            state['momentum_buffer'] = torch.empty_like(p)           # preserves the tap-major strides
+        buf = state['momentum_buffer']
+        if buf.stride() != p.stride():
+            buf = torch.empty_like(p).copy_(buf)
+            state['momentum_buffer'] = buf
+        cout, cin, kw = p.shape
+        dev = p.device
+        cache = getattr(p, '_w2l_pack', None)
+        if cache is None:
+            cache = {}
+            p._w2l_pack = cache
+        precise = any(k for k in cache)                              # keep hi/lo pairs alive only if fp32 mode is in use
+        old = cache.get(precise)
+        if old is not None and old.fwd_hi.device == dev and old.coutp == cout and old.cinp == cin:
+            fwd_hi, fwd_lo, dgr_hi, dgr_lo = old.fwd_hi, old.fwd_lo, old.dgr_hi, old.dgr_lo
+        else:
+            fwd_hi = torch.empty(kw, cout, cin, dtype=torch.bfloat16, device=dev)
+            dgr_hi = torch.empty(kw, cin, cout, dtype=torch.bfloat16, device=dev)
+            fwd_lo = torch.empty_like(fwd_hi) if precise else None
+            dgr_lo = torch.empty_like(dgr_hi) if precise else None
+        check(lib.w2l_sgd_pack(ptr(p), ptr(g), ptr(buf), int(first), float(lr), float(mu), float(wd), int(nesterov),
+                               cout, cin, kw, ptr(fwd_hi), ptr(fwd_lo), ptr(dgr_hi), ptr(dgr_lo), stream_ptr()),
+              'w2l_sgd_pack')
+        torch.autograd.graph.increment_version(p)                    # p changed through its raw pointer
+        cache.clear()
+        cache[precise] = E._PackedW(p._version, fwd_hi, fwd_lo, dgr_hi, dgr_lo, cin, cout, p.data_ptr())
+
+    def _plain(self, params, lr, mu, wd, nesterov, dampening, maximize):
+        grads = [p.grad for p in params]
+        if maximize:
+            grads = torch._foreach_neg(grads)
+        if wd != 0:
+            grads = torch._foreach_add(grads, params, alpha=wd)
+        if mu != 0:
+            bufs = []
+            fresh = []
+            for p, g in zip(params, grads):
+                st = self.state[p]
+                if st.get('momentum_buffer') is None:
+                    st['momentum_buffer'] = torch.clone(g).detach()
+                    fresh.append(True)
+                else:
+                    fresh.append(False)
+                bufs.append(st['momentum_buffer'])
+            old = [b for b, f in zip(bufs, fresh) if not f]
+            oldg = [g for g, f in zip(grads, fresh) if not f]
+            if old:
+                torch._foreach_mul_(old, mu)
+                torch._foreach_add_(old, oldg, alpha=1 - dampening)
+            if nesterov:
+                grads = torch._foreach_add(grads, bufs, alpha=mu)
+            else:
+                grads = bufs
+        torch._foreach_add_(params, grads, alpha=-lr)
