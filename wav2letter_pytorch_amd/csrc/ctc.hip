@@ -18,15 +18,18 @@ namespace {
 
 constexpr float NEG_INF = -INFINITY;
 
+// The recursion is a 500-step serial chain per utterance, so the per-step latency is what matters: the
+// hardware v_exp_f32 / v_log_f32 forms (~1 ulp-level relative error) are used instead of libm's expf/logf.
+// The log-domain values reach magnitudes of ~1e3 where one fp32 ulp (1.2e-4) already dominates that error.
 __device__ __forceinline__ float lse2(float a, float b) {
     const float m = fmaxf(a, b);
     if (m == NEG_INF) return NEG_INF;
-    return m + logf(expf(a - m) + expf(b - m));
+    return m + __logf(__expf(a - m) + __expf(b - m));
 }
 __device__ __forceinline__ float lse3(float a, float b, float c) {
     const float m = fmaxf(fmaxf(a, b), c);
     if (m == NEG_INF) return NEG_INF;
-    return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+    return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
 }
 
 // ---------------------------------------------------------------- softmax family
@@ -81,9 +84,12 @@ struct CtcParams {
     float* nll;                // [N]
 };
 
-template <int SPT>   // states per thread (blockDim = 256)
+// SPT = states per thread (blockDim = 256).  LP_LDS: the utterance's whole log-prob matrix (T x C fp32,
+// 58 KB at T'=500) is staged in LDS once, so a time step never waits on an L2 round trip; otherwise the
+// emissions are prefetched from global memory one step ahead (long utterances, T*C*4 > ~150 KB).
+template <int SPT, bool LP_LDS>
 __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(CtcParams p) {
-    extern __shared__ float sh[];              // [2][Lpad + 4] (two guard cells on each side)
+    extern __shared__ float sh[];              // [2][Lpad + 4] (two guard cells on each side) | [T*C] log-probs
     const int n = blockIdx.x;
     const bool is_beta = blockIdx.y == 1;
     const int tid = threadIdx.x;
@@ -94,6 +100,13 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(CtcParams p) {
     float* buf0 = sh + 2;
     float* buf1 = sh + Lp + 2;
     const float* lp = p.lp + (int64_t)n * p.T * p.C;
+    if (LP_LDS) {
+        float* lds_lp = sh + 2 * Lp;
+        const int total = Tn * p.C;            // rows are contiguous: one linear, coalesced copy
+        for (int i = tid; i < total; i += 256) lds_lp[i] = lp[i];
+        lp = lds_lp;
+        __syncthreads();
+    }
     float* dst = (is_beta ? p.beta : p.alpha) + (int64_t)n * p.T * p.L;
     const int32_t* tg = p.targets + (int64_t)n * p.Smax;
 
@@ -165,7 +178,11 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(CtcParams p) {
             next[s] = v;
             if (s < L) dst[(int64_t)t * p.L + s] = v;
         }
-        __syncthreads();
+        // LDS-only barrier: the alpha/beta stores and the emission prefetch stay in flight across it
+        // (__syncthreads() would drain vmcnt: one L2 round trip per time step on a 500-step serial chain)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         float* tmp = prev; prev = next; next = tmp;
     }
     if (!is_beta && tid == 0) {
@@ -305,13 +322,26 @@ extern "C" int w2l_ctc_loss(const float* log_probs, const int32_t* targets, cons
     p.nll = nll;
     const int spt = (L + 255) / 256;
     dim3 grid(N, 2), block(256);
-    const size_t lds = 2 * (size_t)(spt * 256 + 4) * sizeof(float);
+    size_t lds = 2 * (size_t)(spt * 256 + 4) * sizeof(float);
+    const size_t lp_bytes = (size_t)T * C * sizeof(float);
+    const bool lp_lds = lds + lp_bytes <= 150 * 1024;
+    if (lp_lds) lds += lp_bytes;
+#define W2L_CTC_LAUNCH(SPT)                                                                              \
+    do {                                                                                                 \
+        if (lp_lds) {                                                                                    \
+            W2L_CHECK_HIP(w2l_allow_big_lds((const void*)ctc_alpha_beta_kernel<SPT, true>));             \
+            hipLaunchKernelGGL((ctc_alpha_beta_kernel<SPT, true>), grid, block, lds, (hipStream_t)stream, p);  \
+        } else {                                                                                         \
+            hipLaunchKernelGGL((ctc_alpha_beta_kernel<SPT, false>), grid, block, lds, (hipStream_t)stream, p); \
+        }                                                                                                \
+    } while (0)
     switch (spt) {
-        case 1: hipLaunchKernelGGL(ctc_alpha_beta_kernel<1>, grid, block, lds, (hipStream_t)stream, p); break;
-        case 2: hipLaunchKernelGGL(ctc_alpha_beta_kernel<2>, grid, block, lds, (hipStream_t)stream, p); break;
-        case 3: hipLaunchKernelGGL(ctc_alpha_beta_kernel<3>, grid, block, lds, (hipStream_t)stream, p); break;
-        default: hipLaunchKernelGGL(ctc_alpha_beta_kernel<4>, grid, block, lds, (hipStream_t)stream, p); break;
+        case 1: W2L_CTC_LAUNCH(1); break;
+        case 2: W2L_CTC_LAUNCH(2); break;
+        case 3: W2L_CTC_LAUNCH(3); break;
+        default: W2L_CTC_LAUNCH(4); break;
     }
+#undef W2L_CTC_LAUNCH
     W2L_CHECK_LAUNCH();
     if (grad) {
         hipLaunchKernelGGL(ctc_grad_kernel, dim3((T + 3) / 4, N), dim3(256), 0, (hipStream_t)stream, p, grad, nll);
