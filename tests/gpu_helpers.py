@@ -39,16 +39,17 @@ def device_step(model, x, il, tg, tl):
     return out.detach(), out_lens, loss.detach(), model._last_ctx
 
 
-def device_gates(ectx):
+def device_gates(ectx, relu=False):
     """activation gradient gates the device used, recovered from its stored activations:
-    clamp passes gradient iff 0 < a < 20 (exact ties at the bounds have measure zero)."""
+    clamp passes gradient iff 0 < a < 20 (exact ties at the bounds have measure zero), ReLU iff a > 0."""
     gates = []
     for i, uc in enumerate(ectx['units']):
         act = ectx['acts'][i + 1]
         a = act.hi[:, act.pad_l:act.pad_l + act.T, :act.C].float()
         if act.lo is not None:
             a = a + act.lo[:, act.pad_l:act.pad_l + act.T, :act.C].float()
-        gates.append(((a > 0) & (a < 20)).transpose(1, 2).cpu())
+        g = (a > 0) if relu else ((a > 0) & (a < 20))
+        gates.append(g.transpose(1, 2).cpu())
     return gates
 
 
@@ -107,3 +108,57 @@ def compare_step(model, layers, sd, x, il, tg, tl, precision, drop=False):
         elif 'num_batches' in k:
             assert int(msd[k]) == int(v), k
     return errs, stats, out, out_lens, ref
+
+
+def build_jasper(blocks, sd, precision, mid_layers=None):
+    from wav2letter_pytorch_amd import Jasper
+    from wav2letter_pytorch_amd.config import to_cfg
+    labels = O.ENGLISH_LOWERCASE
+    cfg = to_cfg(dict(name='jasper', mid_layers=mid_layers or len(blocks), jasper_blocks=blocks, input_size=64, labels=labels,
+                      precision=precision, audio_conf=dict(window='hamming', window_stride=0.01, window_size=0.02, sample_rate=16000),
+                      decoder=dict(_target_='decoder.GreedyDecoder', labels=labels)))
+    model = Jasper(cfg)
+    model.load_state_dict({k: v.clone() for k, v in sd.items()})
+    return model.cuda()
+
+
+def compare_jasper_step(model, blocks, sd, x, il, tg, tl, precision):
+    """device Jasper step vs the oracle with the device's ReLU gates replayed"""
+    out, out_lens, loss, ectx = device_step(model, x, il, tg, tl)
+    gates = device_gates(ectx, relu=True)
+
+    def run(gates_):
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running_' not in k}
+        work = {k: v.clone() for k, v in sd.items()}
+        work.update(params)
+        inter = []
+        lp, ol = O.jasper_forward(x, il, work, blocks, training=True, gates=gates_, inter=inter)
+        ls = O.ctc_criterion(lp, tg, ol, tl)
+        ls.backward()
+        return lp.detach(), ol, ls.detach(), {k: p.grad for k, p in params.items()}, work, [a.detach() for a in inter]
+
+    lp0, _, _, _, _, inter0 = run(None)
+    tie = 2e-3 if precision == 'fp32' else 0.25
+    for a, g, uc in zip(inter0, gates, ectx['units']):
+        dis = (a > 0) != g
+        if uc.lens_out is not None:          # frames the next MaskedConv1d zeroes carry no gradient: not comparable
+            t = torch.arange(a.shape[2])[None, None, :]
+            dis = dis & (t < uc.lens_out.cpu().long()[:, None, None])
+        if dis.any():
+            assert bool((dis & ~(a.abs() < tie)).sum() == 0), 'ReLU gate differs away from 0'
+            assert dis.float().mean() < (2e-3 if precision == 'fp32' else 0.05)
+    lp, ol, ls, grads, work, _ = run(gates)
+    errs = {'log_probs': scale_err(out.cpu().numpy(), lp.numpy()),
+            'loss': abs(float(loss) - float(ls)) / max(1.0, abs(float(ls)))}
+    assert torch.equal(out_lens.cpu(), ol.cpu()), (out_lens, ol)
+    for k, p in model.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, k
+        errs[k] = scale_err(p.grad.cpu().numpy(), grads[k].numpy())
+    stats = {}
+    msd = model.state_dict()
+    for k, v in work.items():
+        if 'running_' in k:
+            stats[k] = scale_err(msd[k].cpu().numpy(), v.numpy())
+        elif 'num_batches' in k:
+            assert int(msd[k]) == int(v), k
+    return errs, stats, out, out_lens

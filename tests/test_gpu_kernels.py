@@ -100,6 +100,7 @@ CONV_CASES = [
     (2, 64, 192, 29, 1, 2, 150, 28, 28),    # dilation 2, Cout not a multiple of the 128 tile
     (2, 192, 64, 1, 1, 1, 70, 0, 0),        # 1x1 (classifier-like, Cout < tile)
     (1, 256, 256, 13, 1, 1, 500, 6, 6),     # T spans several 128-row tiles
+    (2, 64, 64, 29, 1, 2, 75, 28, 28),      # short utterances: K steps run into the zero gap / next utterance
 ]
 
 

@@ -197,3 +197,37 @@ def test_fused_sgd_matches_torch_sgd():
     assert torch.equal(pk.fwd_hi, ref)
     assert torch.equal(pk.dgr_hi, wa.detach().flip(2).permute(2, 1, 0).to(torch.bfloat16).contiguous())
     assert isinstance(ma.configure_optimizers()[0][0], FusedSGD)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_jasper_dense_golden(precision):
+    """Jasper with dense (non-separable) blocks, repeat 2, residual 1x1 conv + BN, dilation 2, stride-2 first block,
+    length masking with ragged (odd) lengths: reference-generated fixture jasper_dense.npz"""
+    from gpu_helpers import build_jasper, compare_jasper_step
+    z = load('jasper_dense.npz')
+    meta = ast.literal_eval(str(z['meta']))
+    sd = {k[3:]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith('p0/')}
+    model = build_jasper(meta['blocks'], sd, precision).train()
+    x = torch.from_numpy(z['x'])
+    il, tg, tl = (torch.from_numpy(z[k]) for k in ('in_lens', 'targets', 'target_lens'))
+    errs, stats, out, out_lens = compare_jasper_step(model, meta['blocks'], sd, x, il, tg, tl, precision)
+    check(errs, stats, precision)
+    t = TOL[precision]
+    np.testing.assert_array_equal(out_lens.numpy(), z['out_lens'])
+    assert scale_err(out.cpu().numpy(), z['log_probs']) < t['lp']
+    if precision == 'fp32':
+        model.eval()                 # eval: running stats AND softmax instead of log_softmax (jasper.py:470-473)
+        with torch.no_grad():
+            oe, _ = model(x.cuda(), il)
+        assert scale_err(oe.cpu().numpy(), z['out_eval']) < 2e-3
+        assert abs(float(oe.sum(-1).mean()) - 1.0) < 1e-4
+
+
+def test_jasper_separable_raises_loudly():
+    from gpu_helpers import build_jasper
+    z = load('jasper_sep2.npz')
+    meta = ast.literal_eval(str(z['meta']))
+    sd = {k[3:]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith('p0/')}
+    model = build_jasper(meta['blocks'], sd, 'fp32').train()
+    with pytest.raises(NotImplementedError):
+        model(torch.from_numpy(z['x']).cuda(), torch.from_numpy(z['in_lens']))

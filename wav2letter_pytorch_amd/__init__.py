@@ -6,5 +6,6 @@ from .base_asr_models import ConvCTCASR  # noqa: F401
 from .ctc_loss import CTCLoss  # noqa: F401
 from .decoder import Decoder, GreedyDecoder  # noqa: F401
 from .wav2letter import Conv1dBlock, Wav2Letter  # noqa: F401
+from .jasper import Jasper, JasperBlock, MaskedConv1d  # noqa: F401
 
-__all__ = ['ConvCTCASR', 'CTCLoss', 'Decoder', 'GreedyDecoder', 'Conv1dBlock', 'Wav2Letter']
+__all__ = ['ConvCTCASR', 'CTCLoss', 'Decoder', 'GreedyDecoder', 'Conv1dBlock', 'Wav2Letter', 'Jasper', 'JasperBlock', 'MaskedConv1d']

@@ -198,18 +198,22 @@ __device__ __forceinline__ void bwd_row(const w2l_bnact_t& d, const Chan& c1, co
     float z[8], y1[8], y2v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { o.g[j] = 0.f; o.xh1[j] = 0.f; o.xh2[j] = 0.f; y2v[j] = 0.f; }
-    if (d.lens && t >= d.lens[n]) return;        // masked_fill: no gradient through zeroed frames
     const uint32_t bits = preact8<F32, HAS2>(d, c1, c2, (int64_t)n * d.T + t, cg, G, z, y1, y2v, 0, inv_keep, false, false);
+    // masked_fill (jasper.py:116-119) zeroes the OUTPUT frame t >= len: no gradient flows through it, but the
+    // frame still is a BatchNorm sample, so its normalised value enters dy through the -xhat*sum(g*xhat)/M term
+    const bool masked = d.lens && t >= d.lens[n];
     float g[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = 0.f;
-    add_grad8<GF32>(g1, n, t, d.T, d.C, cg, g);
-    if (has_g2) add_grad8<GF32>(g2, n, t, d.T, d.C, cg, g);
+    if (!masked) {
+        add_grad8<GF32>(g1, n, t, d.T, d.C, cg, g);
+        if (has_g2) add_grad8<GF32>(g2, n, t, d.T, d.C, cg, g);
+    }
     const float gk = d.drop_p > 0.f ? inv_keep : 1.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const bool keep = (bits >> j) & 1u;
-        o.g[j] = (keep && act_pass(z[j], d.act)) ? g[j] * gk : 0.f;
+        o.g[j] = (!masked && keep && act_pass(z[j], d.act)) ? g[j] * gk : 0.f;
         o.xh1[j] = (y1[j] - c1.m[j]) * c1.is[j];           // is == 0 when the branch has no BatchNorm
         if (HAS2) o.xh2[j] = (y2v[j] - c2.m[j]) * c2.is[j];
     }

@@ -86,7 +86,9 @@ class UnitSpec:
     drop_p: float = 0.0
     res: Optional[ConvSpec] = None        # residual branch conv (+BN) -- jasper.py:241-255,400-410
     res_src: Optional[int] = None
-    mask_lens: bool = False               # zero frames t >= len before the next conv (jasper.py:116-119)
+    update_lens: bool = False             # the conv is a MaskedConv1d: lens <- get_seq_len(lens) (jasper.py:109-121)
+    mask_out: bool = False                # zero frames t >= len of the output: the NEXT MaskedConv1d's masked_fill
+                                          # (jasper.py:116-119), applied where the activation is written
 
 
 @dataclass
@@ -293,7 +295,7 @@ class StackEngine:
         st = stream_ptr
         ctx = {'units': [], 'acts': [], 'training': training, 'x_shape': (N, C0, T0)}
         lens_dev = None
-        if lens is not None and any(u.mask_lens for u in self.units):
+        if lens is not None and any(u.update_lens or u.mask_out for u in self.units):
             lens_dev = lens.to(device=dev, dtype=torch.int32)
         # ---- activation 0: the spectrogram, channels-last, padded for its consumers
         pl, pr, mode = self._in_pad_for(0)
@@ -324,9 +326,10 @@ class StackEngine:
                 if u.res.has_bn:
                     uc.scale2, uc.shift2, uc.mean2, uc.invstd2 = self._bn_finalize(u.res, stats2, N * Tout, coutp, training)
             # length bookkeeping (jasper.py:109-112: true division, truncated at the next mask)
-            if u.mask_lens and cur_lens_f is not None:
+            if u.update_lens and cur_lens_f is not None:
                 cur_lens_f = (cur_lens_f + (conv.pad_l + conv.pad_r) - conv.dilation * (conv.kernel - 1) - 1) / conv.stride + 1
                 cur_lens = cur_lens_f.to(torch.int32)
+            if u.mask_out and cur_lens is not None:
                 uc.lens_out = cur_lens
             # ---- BN-apply + dropout + activation -> padded input of the next conv
             opl, opr, omode = self._in_pad_for(ui + 1)
@@ -338,12 +341,11 @@ class StackEngine:
                 uc.seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
                 _dropout_calls += 1
                 uc.offset = _dropout_calls
-            d = self._desc(uc, N, Tout, coutp, p, uc.lens_out if u.mask_lens else None)
+            d = self._desc(uc, N, Tout, coutp, p, uc.lens_out)
             check(lib.w2l_bn_act_fwd(C.byref(d), ptr(out_hi), ptr(out_lo), opl + Tout + opr, opl, opr, omode, st()),
                   'w2l_bn_act_fwd')
             uc.out_index = ui + 1
-            acts.append(Act(out_hi, out_lo, N, Tout, conv.cout, coutp, opl, opr, omode,
-                            uc.lens_out if u.mask_lens else None))
+            acts.append(Act(out_hi, out_lo, N, Tout, conv.cout, coutp, opl, opr, omode, uc.lens_out))
             ctx['units'].append(uc)
 
         # ---- classifier (1x1 conv, bias, no BN) + (log_)softmax
@@ -355,7 +357,7 @@ class StackEngine:
         ctx['acts'] = acts
         ctx['out'] = out
         ctx['softmax_mode'] = softmax_mode
-        ctx['lens_out'] = cur_lens
+        ctx['lens_out'] = cur_lens_f if cur_lens_f is not None else None
         return out, ctx
 
     def _conv_forward(self, conv: ConvSpec, src: Act, need_stats: bool, force_f32: bool = False):
@@ -471,7 +473,7 @@ class StackEngine:
             a_out = acts[oi]
             Tout, coutp = uc.Tout, a_out.CP
             p = u.drop_p if (ctx['training'] and uc.mask is not None) else 0.0
-            d = self._desc(uc, N, Tout, coutp, p, uc.lens_out if u.mask_lens else None)
+            d = self._desc(uc, N, Tout, coutp, p, uc.lens_out)
             g1 = self._gsrc(srcs[0])
             g2 = self._gsrc(srcs[1]) if len(srcs) > 1 else None
             sums = None

@@ -1,0 +1,281 @@
+"""Jasper on the HIP step engine (reference: jasper.py:21-475, itself derived from NVIDIA's
+DeepLearningExamples Jasper).  Module tree, constructor arguments, state-dict keys
+(``jasper_encoder.{b}.mconv.{j}.conv.weight`` / ``.mconv.{j}.{weight,bias,running_*}`` /
+``.res.{r}.{j}...`` / ``final_layer.0.{weight,bias}``) and quirks follow the reference:
+even kernel sizes are bumped to odd (jasper.py:53-58), lengths are updated with true division
+(:109-112), eval mode returns softmax instead of log-softmax (:470-473), NaN assert (:474).
+
+Only what ``Jasper._build_encoder`` can reach is executable (jasper.py:440-449): batch
+normalisation, ReLU, 'add' residual from the block input, conv_mask, dense or separable convs;
+the depthwise half of a separable conv is not built yet and raises at forward time."""
+from __future__ import annotations
+
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .base_asr_models import ConvCTCASR
+from .engine import ACT_NONE, ACT_RELU, PAD_ZERO, StackEngine, UnitSpec
+from .layers import BatchNorm1d, Conv1d, conv_spec, default_precision, run_stack
+
+jasper_activations = {
+    "hardtanh": nn.Hardtanh,
+    "relu": nn.ReLU,
+    "selu": nn.SELU,
+}
+
+
+def init_weights(m, mode='xavier_uniform'):
+    """jasper.py:29-50"""
+    if isinstance(m, MaskedConv1d):
+        init_weights(m.conv, mode)
+    if isinstance(m, Conv1d):
+        if mode == 'xavier_uniform':
+            m.reset_parameters('xavier_uniform')
+        else:
+            raise ValueError("Unknown Initialization mode: {0}".format(mode))
+    elif isinstance(m, BatchNorm1d):
+        m.running_mean.zero_()
+        m.running_var.fill_(1)
+        m.num_batches_tracked.zero_()
+        nn.init.ones_(m.weight)
+        nn.init.zeros_(m.bias)
+
+
+def compute_new_kernel_size(kernel_size, kernel_width):
+    new_kernel_size = max(int(kernel_size * kernel_width), 1)
+    if new_kernel_size % 2 == 0:          # even kernels are rounded up to odd
+        new_kernel_size += 1
+    return new_kernel_size
+
+
+def get_same_padding(kernel_size, stride, dilation):
+    if stride > 1 and dilation > 1:
+        raise ValueError("Only stride OR dilation may be greater than 1")
+    if dilation > 1:
+        return (dilation * kernel_size) // 2 - 1
+    return kernel_size // 2
+
+
+class _NoParams(nn.Module):
+    """stands where the reference keeps an activation / Dropout module so that ModuleList indices
+    (= state-dict keys of the later entries) stay the reference's"""
+
+    def __init__(self, what):
+        super().__init__()
+        self.what = what
+
+    def extra_repr(self):
+        return self.what
+
+
+class MaskedConv1d(nn.Module):
+    """jasper.py:69-132: masked_fill by length + nn.Conv1d(bias=False by default)."""
+    __constants__ = ["use_conv_mask", "real_out_channels", "heads"]
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, heads=-1,
+                 bias=False, use_mask=True):
+        super(MaskedConv1d, self).__init__()
+        if not (heads == -1 or groups == in_channels):
+            raise ValueError("Only use heads for depthwise convolutions")
+        if heads != -1:
+            raise NotImplementedError('heads != -1 is not reachable from Jasper._build_encoder (jasper.py:440-449)')
+        self.real_out_channels = out_channels
+        self.conv = Conv1d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, dilation=dilation,
+                           groups=groups, bias=bias, init='xavier_uniform')
+        self.use_mask = use_mask
+        self.heads = heads
+
+    def get_seq_len(self, lens):
+        return (lens + 2 * self.conv.padding[0] - self.conv.dilation[0] * (self.conv.kernel_size[0] - 1) - 1
+                ) / self.conv.stride[0] + 1
+
+    def forward(self, x, lens):
+        raise RuntimeError('MaskedConv1d runs inside Jasper.forward on the HIP step engine')
+
+
+class GroupShuffle(nn.Module):
+    """jasper.py:135-151 (channel shuffle for grouped convs; not reachable from the config)."""
+
+    def __init__(self, groups, channels):
+        super(GroupShuffle, self).__init__()
+        self.groups = groups
+        self.channels_per_group = channels // groups
+
+    def forward(self, x):
+        sh = x.shape
+        x = x.view(-1, self.groups, self.channels_per_group, sh[-1])
+        x = torch.transpose(x, 1, 2).contiguous()
+        return x.view(-1, self.groups * self.channels_per_group, sh[-1])
+
+
+class JasperBlock(nn.Module):
+    __constants__ = ["conv_mask", "separable", "residual_mode", "res", "mconv"]
+
+    def __init__(self, inplanes, planes, repeat=3, kernel_size=11, kernel_size_factor=1, stride=1, dilation=1,
+                 padding='same', dropout=0, activation=None, residual=True, groups=1, separable=False, heads=-1,
+                 normalization="batch", norm_groups=1, residual_mode='add', residual_panes=[], conv_mask=False):
+        super(JasperBlock, self).__init__()
+        if padding != "same":
+            raise ValueError("currently only 'same' padding is supported")
+        if normalization != "batch":
+            if normalization in ("group", "instance", "layer"):
+                raise NotImplementedError(f'normalization={normalization!r} is not reachable from the config '
+                                          '(jasper.py:440-449) and is not built')
+            raise ValueError(f"Normalization method ({normalization}) does not match one of [batch, layer, group, instance].")
+        if groups != 1 or heads != -1 or len(residual_panes) or residual_mode != 'add':
+            raise NotImplementedError('groups / heads / dense residual / max residual are not reachable from the config')
+        if activation is not None and not isinstance(activation, nn.ReLU):
+            raise NotImplementedError('Jasper._build_encoder always passes nn.ReLU() (jasper.py:448)')
+        if not conv_mask:
+            raise NotImplementedError('conv_mask=False (plain nn.Conv1d blocks) is not built; the config default is True')
+        kernel_size_factor = float(kernel_size_factor)
+        if type(kernel_size) in (list, tuple):
+            kernel_size = [compute_new_kernel_size(k, kernel_size_factor) for k in kernel_size][0]
+        else:
+            kernel_size = compute_new_kernel_size(kernel_size, kernel_size_factor)
+        padding_val = get_same_padding(kernel_size, stride, dilation)
+        self.conv_mask = conv_mask
+        self.separable = separable
+        self.residual_mode = residual_mode
+        self.repeat = repeat
+        self.dropout = dropout
+        self.kernel_size, self.stride, self.dilation, self.padding_val = kernel_size, stride, dilation, padding_val
+
+        inplanes_loop = inplanes
+        conv = nn.ModuleList()
+        for _ in range(repeat - 1):
+            conv.extend(self._get_conv_bn_layer(inplanes_loop, planes, kernel_size=kernel_size, stride=stride,
+                                                dilation=dilation, padding=padding_val, separable=separable))
+            conv.extend(self._get_act_dropout_layer(drop_prob=dropout))
+            inplanes_loop = planes
+        conv.extend(self._get_conv_bn_layer(inplanes_loop, planes, kernel_size=kernel_size, stride=stride,
+                                            dilation=dilation, padding=padding_val, separable=separable))
+        self.mconv = conv
+        self.dense_residual = residual
+        if residual:
+            res_list = nn.ModuleList()
+            res_list.append(nn.ModuleList(self._get_conv_bn_layer(inplanes, planes, kernel_size=1)))
+            self.dense_residual = False
+            self.res = res_list
+        else:
+            self.res = None
+        self.mout = nn.Sequential(*self._get_act_dropout_layer(drop_prob=dropout))
+
+    def _get_conv(self, in_channels, out_channels, kernel_size=11, stride=1, dilation=1, padding=0, bias=False,
+                  groups=1):
+        return MaskedConv1d(in_channels, out_channels, kernel_size, stride=stride, dilation=dilation, padding=padding,
+                            bias=bias, groups=groups, use_mask=self.conv_mask)
+
+    def _get_conv_bn_layer(self, in_channels, out_channels, kernel_size=11, stride=1, dilation=1, padding=0,
+                           separable=False):
+        if separable:
+            layers = [self._get_conv(in_channels, in_channels, kernel_size, stride=stride, dilation=dilation,
+                                     padding=padding, groups=in_channels),
+                      self._get_conv(in_channels, out_channels, kernel_size=1, stride=1, dilation=1, padding=0)]
+        else:
+            layers = [self._get_conv(in_channels, out_channels, kernel_size, stride=stride, dilation=dilation,
+                                     padding=padding)]
+        layers.append(BatchNorm1d(out_channels, eps=1e-3, momentum=0.1))
+        return layers
+
+    def _get_act_dropout_layer(self, drop_prob=0.2):
+        return [_NoParams('ReLU'), _NoParams(f'Dropout(p={drop_prob})')]
+
+    def units(self, a_in: int, next_act: int, name: str, mask_last_output: bool) -> List[UnitSpec]:
+        """engine units of this block; ``a_in`` = index of the block-input activation, ``next_act`` = index the
+        first unit's output will get"""
+        if self.separable:
+            raise NotImplementedError('separable JasperBlock: the depthwise convolution kernel is not built yet '
+                                      '(use separable: False blocks, e.g. Jasper 10x5)')
+        mods = list(self.mconv)
+        convs = [(mods[i], mods[i + 1]) for i in range(len(mods)) if isinstance(mods[i], MaskedConv1d)]
+        out = []
+        src = a_in
+        for r, (mc, bn) in enumerate(convs):
+            last = r == len(convs) - 1
+            spec = conv_spec(mc.conv, bn, self.padding_val, self.padding_val, PAD_ZERO, f'{name}.mconv{r}')
+            u = UnitSpec(main=spec, src=src, act=ACT_RELU, drop_p=float(self.dropout), update_lens=self.conv_mask,
+                         mask_out=self.conv_mask and not (last and not mask_last_output))
+            if last and self.res is not None:
+                rc, rbn = self.res[0][0], self.res[0][1]
+                u.res = conv_spec(rc.conv, rbn, 0, 0, PAD_ZERO, f'{name}.res')
+                u.res_src = a_in
+            out.append(u)
+            src = next_act + r
+        return out
+
+    def forward(self, input_):
+        raise RuntimeError('JasperBlock runs inside Jasper.forward on the HIP step engine')
+
+
+class Jasper(ConvCTCASR):
+    def __init__(self, cfg):
+        super(Jasper, self).__init__(cfg)
+        self.mid_layers = cfg.mid_layers
+        if not cfg.input_size:
+            nfft = (self.audio_conf['sample_rate'] * self.audio_conf['window_size'])
+            self.input_size = int(1 + (nfft / 2))
+        else:
+            self.input_size = cfg.input_size
+        self.precision = default_precision(cfg)
+        self.check_nan = True                    # jasper.py:474 asserts on every forward (host sync)
+        self._build_encoder(cfg)
+        last_layer_input_size = self.jasper_encoder[-1].mconv[-1].num_features
+        self.final_layer = nn.Sequential(Conv1d(last_layer_input_size, len(self.labels), kernel_size=1, stride=1,
+                                                init='xavier_uniform'))
+        self.final_layer.apply(init_weights)
+
+    def _build_encoder(self, cfg):
+        layer_size = self.input_size
+        encoder_layers = []
+        for l in cfg.jasper_blocks[:cfg.mid_layers]:
+            layer = JasperBlock(inplanes=layer_size, planes=l.layer_size, kernel_size=l.kernel_size,
+                                stride=l.get('stride', 1), dilation=l.get('dilation', 1), residual=l.residual,
+                                repeat=l.get('repeat', 1), conv_mask=l.get('conv_mask', True),
+                                separable=l.get('separable', True), activation=torch.nn.ReLU(),
+                                dropout=l.get('dropout', 0))
+            encoder_layers.append(layer)
+            layer_size = l.layer_size
+        self.jasper_encoder = nn.Sequential(*encoder_layers)
+        self.jasper_encoder.apply(init_weights)
+
+    @property
+    def scaling_factor(self):
+        if not hasattr(self, '_scaling_factor'):
+            self._scaling_factor = int(np.prod([block.mconv[0].conv.stride[0] for block in self.jasper_encoder]))
+        return self._scaling_factor
+
+    def engine(self) -> StackEngine:
+        units: List[UnitSpec] = []
+        a_in = 0
+        blocks = list(self.jasper_encoder)
+        for b, blk in enumerate(blocks):
+            # the classifier is a plain nn.Conv1d (jasper.py:433,468): the last block's output is NOT masked
+            us = blk.units(a_in, len(units) + 1, f'block{b}', mask_last_output=b != len(blocks) - 1)
+            units += us
+            a_in = len(units)
+        head = conv_spec(self.final_layer[0], None, 0, 0, PAD_ZERO, 'head')
+        eng = StackEngine(units, head, len(self.labels), precise=self.precision == 'fp32')
+        eng.overlap_wgrad = getattr(self, '_overlap_wgrad', True)
+        reducer = getattr(self, 'grad_reducer', None)
+        if reducer is not None:
+            eng.grad_ready = reducer.on_grad
+            eng.backward_done = reducer.finish
+        return eng
+
+    def forward(self, xs, input_lengths):
+        """[batch, channels, time], lengths -> ([batch, time', labels], lengths) (jasper.py:462-475):
+        log_softmax in training, softmax in eval (reference quirk, kept)."""
+        mode = 0 if self.training else 1
+        if getattr(self, '_debug_keep_ctx', False):
+            out, lens_f, self._last_ctx = run_stack(self.engine(), xs, input_lengths, self.training, softmax_mode=mode,
+                                                    keep_ctx=True)
+        else:
+            out, lens_f = run_stack(self.engine(), xs, input_lengths, self.training, softmax_mode=mode)
+        output_lengths = lens_f.to(dtype=torch.int64).cpu() if lens_f is not None else None
+        if self.check_nan:
+            assert not bool(torch.isnan(out).any())          # is there any NaN in the result?
+        return out, output_lengths
