@@ -95,6 +95,21 @@ int w2l_conv1d_wgrad(const void* dy, int64_t dy_bstride, const void* xp, int64_t
                      float* dw, int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int accumulate,
                      void* stream);
 
+/* ---- depthwise Conv1d, groups == channels (nn.Conv1d inside MaskedConv1d, jasper.py:96-105,127,319-330) ----
+ * weights fp32 tap-major w[k][c]; activations channels-last bf16 hi [+ lo]; fp32 arithmetic; HBM-bound.
+ * fwd:   y[n][t][c] = sum_k w[k][c] * xp[n][t*stride + k*dil][c]; frames t >= lens[n] are written as 0
+ *        (the next MaskedConv1d's masked_fill).  xp: [N][x_rows][C] zero-padded by the producer.
+ * dgrad: dxp[n][v][c] = sum_k w[k][c] * dy[n][v - k*dil][c] (stride 1), v in [0, Tp); dy [N][dy_rows][C] with
+ *        Tout valid frames, frames >= lens[n] count as 0.
+ * wgrad: dw[k][c] += sum_{n, t < min(Tout, lens[n])} dy[n][t][c] * xp[n][t*stride + k*dil][c] (fp32 atomics into
+ *        a zero-filled dw). */
+int w2l_dwconv_fwd(const void* x_hi, const void* x_lo, int x_rows, const float* w, void* y_hi, void* y_lo, int N, int Tout,
+                   int C, int K, int stride, int dil, const int32_t* lens, void* stream);
+int w2l_dwconv_dgrad(const void* dy, int dy_f32, int dy_rows, const float* w, void* dxp, int dxp_f32, int N, int Tp, int Tout,
+                     int C, int K, int dil, const int32_t* lens, void* stream);
+int w2l_dwconv_wgrad(const void* dy, int dy_f32, int dy_rows, const void* x_hi, const void* x_lo, int x_rows, float* dw, int N,
+                     int Tout, int C, int K, int stride, int dil, const int32_t* lens, void* stream);
+
 /* ---- BatchNorm1d + Dropout + activation (wav2letter.py:43-46, jasper.py:363,376,448) ---- */
 
 /* partial [ntiles][2][C] -> batch mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale;

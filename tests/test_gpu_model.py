@@ -223,11 +223,18 @@ def test_jasper_dense_golden(precision):
         assert abs(float(oe.sum(-1).mean()) - 1.0) < 1e-4
 
 
-def test_jasper_separable_raises_loudly():
-    from gpu_helpers import build_jasper
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_jasper_separable_golden(precision):
+    """the shipped jasper.yaml form: depthwise (k32->33 / k38->39, stride 2 first) + pointwise convs, residual,
+    masking with an odd ragged length (float length arithmetic): reference-generated fixture jasper_sep2.npz"""
+    from gpu_helpers import build_jasper, compare_jasper_step
     z = load('jasper_sep2.npz')
     meta = ast.literal_eval(str(z['meta']))
     sd = {k[3:]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith('p0/')}
-    model = build_jasper(meta['blocks'], sd, 'fp32').train()
-    with pytest.raises(NotImplementedError):
-        model(torch.from_numpy(z['x']).cuda(), torch.from_numpy(z['in_lens']))
+    model = build_jasper(meta['blocks'], sd, precision).train()
+    x = torch.from_numpy(z['x'])
+    il, tg, tl = (torch.from_numpy(z[k]) for k in ('in_lens', 'targets', 'target_lens'))
+    errs, stats, out, out_lens = compare_jasper_step(model, meta['blocks'], sd, x, il, tg, tl, precision)
+    check(errs, stats, precision)
+    np.testing.assert_array_equal(out_lens.numpy(), z['out_lens'])
+    assert scale_err(out.cpu().numpy(), z['log_probs']) < TOL[precision]['lp']

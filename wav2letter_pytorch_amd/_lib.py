@@ -51,6 +51,9 @@ _SIGNATURES = {
     'w2l_conv_force_tile_config': (None, [c_i]),
     'w2l_wgrad_needs_zero': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'w2l_conv1d_wgrad': (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'w2l_dwconv_fwd': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'w2l_dwconv_dgrad': (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'w2l_dwconv_wgrad': (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'w2l_bn_finalize': (c_i, [c_p, c_i, c_i, c_i64, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'w2l_bn_act_fwd': (c_i, [C.POINTER(BnActDesc), c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'w2l_bn_bwd_blocks': (c_i, [c_i, c_i, c_i]),

@@ -84,6 +84,8 @@ class UnitSpec:
     src: int                              # index of the activation the main conv reads
     act: int = ACT_NONE
     drop_p: float = 0.0
+    dw: Optional[ConvSpec] = None         # depthwise conv in front of ``main`` (then a 1x1 pointwise conv): the
+                                          # separable form of jasper.py:318-341; ``src`` feeds the depthwise conv
     res: Optional[ConvSpec] = None        # residual branch conv (+BN) -- jasper.py:241-255,400-410
     res_src: Optional[int] = None
     update_lens: bool = False             # the conv is a MaskedConv1d: lens <- get_seq_len(lens) (jasper.py:109-121)
@@ -141,6 +143,7 @@ class _UnitCtx:
     offset: int = 0
     out_index: int = 0
     lens_out: Optional[torch.Tensor] = None
+    mid: Optional['Act'] = None           # depthwise output = pointwise input (separable units)
     keep: list = field(default_factory=list)
 
 
@@ -258,6 +261,8 @@ class StackEngine:
     def parameters(self) -> List[torch.Tensor]:
         out = []
         for u in self.units:
+            if u.dw is not None:
+                out += u.dw.params()
             out += u.main.params()
             if u.res is not None:
                 out += u.res.params()
@@ -272,7 +277,7 @@ class StackEngine:
         convs = []
         for u in self.units:
             if u.src == act_index:
-                convs.append(u.main)
+                convs.append(u.dw if u.dw is not None else u.main)
             if u.res is not None and u.res_src == act_index:
                 convs.append(u.res)
         if act_index == len(self.units):
@@ -312,6 +317,13 @@ class StackEngine:
             uc = _UnitCtx(unit=u)
             src = acts[u.src]
             conv = u.main
+            if u.dw is not None:            # depthwise conv -> (masked) intermediate activation -> 1x1 pointwise conv
+                dwc = u.dw
+                if u.update_lens and cur_lens_f is not None:
+                    cur_lens_f = (cur_lens_f + (dwc.pad_l + dwc.pad_r) - dwc.dilation * (dwc.kernel - 1) - 1) / dwc.stride + 1
+                    cur_lens = cur_lens_f.to(torch.int32)
+                src = self._dw_forward(dwc, src, cur_lens if u.update_lens else None)
+                uc.mid = src
             y, stats, Tout = self._conv_forward(conv, src, need_stats=conv.has_bn and training)
             uc.y, uc.Tout = y, Tout
             coutp = y.shape[2]
@@ -381,6 +393,63 @@ class StackEngine:
         _igemm(src, src.pad_l - conv.pad_l, pk.fwd_hi, pk.fwd_lo, y, bias, stats, pk.cinp, pk.coutp, Tout, conv.kernel,
                conv.stride, conv.dilation, self.precise, alg_flops=2.0 * N * Tout * conv.cout * conv.cin * conv.kernel)
         return y, stats, Tout
+
+    @staticmethod
+    def _dw_weight(dwc: ConvSpec, cp: int) -> torch.Tensor:
+        """fp32 tap-major [K][CP] view / padded copy of a depthwise weight (logical [C, 1, K])"""
+        w = dwc.weight.detach()
+        c, _, k = w.shape
+        km = w.permute(2, 0, 1).reshape(k, c)            # no copy for the tap-major parameter layout
+        if cp == c and km.is_contiguous():
+            return km
+        out = torch.zeros(k, cp, dtype=torch.float32, device=w.device)
+        out[:, :c] = km
+        return out
+
+    def _dw_forward(self, dwc: ConvSpec, src: Act, lens_mid) -> Act:
+        if src.pad_l < dwc.pad_l or src.pad_r < dwc.pad_r:
+            raise ValueError('activation buffer is not padded enough for its depthwise consumer')
+        N, cp = src.N, src.CP
+        Tp = src.T + dwc.pad_l + dwc.pad_r
+        Tmid = (Tp - (dwc.kernel - 1) * dwc.dilation - 1) // dwc.stride + 1
+        dev = src.hi.device
+        mid_hi = torch.empty(N, Tmid, cp, dtype=torch.bfloat16, device=dev)
+        mid_lo = torch.empty_like(mid_hi) if self.precise else None
+        row_off = src.pad_l - dwc.pad_l
+        off = row_off * cp * 2
+        w = self._dw_weight(dwc, cp)
+        check(lib.w2l_dwconv_fwd(C.c_void_p(src.hi.data_ptr() + off),
+                                 C.c_void_p(src.lo.data_ptr() + off) if src.lo is not None else None, src.rows, ptr(w),
+                                 ptr(mid_hi), ptr(mid_lo), N, Tmid, cp, dwc.kernel, dwc.stride, dwc.dilation, ptr(lens_mid),
+                                 stream_ptr()), 'w2l_dwconv_fwd')
+        return Act(mid_hi, mid_lo, N, Tmid, dwc.cout, cp, 0, 0, PAD_ZERO, lens_mid)
+
+    def _dw_backward(self, dwc: ConvSpec, dmid, src: Act, mid: Act, need_dx: bool, grads):
+        """depthwise weight gradient (+ data gradient) from the gradient wrt the pointwise conv's input"""
+        g, _, _, _, per = dmid
+        N, cp = src.N, src.CP
+        dev = g.device
+        row_off = src.pad_l - dwc.pad_l
+        off = row_off * cp * 2
+        k = dwc.kernel
+        dwg = torch.zeros(k, cp, dtype=torch.float32, device=dev)
+        check(lib.w2l_dwconv_wgrad(ptr(g), int(g.dtype == torch.float32), per, C.c_void_p(src.hi.data_ptr() + off),
+                                   C.c_void_p(src.lo.data_ptr() + off) if src.lo is not None else None, src.rows, ptr(dwg), N,
+                                   mid.T, cp, k, dwc.stride, dwc.dilation, ptr(mid.lens), stream_ptr()), 'w2l_dwconv_wgrad')
+        c = dwc.cout
+        gw = dwg.view(k, cp, 1).permute(1, 2, 0)          # logical [CP, 1, K] in the parameter's tap-major layout
+        self._set(grads, dwc.weight, gw if cp == c else gw[:c], storage=dwg)
+        if not need_dx:
+            return None
+        if dwc.stride != 1:
+            raise NotImplementedError('data gradient of a strided depthwise convolution')
+        Tp = src.T + dwc.pad_l + dwc.pad_r
+        dxp = torch.empty(N, Tp, cp, dtype=torch.float32 if self.precise else torch.bfloat16, device=dev)
+        w = self._dw_weight(dwc, cp)
+        check(lib.w2l_dwconv_dgrad(ptr(g), int(g.dtype == torch.float32), per, ptr(w), ptr(dxp),
+                                   int(dxp.dtype == torch.float32), N, Tp, mid.T, cp, k, dwc.dilation, ptr(mid.lens),
+                                   stream_ptr()), 'w2l_dwconv_dgrad')
+        return (dxp, dwc.pad_l, dwc.pad_r, dwc.pad_mode, Tp)
 
     def _bn_finalize(self, conv: ConvSpec, stats, count, cp, training):
         dev = conv.weight.device
@@ -512,7 +581,7 @@ class StackEngine:
                 self._set(grads, res.bn_weight, sums[3, : res.cout])
             # main branch
             pkm = pack_weights(main, precise)
-            src = acts[u.src]
+            src = acts[u.src] if u.dw is None else uc.mid
             self._wgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, grads)
             if main.bias is not None:
                 if main.has_bn:      # sum(dy) == 0 identically under BatchNorm
@@ -520,7 +589,12 @@ class StackEngine:
                 else:
                     dyv = dy_hi[h1:].view(N, Tout + h1, coutp)[:, :Tout, : main.cout]
                     self._set(grads, main.bias, dyv.float().sum((0, 1)))
-            if need_dx_main:
+            if u.dw is not None:
+                dmid = self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src)
+                gsrc = self._dw_backward(u.dw, dmid, acts[u.src], uc.mid, need_dx_main, grads)
+                if gsrc is not None:
+                    act_grads[u.src].append(gsrc)
+            elif need_dx_main:
                 act_grads[u.src].append(self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src))
             if res is not None:
                 pkr = pack_weights(res, precise)

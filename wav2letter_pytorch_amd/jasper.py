@@ -7,7 +7,7 @@ even kernel sizes are bumped to odd (jasper.py:53-58), lengths are updated with 
 
 Only what ``Jasper._build_encoder`` can reach is executable (jasper.py:440-449): batch
 normalisation, ReLU, 'add' residual from the block input, conv_mask, dense or separable convs;
-the depthwise half of a separable conv is not built yet and raises at forward time."""
+separable blocks run a depthwise kernel (csrc/dwconv.hip) followed by the 1x1 pointwise implicit GEMM."""
 from __future__ import annotations
 
 from typing import List
@@ -187,18 +187,31 @@ class JasperBlock(nn.Module):
     def units(self, a_in: int, next_act: int, name: str, mask_last_output: bool) -> List[UnitSpec]:
         """engine units of this block; ``a_in`` = index of the block-input activation, ``next_act`` = index the
         first unit's output will get"""
-        if self.separable:
-            raise NotImplementedError('separable JasperBlock: the depthwise convolution kernel is not built yet '
-                                      '(use separable: False blocks, e.g. Jasper 10x5)')
         mods = list(self.mconv)
-        convs = [(mods[i], mods[i + 1]) for i in range(len(mods)) if isinstance(mods[i], MaskedConv1d)]
+        groups = []                       # (depthwise MaskedConv1d or None, conv MaskedConv1d, BatchNorm1d)
+        i = 0
+        while i < len(mods):
+            if isinstance(mods[i], MaskedConv1d):
+                if self.separable:
+                    groups.append((mods[i], mods[i + 1], mods[i + 2]))
+                    i += 3
+                else:
+                    groups.append((None, mods[i], mods[i + 1]))
+                    i += 2
+            else:
+                i += 1
         out = []
         src = a_in
-        for r, (mc, bn) in enumerate(convs):
-            last = r == len(convs) - 1
-            spec = conv_spec(mc.conv, bn, self.padding_val, self.padding_val, PAD_ZERO, f'{name}.mconv{r}')
+        for r, (dwm, mc, bn) in enumerate(groups):
+            last = r == len(groups) - 1
+            if dwm is None:
+                spec = conv_spec(mc.conv, bn, self.padding_val, self.padding_val, PAD_ZERO, f'{name}.mconv{r}')
+                dws = None
+            else:
+                dws = conv_spec(dwm.conv, None, self.padding_val, self.padding_val, PAD_ZERO, f'{name}.dw{r}', depthwise=True)
+                spec = conv_spec(mc.conv, bn, 0, 0, PAD_ZERO, f'{name}.pw{r}')
             u = UnitSpec(main=spec, src=src, act=ACT_RELU, drop_p=float(self.dropout), update_lens=self.conv_mask,
-                         mask_out=self.conv_mask and not (last and not mask_last_output))
+                         mask_out=self.conv_mask and not (last and not mask_last_output), dw=dws)
             if last and self.res is not None:
                 rc, rbn = self.res[0][0], self.res[0][1]
                 u.res = conv_spec(rc.conv, rbn, 0, 0, PAD_ZERO, f'{name}.res')

@@ -91,9 +91,13 @@ class BatchNorm1d(nn.Module):
         raise RuntimeError('BatchNorm1d is executed by the HIP step engine through its parent model')
 
 
-def conv_spec(conv: Conv1d, bn: Optional[BatchNorm1d], pad_l: int, pad_r: int, pad_mode: int, name: str = '') -> ConvSpec:
-    if conv.groups != 1:
-        raise NotImplementedError('grouped / depthwise convolution is not built yet (jasper.py:319-330)')
+def conv_spec(conv: Conv1d, bn: Optional[BatchNorm1d], pad_l: int, pad_r: int, pad_mode: int, name: str = '',
+              depthwise: bool = False) -> ConvSpec:
+    if depthwise:
+        if conv.groups != conv.in_channels or conv.in_channels != conv.out_channels:
+            raise NotImplementedError('only depthwise (groups == channels) grouped convolutions are built')
+    elif conv.groups != 1:
+        raise NotImplementedError('grouped convolution (1 < groups < channels) is not reachable from the config')
     spec = ConvSpec(weight=conv.weight, bias=conv.bias, kernel=conv.kernel_size[0], stride=conv.stride[0],
                     dilation=conv.dilation[0], pad_l=pad_l, pad_r=pad_r, pad_mode=pad_mode, name=name)
     if bn is not None:
