@@ -72,6 +72,7 @@ def main():
     ap.add_argument('--mid-layers', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true')
+    ap.add_argument('--force-dp', action='store_true', help='run the RCCL gradient path even with one rank (plumbing check)')
     ap.add_argument('--breakdown', action='store_true', help='print the per-kernel event timing table to stderr')
     args = ap.parse_args()
 
@@ -80,7 +81,7 @@ def main():
     import torch.distributed as dist
     from oracle.w2l_oracle import synthetic_batch
 
-    rank, world = init_process_group_from_env()
+    rank, world = init_process_group_from_env(force=args.force_dp)
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -88,8 +89,8 @@ def main():
     torch.manual_seed(0)
     model = Wav2Letter(w2l_cfg(args.mid_layers)).to(dev).train()
     broadcast_parameters(model)
-    if world > 1:
-        model.grad_reducer = GradReducer()
+    if world > 1 or args.force_dp:
+        model.grad_reducer = GradReducer(force=args.force_dp)
     opt, _ = model.configure_optimizers()
     opt = opt[0]
     N, T = args.batch, args.frames
@@ -173,13 +174,13 @@ def main():
             'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'Wav2Letter mid_layers={args.mid_layers} (configuration/model/wav2letter.yaml table), '
                                    f'N={N}/GPU x T={T} x 64 mel, dropout on, fwd+CTC+bwd'
-                                   + ('' if args.no_optimizer else '+SGD(nesterov) step'),
+                                   + ('' if args.no_optimizer else '+fused SGD(nesterov) step'),
                        'global_batch': world * N, 'frames': T, 'parallelism': f'dp{world}',
                        'value_is': 'whole-job frames/s (per-GPU = value / n_gpus)', 'loss': round(float(loss.detach()), 4)},
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

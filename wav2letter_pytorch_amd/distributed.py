@@ -23,13 +23,16 @@ import torch.distributed as dist
 SMALL_BYTES = 1 << 20
 
 
-def init_process_group_from_env(backend: Optional[str] = None):
-    """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+def init_process_group_from_env(backend: Optional[str] = None, force: bool = False):
+    """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
+    ``force`` creates a 1-rank group too (used to exercise the RCCL path on a single GPU)."""
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1:
+    if world <= 1 and not force:
         return 0, 1
+    os.environ.setdefault('RANK', '0')
+    os.environ.setdefault('WORLD_SIZE', '1')
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -44,9 +47,10 @@ def init_process_group_from_env(backend: Optional[str] = None):
 class GradReducer:
     """Averages gradients across the ranks of ``group`` as they become ready."""
 
-    def __init__(self, group=None, small_bytes: int = SMALL_BYTES):
+    def __init__(self, group=None, small_bytes: int = SMALL_BYTES, force: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.small_bytes = small_bytes
         self._stream = None
         self._works = []
@@ -67,7 +71,7 @@ class GradReducer:
 
     def on_grad(self, param, grad: torch.Tensor, storage: Optional[torch.Tensor] = None):
         """``grad`` may be a strided view; ``storage`` is the dense buffer it lives in."""
-        if self.world <= 1:
+        if not self.active:
             return
         buf = storage if storage is not None else grad
         if not buf.is_contiguous():
@@ -92,7 +96,7 @@ class GradReducer:
 
     def finish(self):
         """Flush the small gradients, then make the current stream wait for every collective."""
-        if self.world <= 1:
+        if not self.active:
             return
         flat = None
         if self._small:
@@ -100,7 +104,7 @@ class GradReducer:
             self._launch(flat)
         for work, buf, need_div in self._works:
             work.wait()                      # stream-level wait for NCCL works; blocking for gloo
-            if need_div:
+            if need_div and self.world > 1:
                 buf.div_(self.world)
         if flat is not None:
             off = 0
