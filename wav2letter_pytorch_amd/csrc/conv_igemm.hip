@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
 #pragma unroll
         for (int i = 0; i < W_PER_WAVE; ++i) {
             const int grp = wave + i * NWAVES;
-            if (grp < WGROUPS) glds16(slab + w_voff[i], dst + grp * 1024);
+            if ((WGROUPS % NWAVES == 0) || grp < WGROUPS) glds16(slab + w_voff[i], dst + grp * 1024);
         }
     };
     auto stage_x = [&](char* dst, int c) {
@@ -142,21 +142,35 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
         const char* Bb = xb + (tsh << 7);
         const char* B0 = Bb + sw0;
         const char* B1 = Bb + (sw0 ^ 64);            // chunk 4+fq == (chunk fq) ^ 4
+        // both k-substeps' fragments are requested up front (16 ds_read_b128 in flight); the second half lands
+        // while the first half's MFMAs run.  sched_barrier pins that order against the register-pressure scheduler.
+        bf16x8 a0[MS], b0[NS], a1[MS], b1[NS];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[MS], b[NS];
+        for (int mi = 0; mi < MS; ++mi) a0[mi] = *reinterpret_cast<const bf16x8*>(A0 + mi * 16 * ROWB);
 #pragma unroll
-            for (int mi = 0; mi < MS; ++mi)
-                a[mi] = *reinterpret_cast<const bf16x8*>((ks ? A1 : A0) + mi * 16 * ROWB);
+        for (int ni = 0; ni < NS; ++ni) b0[ni] = *reinterpret_cast<const bf16x8*>(B0 + ni * 16 * S * ROWB);
+#pragma unroll
+        for (int mi = 0; mi < MS; ++mi) a1[mi] = *reinterpret_cast<const bf16x8*>(A1 + mi * 16 * ROWB);
+#pragma unroll
+        for (int ni = 0; ni < NS; ++ni) b1[ni] = *reinterpret_cast<const bf16x8*>(B1 + ni * 16 * S * ROWB);
+#pragma unroll
+        for (int mi = 0; mi < MS; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NS; ++ni)
-                b[ni] = *reinterpret_cast<const bf16x8*>((ks ? B1 : B0) + ni * 16 * S * ROWB);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
 #pragma unroll
-            for (int mi = 0; mi < MS; ++mi)
+        for (int mi = 0; mi < MS; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NS; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            for (int ni = 0; ni < NS; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
+        // schedule: ks0 fragment reads, then ks1 reads slotted one per MFMA into the ks0 MFMAs, then the rest
+        __builtin_amdgcn_sched_group_barrier(0x100, MS + NS, 0);
+#pragma unroll
+        for (int i = 0; i < MS + NS; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MS * NS - (MS + NS), 0);
         kw = kw_n;
         c = c_n;
     }

@@ -159,6 +159,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         n_cur = n_n; ts_cur = ts_n;
         const char* ab = par ? abuf1 : abuf0;
         const char* bb = par ? bbuf1 : bbuf0;
+        // one address add per distinct lane constant and step; (ks, h) offsets are ds_read immediates
+        const char* pa[4];
+        const char* pb[KWB][2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pa[i] = ab + a_lane[i];
+#pragma unroll
+            for (int tp = 0; tp < KWB; ++tp)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) pb[tp][h][i] = bb + b_lane[tp][h][i];
+        }
 #pragma unroll
         for (int ks = 0; ks < BT / 32; ++ks) {
             bf16x8 a[4];
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const bf16x4 va = tr_read(ab + a_lane[i] + (ks * 32 + h * 4) * ROWB);
+                    const bf16x4 va = tr_read(pa[i] + (ks * 32 + h * 4) * ROWB);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) a[i][h * 4 + e] = va[e];
                 }
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
                     for (int h = 0; h < 2; ++h)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const bf16x4 vb = tr_read(bb + b_lane[tp][h][i] + ks * 32 * s * ROWB);
+                            const bf16x4 vb = tr_read(pb[tp][h][i] + ks * 32 * s * ROWB);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) b[i][h * 4 + e] = vb[e];
                         }
