@@ -73,6 +73,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true')
     ap.add_argument('--force-dp', action='store_true', help='run the RCCL gradient path even with one rank (plumbing check)')
+    ap.add_argument('--serial-wgrad', action='store_true', help='keep weight gradients on the main stream (clean per-kernel durations for profiling)')
     ap.add_argument('--breakdown', action='store_true', help='print the per-kernel event timing table to stderr')
     args = ap.parse_args()
 
@@ -91,6 +92,8 @@ def main():
     broadcast_parameters(model)
     if world > 1 or args.force_dp:
         model.grad_reducer = GradReducer(force=args.force_dp)
+    if args.serial_wgrad:
+        model._overlap_wgrad = False
     opt, _ = model.configure_optimizers()
     opt = opt[0]
     N, T = args.batch, args.frames
@@ -137,7 +140,7 @@ def main():
         for _ in range(3):
             step()
         torch.cuda.synchronize()
-        model._overlap_wgrad = True
+        model._overlap_wgrad = not args.serial_wgrad
         agg = {}
         for name, flops, s, e in E.KERNEL_TIMER:
             a = agg.setdefault(name, [0.0, 0.0, 0])

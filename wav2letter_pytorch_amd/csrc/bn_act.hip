@@ -219,7 +219,7 @@ __device__ __forceinline__ void bwd_row(const w2l_bnact_t& d, const Chan& c1, co
     }
 }
 
-constexpr int BWD_ROWS_PER_BLOCK = 32;   // 500 blocks at N*T = 16000
+constexpr int BWD_ROWS_PER_BLOCK = 16;   // 1000 blocks at N*T = 16000
 
 // partial[blk][ncomp][C]: sum g, sum g*xh1 [, sum g, sum g*xh2 when there is a residual branch].
 // A thread owns one channel group for the whole block: per-channel constants live in registers.
@@ -277,14 +277,24 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(w2l_bnact_t d, w
     }
 }
 
-// column sums of partial[nblocks][ncols]: 32 columns x 8 row-lanes per block, coalesced 128-byte rows
+// column sums of partial[nblocks][ncols]: 32 columns x 8 row-lanes per block, coalesced 128-byte rows,
+// 8 independent loads in flight per lane (the kernel is a latency chain otherwise: ~60 dependent L2 reads)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int nblocks, int ncols, float* sums) {
     __shared__ float red[8][33];
     const int cx = threadIdx.x & 31, ly = threadIdx.x >> 5;
     const int col = blockIdx.x * 32 + cx;
     float s = 0.f;
-    if (col < ncols)
-        for (int b = ly; b < nblocks; b += 8) s += partial[(int64_t)b * ncols + col];
+    if (col < ncols) {
+        int b = ly;
+        float a[8];
+        for (; b + 56 < nblocks; b += 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = partial[(int64_t)(b + 8 * u) * ncols + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += a[u];
+        }
+        for (; b < nblocks; b += 8) s += partial[(int64_t)b * ncols + col];
+    }
     red[ly][cx] = s;
     __syncthreads();
     if (ly == 0 && col < ncols) {
