@@ -37,6 +37,23 @@ def w2l_cfg(mid_layers, dropout=True):
                        scheduler=dict(_target_='torch.optim.lr_scheduler.ExponentialLR', gamma=0.999)))
 
 
+def jasper10x5_cfg():
+    """Jasper 10x5 (BASELINE config 4) through the reference's own jasper_blocks keys: 13 dense blocks, 322 M params"""
+    from oracle.w2l_oracle import ENGLISH_LOWERCASE
+    from wav2letter_pytorch_amd.config import to_cfg
+    labels = ENGLISH_LOWERCASE
+    blocks = [dict(layer_size=256, kernel_size=11, stride=2, residual=False, separable=False, repeat=1)]
+    for c, k in ((256, 11), (384, 13), (512, 17), (640, 21), (768, 25)):
+        blocks += [dict(layer_size=c, kernel_size=k, stride=1, residual=True, separable=False, repeat=5)] * 2
+    blocks += [dict(layer_size=896, kernel_size=29, stride=1, dilation=2, residual=False, separable=False, repeat=1),
+               dict(layer_size=1024, kernel_size=1, stride=1, residual=False, separable=False, repeat=1)]
+    return to_cfg(dict(name='jasper', mid_layers=len(blocks), jasper_blocks=blocks, input_size=64, labels=labels, precision='bf16',
+                       audio_conf=dict(window='hamming', window_stride=0.01, window_size=0.02, sample_rate=16000),
+                       decoder=dict(_target_='decoder.GreedyDecoder', labels=labels),
+                       optimizer=dict(_target_='torch.optim.SGD', lr=1e-5, momentum=0.9, nesterov=True, weight_decay=1e-5),
+                       scheduler=dict(_target_='torch.optim.lr_scheduler.ExponentialLR', gamma=0.999)))
+
+
 def cpu_baseline(budget_s=20.0):
     """the oracle's training step (fp32, torch CPU ops = what the reference executes) on a bounded
     sample of the same workload: W2L mid_layers=20, N=2, T=1000."""
@@ -70,6 +87,8 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--frames', type=int, default=1000)
     ap.add_argument('--mid-layers', type=int, default=20)
+    ap.add_argument('--model', default='wav2letter', choices=['wav2letter', 'jasper10x5'],
+                    help='wav2letter = the headline workload; jasper10x5 = BASELINE config 4 (secondary)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true')
     ap.add_argument('--force-dp', action='store_true', help='run the RCCL gradient path even with one rank (plumbing check)')
@@ -77,7 +96,7 @@ def main():
     ap.add_argument('--breakdown', action='store_true', help='print the per-kernel event timing table to stderr')
     args = ap.parse_args()
 
-    from wav2letter_pytorch_amd import Wav2Letter, engine as E
+    from wav2letter_pytorch_amd import Jasper, Wav2Letter, engine as E
     from wav2letter_pytorch_amd.distributed import GradReducer, broadcast_parameters, init_process_group_from_env
     import torch.distributed as dist
     from oracle.w2l_oracle import synthetic_batch
@@ -88,7 +107,11 @@ def main():
     dev = torch.device('cuda', local)
 
     torch.manual_seed(0)
-    model = Wav2Letter(w2l_cfg(args.mid_layers)).to(dev).train()
+    if args.model == 'jasper10x5':
+        model = Jasper(jasper10x5_cfg()).to(dev).train()
+        model.check_nan = False              # the reference's per-step NaN assert is a host sync
+    else:
+        model = Wav2Letter(w2l_cfg(args.mid_layers)).to(dev).train()
     broadcast_parameters(model)
     if world > 1 or args.force_dp:
         model.grad_reducer = GradReducer(force=args.force_dp)
@@ -102,9 +125,11 @@ def main():
     tg_d, tl_d = tg.to(dev), tl.to(dev)
     ol = model.compute_output_lengths(il).to(dev)
 
+    il_d = il.to(dev)
+
     def step():
         opt.zero_grad(set_to_none=True)
-        out, _ = model(x, None)
+        out, _ = model(x, il_d if args.model == 'jasper10x5' else None)
         loss = model.criterion(out.transpose(0, 1), tg_d, ol, tl_d)
         loss.backward()
         if not args.no_optimizer:
@@ -168,14 +193,17 @@ def main():
 
     if rank == 0:
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == 'wav2letter':
             cpu = cpu_baseline()
         line = {
-            'metric': 'audio-frames/sec/GPU (fwd+bwd+CTC), Wav2Letter 64-mel x 1000-frame bf16',
+            'metric': ('audio-frames/sec/GPU (fwd+bwd+CTC), Wav2Letter 64-mel x 1000-frame bf16' if args.model == 'wav2letter'
+                       else 'audio-frames/sec/GPU (fwd+bwd+CTC), Jasper 10x5 bf16 (secondary workload)'),
             'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': f'Wav2Letter mid_layers={args.mid_layers} (configuration/model/wav2letter.yaml table), '
+            'config': {'workload': ('Jasper 10x5 (13 dense blocks, repeat 5, 322 M params), ' if args.model == 'jasper10x5' else '')
+                                   + f'Wav2Letter mid_layers={args.mid_layers} (configuration/model/wav2letter.yaml table), ' * (args.model == 'wav2letter')
+                                   +
                                    f'N={N}/GPU x T={T} x 64 mel, dropout on, fwd+CTC+bwd'
                                    + ('' if args.no_optimizer else '+fused SGD(nesterov) step'),
                        'global_batch': world * N, 'frames': T, 'parallelism': f'dp{world}',

@@ -238,3 +238,31 @@ def test_jasper_separable_golden(precision):
     check(errs, stats, precision)
     np.testing.assert_array_equal(out_lens.numpy(), z['out_lens'])
     assert scale_err(out.cpu().numpy(), z['log_probs']) < TOL[precision]['lp']
+
+
+def test_trainer_fit_loop_and_checkpoint(tmp_path):
+    """training_step / validation_step / configure_optimizers through the minimal Trainer (train.py:34-37 flow):
+    loss decreases on a fixed batch, metrics carry the reference's log keys, the checkpoint reloads"""
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd.trainer import Trainer
+    layers = [(128, 11, 2, 1, 0.0), (128, 11, 1, 1, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=21)
+    model = build_w2l(layers, sd, 'bf16')
+    model._cfg.optimizer.lr = 0.05
+    x, il, tg, tl = O.synthetic_batch(4, 200, seed=22, s_lo=5, s_hi=12)
+    texts = tuple(''.join(O.ENGLISH_LOWERCASE[int(i)] for i in tg[n, :int(tl[n])]) for n in range(4))
+    batch = (x, il, tg, tl, ('a', 'b', 'c', 'd'), texts)
+    tr = Trainer(default_root_dir=str(tmp_path), max_epochs=2, log_every_n_steps=1)
+    tr.fit(model, [batch] * 6, [batch])
+    losses = [l['train_loss'] for _, l in tr.logged]
+    assert losses[-1] < losses[0]
+    keys = set(tr.logged[-1][1])
+    assert {'train_loss', 'learning_rate', 'train_cer', 'train_wer', 'train_len_ratio'} <= keys
+    assert {'val_loss', 'val_cer', 'val_wer', 'val_len_ratio'} <= set(model._logged)
+    ck = sorted(os.listdir(tmp_path))
+    assert len(ck) == 2 and ck[0].endswith('.ckpt')
+    state = torch.load(os.path.join(tmp_path, ck[-1]))['state_dict']
+    m2 = build_w2l(layers, sd, 'bf16')
+    m2.load_state_dict(state)
+    for (k, a), (_, b) in zip(model.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a.cpu(), b.cpu()), k
