@@ -83,14 +83,14 @@ def main():
 
         if args.sweep:
             res = []
-            for ci in range(10):
+            for ci in range(17):
                 L.lib.w2l_conv_force_tile_config(ci)
                 try:
                     a = timeit(fwd, args.reps)
                     b = timeit(dgrad, args.reps) if s == 1 else float('nan')
                 except Exception as ex:      # config does not fit LDS
                     a = b = float('nan')
-                res.append(f'cfg{ci}: fwd {flops / a / 1e9:5.0f} dgr {flops / b / 1e9:5.0f}')
+                res.append(f'{ci}:{flops / a / 1e9:5.0f}/{flops / b / 1e9:5.0f}')
             L.lib.w2l_conv_force_tile_config(-1)
             print('      ' + ' | '.join(res))
         tf = timeit(fwd, args.reps)

@@ -210,6 +210,10 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
         }
     }
     if (p.stats) {
+        // statistics rows are laid out per 128-column tile (w2l_conv_stat_tiles); a 256-column block owns two
+        constexpr int HALVES = BN / 128;
+        constexpr int WPH = NW / HALVES;               // N-waves per 128-column half
+        static_assert(BN % 128 == 0 || true, "");
         __syncthreads();                               // main-loop LDS is dead from here
         float* red = reinterpret_cast<float*>(smem);   // [NW][2][BM]
 #pragma unroll
@@ -229,12 +233,18 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
                 }
             }
         __syncthreads();
-        for (int cl = tid; cl < BM; cl += NT) {
-            if (m0 + cl < Cout) {
+        const int tiles128 = (Tout + 127) / 128;
+        for (int idx = tid; idx < BM * HALVES; idx += NT) {
+            const int h = idx / BM, cl = idx - h * BM;
+            const int trow = tt * HALVES + h;          // 128-column tile index inside the utterance
+            if (m0 + cl < Cout && trow < tiles128) {
                 float a = 0.f, b = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) { a += red[(w * 2 + 0) * BM + cl]; b += red[(w * 2 + 1) * BM + cl]; }
-                float* dst = p.stats + (int64_t)col * 2 * Cout;
+                for (int w = 0; w < WPH; ++w) {
+                    a += red[((h * WPH + w) * 2 + 0) * BM + cl];
+                    b += red[((h * WPH + w) * 2 + 1) * BM + cl];
+                }
+                float* dst = p.stats + ((int64_t)n * tiles128 + trow) * 2 * Cout;
                 dst[m0 + cl] = a;
                 dst[Cout + m0 + cl] = b;
             }
@@ -246,9 +256,11 @@ struct TileCfg { int mw, nw, ms, ns; float eff; };
 // candidate block shapes (BM = 16*mw*ms output channels x BN = 16*nw*ns time rows) with their measured
 // relative MFMA efficiency at full occupancy (tools/bench_conv.py --sweep, MI355X)
 constexpr TileCfg kCfgs[] = {
-    {2, 2, 2, 4, 0.80f}, {2, 2, 3, 4, 0.92f}, {2, 2, 4, 4, 0.94f}, {2, 2, 5, 4, 1.00f},   // BN 128, 4 waves
-    {4, 2, 3, 4, 0.84f}, {4, 2, 4, 4, 0.88f},                                               // BN 128, 8 waves
-    {2, 3, 2, 3, 0.78f}, {2, 3, 3, 3, 0.90f}, {2, 3, 4, 3, 0.93f}, {2, 3, 5, 3, 0.97f},   // BN 144, 6 waves
+    {2, 2, 2, 4, 0.83f}, {2, 2, 3, 4, 1.00f}, {2, 2, 4, 4, 1.00f}, {2, 2, 5, 4, 1.01f},   // BN 128, 4 waves
+    {4, 2, 3, 4, 0.90f}, {4, 2, 4, 4, 0.92f},                                               // BN 128, 8 waves
+    {2, 3, 2, 3, 0.80f}, {2, 3, 3, 3, 0.97f}, {2, 3, 4, 3, 0.97f}, {2, 3, 5, 3, 0.98f},   // BN 144, 6 waves
+    {2, 4, 2, 4, 0.85f}, {2, 4, 3, 4, 0.97f}, {2, 4, 4, 4, 1.00f}, {2, 4, 5, 4, 1.04f},   // BN 256, 8 waves, 1 block/CU
+    {2, 4, 6, 4, 1.10f}, {2, 4, 7, 4, 1.06f}, {2, 4, 8, 4, 1.12f},
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -290,7 +302,7 @@ static int choose_cfg(int N, int Cout, int Tout, int Kw, int stride, int dil, bo
     for (int i = 0; i < kNumCfgs; ++i) {
         const TileCfg& c = kCfgs[i];
         const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
-        if (need_bn128 && bn != 128) continue;
+        if (need_bn128 && bn % 128 != 0) continue;     // BatchNorm partial statistics are per 128-column tile
         if (stride != 1 && i != 2) continue;          // strided convs (first layer only) use the 128x128 shape
         if (g_force_cfg >= 0 && g_force_cfg < kNumCfgs && i != g_force_cfg) continue;
         const size_t lds = 2 * (size_t)bm * ROWB + 2 * (size_t)cfg_xrows(c, stride, Kw, dil) * ROWB;
@@ -359,6 +371,13 @@ extern "C" int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_row
         case 6: return launch_cfg<2, 3, 2, 3>(p, tiles_m, lds, st);
         case 7: return launch_cfg<2, 3, 3, 3>(p, tiles_m, lds, st);
         case 8: return launch_cfg<2, 3, 4, 3>(p, tiles_m, lds, st);
-        default: return launch_cfg<2, 3, 5, 3>(p, tiles_m, lds, st);
+        case 9: return launch_cfg<2, 3, 5, 3>(p, tiles_m, lds, st);
+        case 10: return launch_cfg<2, 4, 2, 4>(p, tiles_m, lds, st);
+        case 11: return launch_cfg<2, 4, 3, 4>(p, tiles_m, lds, st);
+        case 12: return launch_cfg<2, 4, 4, 4>(p, tiles_m, lds, st);
+        case 13: return launch_cfg<2, 4, 5, 4>(p, tiles_m, lds, st);
+        case 14: return launch_cfg<2, 4, 6, 4>(p, tiles_m, lds, st);
+        case 15: return launch_cfg<2, 4, 7, 4>(p, tiles_m, lds, st);
+        default: return launch_cfg<2, 4, 8, 4>(p, tiles_m, lds, st);
     }
 }
