@@ -266,3 +266,28 @@ def test_trainer_fit_loop_and_checkpoint(tmp_path):
     m2.load_state_dict(state)
     for (k, a), (_, b) in zip(model.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a.cpu(), b.cpu()), k
+
+
+@pytest.mark.parametrize('case', ['w2l_ml3', 'w2l_mix5', 'jasper_dense', 'jasper_sep2'])
+def test_input_gradient_golden(case):
+    """d loss / d spectrogram (cold path: zero-stuffed strided data gradient + reflect fold) vs the fixture's
+    input_grad; compared on the L2 norm because activation-gate ties perturb single elements"""
+    z = load(case + '.npz')
+    meta = ast.literal_eval(str(z['meta']))
+    sd = {k[3:]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith('p0/')}
+    if case.startswith('jasper'):
+        from gpu_helpers import build_jasper
+        model = build_jasper(meta['blocks'], sd, 'fp32').train()
+    else:
+        layers = [(l['output_size'], l['kernel_size'], l['stride'], l['dilation'], 0.0) for l in meta['layers']]
+        model = build_w2l(layers, sd, 'fp32').train()
+    x = torch.from_numpy(z['x']).cuda().requires_grad_(True)
+    il, tg, tl = (torch.from_numpy(z[k]) for k in ('in_lens', 'targets', 'target_lens'))
+    out, ol = model(x, il)
+    model.criterion(out.transpose(0, 1), tg, ol, tl).backward()
+    ref = z['input_grad']
+    got = x.grad.cpu().numpy()
+    assert got.shape == ref.shape
+    rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    assert rel < 2e-2, rel
+    assert np.mean(np.abs(got - ref) > 1e-3 * np.abs(ref).max()) < 0.05

@@ -289,7 +289,8 @@ class StackEngine:
                 mode = c.pad_mode
         return pl, pr, mode
 
-    def forward(self, x: torch.Tensor, lens: Optional[torch.Tensor], training: bool, softmax_mode: int = 0):
+    def forward(self, x: torch.Tensor, lens: Optional[torch.Tensor], training: bool, softmax_mode: int = 0,
+                want_input_grad: bool = False):
         """x fp32 [N, C, T] on device -> (out fp32 [N, T', n_labels], lens_out or None)."""
         _lib.require_device(x)
         global _dropout_calls
@@ -298,7 +299,7 @@ class StackEngine:
         x = x.contiguous().float()
         dev = x.device
         st = stream_ptr
-        ctx = {'units': [], 'acts': [], 'training': training, 'x_shape': (N, C0, T0)}
+        ctx = {'units': [], 'acts': [], 'training': training, 'x_shape': (N, C0, T0), 'want_dx': bool(want_input_grad)}
         lens_dev = None
         if lens is not None and any(u.update_lens or u.mask_out for u in self.units):
             lens_dev = lens.to(device=dev, dtype=torch.int32)
@@ -441,13 +442,20 @@ class StackEngine:
         self._set(grads, dwc.weight, gw if cp == c else gw[:c], storage=dwg)
         if not need_dx:
             return None
-        if dwc.stride != 1:
-            raise NotImplementedError('data gradient of a strided depthwise convolution')
         Tp = src.T + dwc.pad_l + dwc.pad_r
+        tmid, lens_mid = mid.T, mid.lens
+        if dwc.stride != 1:                # cold path (spectrogram gradient only): zero-stuff to stride 1
+            s_ = dwc.stride
+            tup = (mid.T - 1) * s_ + 1
+            up = torch.zeros(N, tup, cp, dtype=g.dtype, device=dev)
+            up[:, 0:tup:s_] = g.view(N, per, cp)[:, :mid.T]
+            g, per, tmid = up, tup, tup
+            if lens_mid is not None:
+                lens_mid = ((lens_mid - 1) * s_ + 1).clamp(min=0).to(torch.int32)
         dxp = torch.empty(N, Tp, cp, dtype=torch.float32 if self.precise else torch.bfloat16, device=dev)
         w = self._dw_weight(dwc, cp)
         check(lib.w2l_dwconv_dgrad(ptr(g), int(g.dtype == torch.float32), per, ptr(w), ptr(dxp),
-                                   int(dxp.dtype == torch.float32), N, Tp, mid.T, cp, k, dwc.dilation, ptr(mid.lens),
+                                   int(dxp.dtype == torch.float32), N, Tp, tmid, cp, k, dwc.dilation, ptr(lens_mid),
                                    stream_ptr()), 'w2l_dwconv_dgrad')
         return (dxp, dwc.pad_l, dwc.pad_r, dwc.pad_mode, Tp)
 
@@ -556,7 +564,7 @@ class StackEngine:
                 check(lib.w2l_bn_bwd_finalize(ptr(partial), nb, coutp, ncomp, ptr(sums), st()), 'w2l_bn_bwd_finalize')
                 uc.keep.append((partial, sums))
             main, res = u.main, u.res
-            need_dx_main = self._needs_grad(u.src)
+            need_dx_main = self._needs_grad(u.src, ctx)
             tail = roundup(Tout, 64) - Tout              # wgrad walks each utterance in 64-row steps over zero rows
             h1 = max((main.kernel - 1) * main.dilation, tail)
             dy_hi = torch.empty(h1 + N * (Tout + h1), coutp, dtype=torch.bfloat16, device=dev)
@@ -602,8 +610,9 @@ class StackEngine:
                 self._wgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc, grads)
                 if res.bias is not None:
                     self._set(grads, res.bias, torch.zeros(res.cout, dtype=torch.float32, device=dev))
-                if self._needs_grad(u.res_src):
+                if self._needs_grad(u.res_src, ctx):
                     act_grads[u.res_src].append(self._dgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc))
+        ctx['input_grad'] = self.input_grad(ctx, act_grads[0]) if ctx.get('want_dx') and act_grads[0] else None
         if getattr(self, '_side_used', False):
             main = torch.cuda.current_stream(dev)
             main.wait_stream(self._side)
@@ -616,8 +625,29 @@ class StackEngine:
         return [grads.get(id(p)) for p in self.parameters()]
 
     # ------------------------------------------------------------------ helpers
-    def _needs_grad(self, act_index: int) -> bool:
-        return act_index != 0          # the spectrogram needs no gradient in training (base_asr_models.py:78-85)
+    def _needs_grad(self, act_index: int, ctx=None) -> bool:
+        # the spectrogram needs no gradient in training (base_asr_models.py:78-85); computed only on request
+        return act_index != 0 or bool(ctx and ctx.get('want_dx'))
+
+    def input_grad(self, ctx, srcs) -> torch.Tensor:
+        """gradient wrt the fp32 [N, C, T] spectrogram from the padded-coordinate gradient(s) of activation 0
+        (cold path, torch ops: fold the reflected halo rows back, un-pad, back to channels-first)"""
+        N, C0, T0 = ctx['x_shape']
+        a0 = ctx['acts'][0]
+        total = None
+        for (g, pl, pr, mode, per) in srcs:
+            gv = g.view(N, per, a0.CP)[:, :pl + T0 + pr, :C0].float()
+            core = gv[:, pl:pl + T0].clone()
+            if mode == PAD_REFLECT:
+                if pl:
+                    core[:, 1:pl + 1] += gv[:, :pl].flip(1)
+                if pr:
+                    core[:, T0 - 1 - pr:T0 - 1] += gv[:, pl + T0:pl + T0 + pr].flip(1)
+            total = core if total is None else total + core
+        if a0.lens is not None:          # masked_fill on the input (jasper.py:116-119)
+            t = torch.arange(T0, device=total.device)[None, :, None]
+            total = total * (t < a0.lens.long()[:, None, None])
+        return total.transpose(1, 2).contiguous()
 
     def _notify(self, param, grad, storage=None):
         if self.grad_ready is not None:
@@ -691,13 +721,25 @@ class StackEngine:
         """dXpad (gradient wrt the conv's padded input) through the same implicit-GEMM kernel, run over
         the shared-halo dy buffer as ONE sequence of N*(Tout+halo) rows: tiles never straddle a partially
         filled per-utterance remainder.  Row v of utterance n lands at output row n*(Tout+halo) + v."""
-        if conv.stride != 1:
-            raise NotImplementedError('data gradient of a strided convolution (only the first layer is strided, '
-                                      'and the spectrogram needs no gradient)')
         N = src.N
         Tp = src.T + conv.pad_l + conv.pad_r
         hb = (conv.kernel - 1) * conv.dilation
-        assert Tp == Tout + hb and halo >= hb
+        if conv.stride != 1:
+            # cold path (only the spectrogram's gradient needs it): dy is zero-stuffed to stride 1 -- dy_up[t*s] = dy[t]
+            # -- and the stride-1 data gradient runs on that; rows past (Tout-1)*s + hb of the padded input get none
+            s_ = conv.stride
+            Tup = (Tout - 1) * s_ + 1
+            hup = max(hb, roundup(Tup, 64) - Tup)
+
+            def stuff(t):
+                if t is None:
+                    return None
+                up = torch.zeros(hup + N * (Tup + hup), pk.coutp, dtype=t.dtype, device=t.device)
+                up[hup:].view(N, Tup + hup, pk.coutp)[:, 0:Tup:s_] = t[halo:].view(N, Tout + halo, pk.coutp)[:, :Tout]
+                return up
+
+            dy_hi, dy_lo, halo, Tout = stuff(dy_hi), stuff(dy_lo), hup, Tup
+        assert Tout + hb <= Tp and halo >= hb
         dev = dy_hi.device
         per = Tout + halo
         flat_rows = N * per
@@ -706,4 +748,8 @@ class StackEngine:
         dyact = Act(dy_hi, dy_lo, 1, total, pk.coutp, pk.coutp, 0, 0, PAD_ZERO)
         _igemm(dyact, halo - hb, pk.dgr_hi, pk.dgr_lo, dxp, None, None, pk.coutp, pk.cinp, flat_rows, conv.kernel, 1,
                conv.dilation, self.precise, alg_flops=2.0 * N * Tout * conv.cout * conv.cin * conv.kernel)
+        if per < Tp:                      # strided case: the last (Tp - Tup - hb) padded rows receive no gradient
+            full = torch.zeros(N, Tp, pk.cinp, dtype=dxp.dtype, device=dev)
+            full[:, :per] = dxp.view(N, per, pk.cinp)
+            return (full, conv.pad_l, conv.pad_r, conv.pad_mode, Tp)
         return (dxp, conv.pad_l, conv.pad_r, conv.pad_mode, per)

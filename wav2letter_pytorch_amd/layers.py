@@ -113,10 +113,8 @@ class _StackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, engine: StackEngine, lens, training: bool, softmax_mode: int, holder: dict, *params):
-        if x.requires_grad:
-            raise NotImplementedError('gradient wrt the input spectrogram is not implemented '
-                                      '(the first conv is strided; training does not need it)')
-        out, ectx = engine.forward(x, lens, training, softmax_mode)
+        want_dx = bool(x.requires_grad)
+        out, ectx = engine.forward(x, lens, training, softmax_mode, want_input_grad=want_dx)
         ctx.engine, ctx.ectx = engine, ectx
         if holder.get('keep_ctx'):
             holder['ctx'] = ectx
@@ -126,8 +124,9 @@ class _StackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         grads = ctx.engine.backward(ctx.ectx, g)
+        dx = ctx.ectx.get('input_grad')
         ctx.ectx = None
-        return (None, None, None, None, None, None, *grads)
+        return (dx, None, None, None, None, None, *grads)
 
 
 def run_stack(engine: StackEngine, x, lens, training: bool, softmax_mode: int = 0, keep_ctx: bool = False):
