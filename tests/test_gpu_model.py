@@ -291,3 +291,36 @@ def test_input_gradient_golden(case):
     rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
     assert rel < 2e-2, rel
     assert np.mean(np.abs(got - ref) > 1e-3 * np.abs(ref).max()) < 0.05
+
+
+@pytest.mark.parametrize('N,T', [(1, 57), (5, 129), (2, 64)])
+def test_w2l_edge_shapes_fp32(N, T):
+    """batch of one, odd / tiny utterance lengths (Tout < one 64-row wgrad step, partial 128-row tiles), ragged"""
+    layers = [(64, 11, 2, 1, 0.0), (96, 13, 1, 1, 0.0), (64, 7, 1, 2, 0.0)]
+    _synthetic_case(layers, N=N, T=T, precision='fp32', seed=30 + N, ragged=N > 1)
+
+
+def test_reflect_pad_longer_than_sequence_raises():
+    """ReflectionPad1d needs pad < T (torch raises in the reference too): T'=10 after stride 2, pad 12"""
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd._lib import W2LError
+    layers = [(64, 11, 2, 1, 0.0), (64, 13, 1, 2, 0.0)]
+    model = build_w2l(layers, O.init_wav2letter_state(layers, seed=1), 'fp32').train()
+    with pytest.raises(W2LError):
+        model(torch.randn(2, 64, 20).cuda(), torch.tensor([20, 20]))
+
+
+def test_infeasible_and_empty_targets_end_to_end():
+    """zero_infinity through the whole step: an utterance whose target cannot be aligned contributes 0 loss and
+    0 gradient; an empty target is legal (base_asr_models.py:23)"""
+    from oracle import w2l_oracle as O
+    layers = [(64, 11, 2, 1, 0.0), (64, 11, 1, 1, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=40)
+    model = build_w2l(layers, sd, 'fp32').train()
+    x, il, tg, tl = O.synthetic_batch(3, 80, seed=41, s_lo=5, s_hi=10)
+    tg = torch.cat([tg, torch.randint(1, 29, (3, 60), dtype=torch.int32)], 1)
+    tl = torch.tensor([70, 0, int(tl[2])], dtype=torch.int32)          # 70 labels cannot fit 40 frames; empty target
+    tg[1] = 0
+    errs, stats, out, out_lens, ref = compare_step(model, layers, sd, x, il, tg, tl, 'fp32')
+    check(errs, stats, 'fp32')
+    assert float(ref['loss']) > 0
