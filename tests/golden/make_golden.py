@@ -303,5 +303,35 @@ def main():
     print('greedy_cases.npz', strings, small)
 
 
+def novograd_fixture():
+    """4 steps of the reference Novograd (novograd.py:52-114) on two small tensors, both amsgrad settings"""
+    _install_stubs()
+    from novograd import Novograd
+    out = {}
+    for tag, kw in dict(plain=dict(lr=0.01, betas=(0.95, 0.5), weight_decay=1e-3, grad_averaging=True),
+                        ams=dict(lr=0.02, betas=(0.9, 0.25), weight_decay=0.0, grad_averaging=False, amsgrad=True)).items():
+        g = torch.Generator().manual_seed(7)
+        ps = [torch.nn.Parameter(torch.randn(4, 3, generator=g)), torch.nn.Parameter(torch.randn(5, generator=g))]
+        out[f'{tag}/p0_0'], out[f'{tag}/p0_1'] = ps[0].detach().numpy().copy(), ps[1].detach().numpy().copy()
+        opt = Novograd(ps, **kw)
+        grads = []
+        for it in range(4):
+            gs = [torch.randn(4, 3, generator=g) * (it + 1), torch.randn(5, generator=g)]
+            grads.append([x.numpy().copy() for x in gs])
+            for q, x in zip(ps, gs):
+                q.grad = x.clone()
+            opt.step()
+        out[f'{tag}/grads0'] = np.stack([x[0] for x in grads])
+        out[f'{tag}/grads1'] = np.stack([x[1] for x in grads])
+        out[f'{tag}/p4_0'], out[f'{tag}/p4_1'] = ps[0].detach().numpy().copy(), ps[1].detach().numpy().copy()
+        out[f'{tag}/v_0'] = opt.state[ps[0]]['exp_avg_sq'].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'novograd_cases.npz'), **out)
+    print('novograd_cases.npz', out['plain/p4_1'])
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'novograd':
+        novograd_fixture()
+    else:
+        main()
+        novograd_fixture()

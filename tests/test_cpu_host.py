@@ -230,3 +230,22 @@ def test_grad_reducer_gloo_world2():
     assert torch.allclose(big0, (exp[0] + exp[1]) / 2, atol=1e-6)
     for a, b in zip(s0, s1):
         assert torch.equal(a, b)
+
+
+def test_novograd_matches_reference_fixture():
+    """4 steps against tests/golden/novograd_cases.npz (generated from the reference's novograd.py)"""
+    from wav2letter_pytorch_amd.novograd import Novograd
+    z = np.load(os.path.join(GOLD, 'novograd_cases.npz'))
+    for tag, kw in dict(plain=dict(lr=0.01, betas=(0.95, 0.5), weight_decay=1e-3, grad_averaging=True),
+                        ams=dict(lr=0.02, betas=(0.9, 0.25), weight_decay=0.0, grad_averaging=False, amsgrad=True)).items():
+        ps = [torch.nn.Parameter(torch.from_numpy(z[f'{tag}/p0_0'].copy())), torch.nn.Parameter(torch.from_numpy(z[f'{tag}/p0_1'].copy()))]
+        opt = Novograd(ps, **kw)
+        for it in range(4):
+            ps[0].grad = torch.from_numpy(z[f'{tag}/grads0'][it].copy())
+            ps[1].grad = torch.from_numpy(z[f'{tag}/grads1'][it].copy())
+            opt.step()
+        np.testing.assert_allclose(ps[0].detach().numpy(), z[f'{tag}/p4_0'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(ps[1].detach().numpy(), z[f'{tag}/p4_1'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(opt.state[ps[0]]['exp_avg_sq'].numpy(), z[f'{tag}/v_0'], rtol=1e-5)
+    with pytest.raises(ValueError):
+        Novograd(ps, betas=(1.0, 0))
