@@ -80,6 +80,14 @@ int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_rows_total, co
                      int accumulate, const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout,
                      int Kw, int stride, int dil, void* stream);
 
+/* Autotune: time every feasible block shape for this exact problem on the caller's device (HIP events on
+ * `stream`, SYNCHRONISING) and remember the fastest for later w2l_conv1d_igemm calls of the same shape.
+ * Call once per shape during warm-up; no-op when already tuned.  The output is written like a normal
+ * accumulate=0 launch. */
+int w2l_conv1d_igemm_tune(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y, int y_f32,
+                          const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout, int Kw, int stride,
+                          int dil, int reps, void* stream);
+
 /* tuning hook: force block-shape candidate idx (>= 0) for every later w2l_conv1d_igemm call; -1 = automatic */
 void w2l_conv_force_tile_config(int idx);
 

@@ -83,13 +83,16 @@ def main():
 
         if args.sweep:
             res = []
-            for ci in range(17):
+            for ci in range(21):
                 L.lib.w2l_conv_force_tile_config(ci)
                 try:
                     a = timeit(fwd, args.reps)
+                except Exception:            # config not allowed with statistics / does not fit LDS
+                    a = float('nan')
+                try:
                     b = timeit(dgrad, args.reps) if s == 1 else float('nan')
-                except Exception as ex:      # config does not fit LDS
-                    a = b = float('nan')
+                except Exception:
+                    b = float('nan')
                 res.append(f'{ci}:{flops / a / 1e9:5.0f}/{flops / b / 1e9:5.0f}')
             L.lib.w2l_conv_force_tile_config(-1)
             print('      ' + ' | '.join(res))

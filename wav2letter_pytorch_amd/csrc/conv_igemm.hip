@@ -16,6 +16,9 @@
 // its autograd data gradient.  Padding is physical: the producer kernel writes the
 // reflect (wav2letter.py:28-34) or zero halo, so the hot loop has no padding logic.
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <tuple>
 
 namespace {
 
@@ -261,6 +264,7 @@ constexpr TileCfg kCfgs[] = {
     {2, 3, 2, 3, 0.80f}, {2, 3, 3, 3, 0.97f}, {2, 3, 4, 3, 0.97f}, {2, 3, 5, 3, 0.98f},   // BN 144, 6 waves
     {2, 4, 2, 4, 0.85f}, {2, 4, 3, 4, 0.97f}, {2, 4, 4, 4, 1.00f}, {2, 4, 5, 4, 1.04f},   // BN 256, 8 waves, 1 block/CU
     {2, 4, 6, 4, 1.10f}, {2, 4, 7, 4, 1.06f}, {2, 4, 8, 4, 1.12f},
+    {2, 3, 4, 6, 1.00f}, {2, 3, 5, 6, 1.00f}, {2, 3, 6, 6, 1.00f}, {2, 3, 7, 6, 1.00f},   // BN 288, 6 waves, 1 block/CU
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -295,8 +299,29 @@ static inline int cfg_xrows(const TileCfg& c, int stride, int Kw, int dil) {
     return ((bn - 1) * stride + (Kw - 1) * dil + 1 + 7) & ~7;
 }
 
-// pick the block shape: whole rounds of resident blocks on the 256 CUs, larger tiles preferred
-static int choose_cfg(int N, int Cout, int Tout, int Kw, int stride, int dil, bool need_bn128) {
+// measured choices (w2l_conv1d_igemm_tune): shape -> block-shape index
+typedef std::tuple<int, int, int, int, int, int, int, int> ShapeKey;
+static std::map<ShapeKey, int> g_tuned;
+static std::mutex g_tuned_mu;
+
+static bool cfg_feasible(int i, int Kw, int stride, int dil, bool need_bn128) {
+    const TileCfg& c = kCfgs[i];
+    const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
+    if (need_bn128 && bn % 128 != 0) return false;
+    if (stride != 1 && i != 2) return false;
+    if (i == 20) return false;                               // spills (kept only for index stability)
+    const size_t lds = 2 * (size_t)bm * ROWB + 2 * (size_t)cfg_xrows(c, stride, Kw, dil) * ROWB;
+    return lds <= 160 * 1024;
+}
+
+// pick the block shape: a measured choice if this shape was tuned, else a cost model (whole rounds of
+// resident blocks on the 256 CUs, larger tiles preferred)
+static int choose_cfg(int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, bool need_bn128) {
+    if (g_force_cfg < 0) {
+        std::lock_guard<std::mutex> lock(g_tuned_mu);
+        auto it = g_tuned.find(ShapeKey(N, Cin, Cout, Tout, Kw, stride, dil, need_bn128 ? 1 : 0));
+        if (it != g_tuned.end()) return it->second;
+    }
     int best = -1;
     double best_cost = 1e30;
     for (int i = 0; i < kNumCfgs; ++i) {
@@ -351,7 +376,7 @@ extern "C" int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_row
     W2L_CHECK_ARG(need <= p.x_max_row, "conv1d_igemm: padded input too small (need row %lld, have %lld)",
                   (long long)need, (long long)p.x_max_row);
     // BatchNorm partial statistics are laid out per 128-row column tile (w2l_conv_stat_tiles)
-    const int ci = choose_cfg(N, Cout, Tout, Kw, stride, dil, stats_partial != nullptr);
+    const int ci = choose_cfg(N, Cin, Cout, Tout, Kw, stride, dil, stats_partial != nullptr);
     W2L_CHECK_ARG(ci >= 0, "conv1d_igemm: no block shape fits LDS (Kw=%d dil=%d stride=%d)", Kw, dil, stride);
     const TileCfg& c = kCfgs[ci];
     const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
@@ -378,6 +403,55 @@ extern "C" int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_row
         case 13: return launch_cfg<2, 4, 5, 4>(p, tiles_m, lds, st);
         case 14: return launch_cfg<2, 4, 6, 4>(p, tiles_m, lds, st);
         case 15: return launch_cfg<2, 4, 7, 4>(p, tiles_m, lds, st);
-        default: return launch_cfg<2, 4, 8, 4>(p, tiles_m, lds, st);
+        case 16: return launch_cfg<2, 4, 8, 4>(p, tiles_m, lds, st);
+        case 17: return launch_cfg<2, 3, 4, 6>(p, tiles_m, lds, st);
+        case 18: return launch_cfg<2, 3, 5, 6>(p, tiles_m, lds, st);
+        case 19: return launch_cfg<2, 3, 6, 6>(p, tiles_m, lds, st);
+        default: return launch_cfg<2, 3, 7, 6>(p, tiles_m, lds, st);
     }
+}
+
+// Measure every feasible block shape for this problem on the caller's device and remember the fastest.
+// EXPLICITLY synchronising (hipEventSynchronize): call it once per shape during warm-up, never inside a
+// captured / latency-critical region.  Only for accumulate == 0 launches (the output is simply rewritten).
+extern "C" int w2l_conv1d_igemm_tune(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y,
+                                     int y_f32, const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout,
+                                     int Kw, int stride, int dil, int reps, void* stream) {
+    const bool need128 = stats_partial != nullptr;
+    const ShapeKey key(N, Cin, Cout, Tout, Kw, stride, dil, need128 ? 1 : 0);
+    {
+        std::lock_guard<std::mutex> lock(g_tuned_mu);
+        if (g_tuned.count(key)) return 0;
+    }
+    hipEvent_t e0, e1;
+    W2L_CHECK_HIP(hipEventCreate(&e0));
+    W2L_CHECK_HIP(hipEventCreate(&e1));
+    hipStream_t st = (hipStream_t)stream;
+    int best = -1;
+    float best_ms = 1e30f;
+    const int saved = g_force_cfg;
+    if (reps < 1) reps = 1;
+    for (int i = 0; i < kNumCfgs; ++i) {
+        if (!cfg_feasible(i, Kw, stride, dil, need128)) continue;
+        g_force_cfg = i;
+        int rc = w2l_conv1d_igemm(xp, x_bstride, x_rows_total, w, y, y_f32, 0, bias, stats_partial, N, Cin, Cout, Tout, Kw,
+                                  stride, dil, stream);                        // warm-up (also validates the launch)
+        if (rc != 0) continue;
+        (void)hipEventRecord(e0, st);
+        for (int r = 0; r < reps; ++r)
+            w2l_conv1d_igemm(xp, x_bstride, x_rows_total, w, y, y_f32, 0, bias, stats_partial, N, Cin, Cout, Tout, Kw,
+                             stride, dil, stream);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+        if (ms < best_ms) { best_ms = ms; best = i; }
+    }
+    g_force_cfg = saved;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    W2L_CHECK_ARG(best >= 0, "conv1d_igemm_tune: no feasible block shape");
+    std::lock_guard<std::mutex> lock(g_tuned_mu);
+    g_tuned[key] = best;
+    return 0;
 }

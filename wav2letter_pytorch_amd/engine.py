@@ -15,6 +15,7 @@ overlap, see distributed.py).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence
 
@@ -148,6 +149,10 @@ class _UnitCtx:
 
 
 _dropout_calls = 0
+# measure-and-pick of the conv block shape per problem shape (synchronises once per new shape); W2L_AUTOTUNE=0 keeps
+# the library's cost model
+AUTOTUNE = os.environ.get('W2L_AUTOTUNE', '1') != '0'
+_tuned_shapes = set()
 
 # optional kernel timer (bench.py): list of (kernel_name, flops, start_event, end_event)
 KERNEL_TIMER: Optional[list] = None
@@ -226,6 +231,13 @@ def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw
 
     st = stream_ptr()
     if not precise:
+        if AUTOTUNE:
+            key = (n, Cin, Cout, Tout, Kw, stride, dil, stats is not None, x.hi.device.index)
+            if key not in _tuned_shapes:       # once per shape and device, during the first (warm-up) step
+                _tuned_shapes.add(key)
+                check(lib.w2l_conv1d_igemm_tune(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y),
+                                                int(y.dtype == torch.float32), ptr(bias), ptr(stats), n, Cin, Cout, Tout,
+                                                Kw, stride, dil, 2, st), 'w2l_conv1d_igemm_tune')
         with _timed('conv_igemm_kernel', alg_flops):
             check(lib.w2l_conv1d_igemm(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y), int(y.dtype == torch.float32),
                                        0, ptr(bias), ptr(stats), n, Cin, Cout, Tout, Kw, stride, dil, st),
