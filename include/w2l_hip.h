@@ -103,6 +103,12 @@ int w2l_conv1d_wgrad(const void* dy, int64_t dy_bstride, const void* xp, int64_t
                      float* dw, int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int accumulate,
                      void* stream);
 
+/* Autotune of the split-K factor, like w2l_conv1d_igemm_tune (SYNCHRONISING, warm-up only); dw_scratch is a
+ * throw-away [Kw][Cout][Cin] fp32 buffer.  Call before w2l_wgrad_needs_zero() / w2l_conv1d_wgrad for the shape. */
+int w2l_conv1d_wgrad_tune(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride, int64_t x_rows_total,
+                          float* dw_scratch, int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int reps,
+                          void* stream);
+
 /* ---- depthwise Conv1d, groups == channels (nn.Conv1d inside MaskedConv1d, jasper.py:96-105,127,319-330) ----
  * weights fp32 tap-major w[k][c]; activations channels-last bf16 hi [+ lo]; fp32 arithmetic; HBM-bound.
  * fwd:   y[n][t][c] = sum_k w[k][c] * xp[n][t*stride + k*dil][c]; frames t >= lens[n] are written as 0

@@ -16,6 +16,9 @@
 // Replaces the weight-gradient half of aten::convolution_backward for the
 // nn.Conv1d call sites wav2letter.py:35-36,42 / jasper.py:96-105,127.
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <tuple>
 
 namespace {
 
@@ -230,8 +233,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
 // Split the (n,t) reduction over `splits` blocks per tile so that the grid fills whole rounds of the
 // 512 resident blocks (256 CUs x 2): cost = rounds x steps-per-block (+ the fp32 atomic traffic of the
 // extra partial tiles, ~1.3 TB/s chip-wide).  Non-power-of-two splits are allowed.
+// measured choices (w2l_conv1d_wgrad_tune): shape -> split count
+typedef std::tuple<int, int, int, int, int> WShapeKey;
+std::map<WShapeKey, int> g_wtuned;
+std::mutex g_wtuned_mu;
+int g_force_splits = 0;
+
 int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out) {
     const int kwb = Kw > 1 ? KWB_DEFAULT : 1;
+    {
+        const int ts = (Tout + BT - 1) / BT;
+        if (tsteps_out) *tsteps_out = ts;
+        if (g_force_splits > 0) return g_force_splits <= N * ts ? g_force_splits : N * ts;
+        std::lock_guard<std::mutex> lock(g_wtuned_mu);
+        auto it = g_wtuned.find(WShapeKey(N, Cin, Cout, Tout, Kw));
+        if (it != g_wtuned.end()) return it->second;
+    }
     const int tiles = ((Cout + BM - 1) / BM) * ((Cin + BNC - 1) / BNC) * ((Kw + kwb - 1) / kwb);
     const int tsteps = (Tout + BT - 1) / BT;
     const int total = N * tsteps;
@@ -295,5 +312,52 @@ extern "C" int w2l_conv1d_wgrad(const void* dy, int64_t dy_bstride, const void* 
         hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, block, lds, (hipStream_t)stream, p);
     }
     W2L_CHECK_LAUNCH();
+    return 0;
+}
+
+// Measure candidate split-K factors for this problem on the caller's device and remember the fastest
+// (SYNCHRONISING; warm-up only).  `dw_scratch` is a throw-away [Kw][Cout][Cin] fp32 buffer.
+extern "C" int w2l_conv1d_wgrad_tune(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride,
+                                     int64_t x_rows_total, float* dw_scratch, int N, int Cin, int Cout, int Tout, int Kw,
+                                     int stride, int dil, int reps, void* stream) {
+    const WShapeKey key(N, Cin, Cout, Tout, Kw);
+    {
+        std::lock_guard<std::mutex> lock(g_wtuned_mu);
+        if (g_wtuned.count(key)) return 0;
+    }
+    hipEvent_t e0, e1;
+    W2L_CHECK_HIP(hipEventCreate(&e0));
+    W2L_CHECK_HIP(hipEventCreate(&e1));
+    hipStream_t st = (hipStream_t)stream;
+    const int total = N * ((Tout + BT - 1) / BT);
+    const int cands[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32};
+    int best = -1;
+    float best_ms = 1e30f;
+    if (reps < 1) reps = 1;
+    const size_t bytes = (size_t)Kw * Cout * Cin * sizeof(float);
+    for (int s : cands) {
+        if (s > total || (s > 1 && total / s < 4)) break;
+        g_force_splits = s;
+        int rc = w2l_conv1d_wgrad(dy, dy_bstride, xp, x_bstride, x_rows_total, dw_scratch, N, Cin, Cout, Tout, Kw, stride, dil,
+                                  0, stream);
+        if (rc != 0) continue;
+        (void)hipEventRecord(e0, st);
+        for (int r = 0; r < reps; ++r) {
+            if (s > 1) (void)hipMemsetAsync(dw_scratch, 0, bytes, st);      // the zero fill a split launch needs is part of its cost
+            w2l_conv1d_wgrad(dy, dy_bstride, xp, x_bstride, x_rows_total, dw_scratch, N, Cin, Cout, Tout, Kw, stride, dil, 0,
+                             stream);
+        }
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+        if (ms < best_ms) { best_ms = ms; best = s; }
+    }
+    g_force_splits = 0;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    W2L_CHECK_ARG(best >= 1, "conv1d_wgrad_tune: no candidate ran");
+    std::lock_guard<std::mutex> lock(g_wtuned_mu);
+    g_wtuned[key] = best;
     return 0;
 }

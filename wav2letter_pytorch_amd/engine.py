@@ -702,13 +702,22 @@ class StackEngine:
         dev = w.device
         N = src.N
         direct = (pk.coutp == cout and pk.cinp == cin)
-        need_zero = bool(lib.w2l_wgrad_needs_zero(N, pk.cinp, pk.coutp, Tout, kw)) or self.precise
-        alloc = torch.zeros if need_zero else torch.empty
-        dw = alloc(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
         row_off = src.pad_l - conv.pad_l
         x_bstride = src.rows * src.CP
         x_rows_total = N * src.rows - row_off
         dy_bstride = (Tout + halo) * pk.coutp          # shared-halo layout: utterance n starts at row halo + n*(Tout+halo)
+        if AUTOTUNE and not self.precise:
+            key = ('wgrad', N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, dev.index)
+            if key not in _tuned_shapes:       # once per shape and device, during the first (warm-up) step
+                _tuned_shapes.add(key)
+                scratch = torch.empty(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
+                check(lib.w2l_conv1d_wgrad_tune(C.c_void_p(dy_hi.data_ptr() + halo * pk.coutp * 2), dy_bstride,
+                                                C.c_void_p(src.hi.data_ptr() + row_off * src.CP * 2), x_bstride, x_rows_total,
+                                                ptr(scratch), N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, 2,
+                                                stream_ptr()), 'w2l_conv1d_wgrad_tune')
+        need_zero = bool(lib.w2l_wgrad_needs_zero(N, pk.cinp, pk.coutp, Tout, kw)) or self.precise
+        alloc = torch.zeros if need_zero else torch.empty
+        dw = alloc(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
         st = stream_ptr()
 
         def run(dy, x, acc):
