@@ -93,6 +93,8 @@ def main():
     ap.add_argument('--no-optimizer', action='store_true')
     ap.add_argument('--force-dp', action='store_true', help='run the RCCL gradient path even with one rank (plumbing check)')
     ap.add_argument('--serial-wgrad', action='store_true', help='keep weight gradients on the main stream (clean per-kernel durations for profiling)')
+    ap.add_argument('--trace-steps', action='store_true', help='per-step host-enqueue vs GPU time (stderr), then exit')
+    ap.add_argument('--host-profile', action='store_true', help='cProfile of the host side of the step (stderr), then exit')
     ap.add_argument('--breakdown', action='store_true', help='print the per-kernel event timing table to stderr')
     args = ap.parse_args()
 
@@ -145,6 +147,41 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if args.trace_steps:
+        # per-step host enqueue time vs GPU time (event to event): tells a host-bound box from a slow-clock box
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        host = []
+        evs[0].record()
+        for i in range(args.steps):
+            h0 = time.perf_counter()
+            step()
+            evs[i + 1].record()
+            host.append((time.perf_counter() - h0) * 1e3)
+        torch.cuda.synchronize()
+        gpu = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+        print('load average: %s' % open('/proc/loadavg').read().strip(), file=sys.stderr)
+        print('host enqueue ms/step: ' + ' '.join('%.1f' % v for v in host), file=sys.stderr)
+        print('gpu ms/step:          ' + ' '.join('%.1f' % v for v in gpu), file=sys.stderr)
+        return
+    if args.host_profile:
+        import cProfile
+        import pstats
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print('enqueue %.3f ms/step, with drain %.3f ms/step' % ((t1 - t0) / args.steps * 1e3, (t2 - t0) / args.steps * 1e3),
+              file=sys.stderr)
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(args.steps):
+            step()
+        pr.disable()
+        torch.cuda.synchronize()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats('tottime').print_stats(50)
+        return
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -180,6 +217,14 @@ def main():
                 'unit': 'TFLOP/s', 'frac': round(ach / BF16_DENSE_PEAK_TFLOPS, 4), 'traffic': None,
                 'launches_per_step': cnt // 3, 'avg_launch_ms': round(tt / cnt * 1e3, 4),
                 'alg_gflop_per_launch': round(fl / cnt / 1e9, 2)}
+        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_bench.json')
+        if args.model == 'wav2letter' and args.mid_layers == 20 and args.batch == 32 and os.path.exists(pmc_file):
+            # HBM-side bytes per launch from the committed PMC passes of this same command (tools/make_profiles.sh):
+            # FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 FETCH correction applied (tools/prof_summary.py)
+            k = json.load(open(pmc_file))['kernels'].get(name, {})
+            if 'traffic_bytes_per_launch' in k:
+                roof['traffic'] = round(k['traffic_bytes_per_launch'])
+                roof['traffic_source'] = 'profiles/r01_pmc_bench.json (rocprofv3 --pmc, mean over the step\'s launches)'
         if 'conv_wgrad_kernel' in agg:
             fl2, tt2, cnt2 = agg['conv_wgrad_kernel']
             roof['wgrad_kernel'] = {'achieved': round(fl2 / tt2 / 1e12, 1), 'frac': round(fl2 / tt2 / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4),

@@ -109,6 +109,12 @@ int w2l_conv1d_wgrad_tune(const void* dy, int64_t dy_bstride, const void* xp, in
                           float* dw_scratch, int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int reps,
                           void* stream);
 
+/* Persistence of the measured choices of w2l_conv1d_igemm_tune / w2l_conv1d_wgrad_tune (a small text file; the
+ * analogue of a vendor library's find-db).  save: 0 on success.  load: number of entries taken, -1 on error; lines
+ * that do not describe a feasible launch of THIS build are skipped. */
+int w2l_tune_save(const char* path);
+int w2l_tune_load(const char* path);
+
 /* ---- depthwise Conv1d, groups == channels (nn.Conv1d inside MaskedConv1d, jasper.py:96-105,127,319-330) ----
  * weights fp32 tap-major w[k][c]; activations channels-last bf16 hi [+ lo]; fp32 arithmetic; HBM-bound.
  * fwd:   y[n][t][c] = sum_k w[k][c] * xp[n][t*stride + k*dil][c]; frames t >= lens[n] are written as 0

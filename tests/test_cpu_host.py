@@ -204,7 +204,9 @@ def _dp_worker(rank, world, port, q):
     for t in smalls:
         red.on_grad(None, t)
     red.finish()
-    q.put((rank, mod.lin.weight.detach().clone(), conv_w.detach().clone(), big.clone(), [t.clone() for t in smalls]))
+    # numpy payloads are pickled by value (torch tensors travel as shared-memory handles that die with this process)
+    q.put((rank, mod.lin.weight.detach().numpy().copy(), conv_w.detach().numpy().copy(), big.numpy().copy(),
+           [t.numpy().copy() for t in smalls]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -223,6 +225,8 @@ def test_grad_reducer_gloo_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    res = [(r, torch.from_numpy(w), torch.from_numpy(c), torch.from_numpy(b), [torch.from_numpy(t) for t in s])
+           for r, w, c, b, s in res]
     (_, w0, c0, big0, s0), (_, w1, c1, big1, s1) = res
     assert torch.equal(w0, w1) and torch.equal(c0, c1)                        # broadcast made the replicas identical
     assert torch.equal(big0, big1)
@@ -249,3 +253,28 @@ def test_novograd_matches_reference_fixture():
         np.testing.assert_allclose(opt.state[ps[0]]['exp_avg_sq'].numpy(), z[f'{tag}/v_0'], rtol=1e-5)
     with pytest.raises(ValueError):
         Novograd(ps, betas=(1.0, 0))
+
+
+def test_tune_cache_roundtrip(tmp_path):
+    """w2l_tune_save / w2l_tune_load: host-only persistence of the measured block-shape / split-K choices."""
+    from wav2letter_pytorch_amd import _lib as L
+    src = tmp_path / 'in.txt'
+    src.write_text('w2l-tune v1 gfx950\n'
+                   'igemm 7 640 768 1000 21 1 1 1 15\n'
+                   'igemm 7 640 768 1000 21 1 1 1 99\n'      # unknown block shape: skipped
+                   'igemm 7 640 768 500 21 2 1 0 15\n'       # stride 2 only runs on shape 2: skipped
+                   'wgrad 7 640 768 1000 21 3\n'
+                   'wgrad 1 64 64 10 3 999\n'                # more splits than (n,t) steps: skipped
+                   'garbage\n')
+    assert L.lib.w2l_tune_load(str(src).encode()) == 2
+    out = tmp_path / 'out.txt'
+    assert L.lib.w2l_tune_save(str(out).encode()) == 0
+    lines = out.read_text().splitlines()
+    assert lines[0] == 'w2l-tune v1 gfx950'
+    assert 'igemm 7 640 768 1000 21 1 1 1 15' in lines and 'wgrad 7 640 768 1000 21 3' in lines
+    assert not any(' 99' in ln or ' 999' in ln for ln in lines)
+    assert L.lib.w2l_tune_load(str(tmp_path / 'missing').encode()) == -1
+    assert b'cannot open' in L.lib.w2l_last_error()
+    bad = tmp_path / 'bad.txt'
+    bad.write_text('something else\n')
+    assert L.lib.w2l_tune_load(str(bad).encode()) == -1

@@ -455,3 +455,20 @@ extern "C" int w2l_conv1d_igemm_tune(const void* xp, int64_t x_bstride, int64_t 
     g_tuned[key] = best;
     return 0;
 }
+
+// Tuning-cache (de)serialisation used by w2l_tune_save / w2l_tune_load (runtime.hip).
+void w2l_igemm_tune_dump(FILE* f) {
+    std::lock_guard<std::mutex> lock(g_tuned_mu);
+    for (const auto& kv : g_tuned) {
+        const ShapeKey& k = kv.first;
+        fprintf(f, "igemm %d %d %d %d %d %d %d %d %d\n", std::get<0>(k), std::get<1>(k), std::get<2>(k), std::get<3>(k),
+                std::get<4>(k), std::get<5>(k), std::get<6>(k), std::get<7>(k), kv.second);
+    }
+}
+
+bool w2l_igemm_tune_put(const int* v) {          // v[0..7] = key, v[8] = block-shape index
+    if (v[8] < 0 || v[8] >= kNumCfgs || !cfg_feasible(v[8], v[4], v[5], v[6], v[7] != 0)) return false;
+    std::lock_guard<std::mutex> lock(g_tuned_mu);
+    g_tuned[ShapeKey(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])] = v[8];
+    return true;
+}

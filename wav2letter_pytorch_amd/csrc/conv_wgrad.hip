@@ -361,3 +361,22 @@ extern "C" int w2l_conv1d_wgrad_tune(const void* dy, int64_t dy_bstride, const v
     g_wtuned[key] = best;
     return 0;
 }
+
+// Tuning-cache (de)serialisation used by w2l_tune_save / w2l_tune_load (runtime.hip).
+void w2l_wgrad_tune_dump(FILE* f) {
+    std::lock_guard<std::mutex> lock(g_wtuned_mu);
+    for (const auto& kv : g_wtuned) {
+        const WShapeKey& k = kv.first;
+        fprintf(f, "wgrad %d %d %d %d %d %d\n", std::get<0>(k), std::get<1>(k), std::get<2>(k), std::get<3>(k),
+                std::get<4>(k), kv.second);
+    }
+}
+
+bool w2l_wgrad_tune_put(const int* v) {          // v[0..4] = key, v[5] = split count
+    if (v[5] < 1 || v[0] < 1 || v[3] < 1) return false;
+    const int ts = (v[3] + BT - 1) / BT;
+    if ((int64_t)v[5] > (int64_t)v[0] * ts) return false;
+    std::lock_guard<std::mutex> lock(g_wtuned_mu);
+    g_wtuned[WShapeKey(v[0], v[1], v[2], v[3], v[4])] = v[5];
+    return true;
+}

@@ -1,6 +1,7 @@
 // Error reporting, ABI version and host-side helpers of libw2l_hip.so.
 #include "common.h"
 #include <mutex>
+#include <string.h>
 #include <unordered_set>
 #include <vector>
 #include <algorithm>
@@ -26,6 +27,49 @@ hipError_t w2l_allow_big_lds(const void* kernel) {
 
 extern "C" const char* w2l_last_error(void) { return g_err; }
 extern "C" int w2l_abi_version(void) { return 1; }
+
+// ---- tuning cache persistence (the measured block-shape / split-K choices of w2l_conv1d_*_tune) ----
+void w2l_igemm_tune_dump(FILE* f);
+bool w2l_igemm_tune_put(const int* v);
+void w2l_wgrad_tune_dump(FILE* f);
+bool w2l_wgrad_tune_put(const int* v);
+static const char kTuneHeader[] = "w2l-tune v1 gfx950";
+
+extern "C" int w2l_tune_save(const char* path) {
+    W2L_CHECK_ARG(path != nullptr, "tune_save: null path");
+    FILE* f = fopen(path, "w");
+    W2L_CHECK_ARG(f != nullptr, "tune_save: cannot open %s", path);
+    fprintf(f, "%s\n", kTuneHeader);
+    w2l_igemm_tune_dump(f);
+    w2l_wgrad_tune_dump(f);
+    const bool ok = fclose(f) == 0;
+    W2L_CHECK_ARG(ok, "tune_save: write to %s failed", path);
+    return 0;
+}
+
+// Returns the number of entries taken (>= 0), or -1 on error.  Unknown / infeasible lines are skipped, so a cache
+// written by another build can never select an invalid launch.
+extern "C" int w2l_tune_load(const char* path) {
+    if (path == nullptr) { w2l_set_error("tune_load: null path"); return -1; }
+    FILE* f = fopen(path, "r");
+    if (f == nullptr) { w2l_set_error("tune_load: cannot open %s", path); return -1; }
+    char line[256];
+    int taken = 0;
+    if (fgets(line, sizeof(line), f) == nullptr || strncmp(line, kTuneHeader, sizeof(kTuneHeader) - 1) != 0) {
+        fclose(f);
+        w2l_set_error("tune_load: %s is not a %s file", path, kTuneHeader);
+        return -1;
+    }
+    while (fgets(line, sizeof(line), f) != nullptr) {
+        int v[9];
+        if (sscanf(line, "igemm %d %d %d %d %d %d %d %d %d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8) == 9)
+            taken += w2l_igemm_tune_put(v) ? 1 : 0;
+        else if (sscanf(line, "wgrad %d %d %d %d %d %d", v, v + 1, v + 2, v + 3, v + 4, v + 5) == 6)
+            taken += w2l_wgrad_tune_put(v) ? 1 : 0;
+    }
+    fclose(f);
+    return taken;
+}
 
 // Edit distance over int32 symbols (stands in for python-Levenshtein's distance(),
 // decoder.py:49,60).  Host code: the strings live on the host.

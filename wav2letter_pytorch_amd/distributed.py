@@ -89,7 +89,7 @@ class GradReducer:
             side.wait_event(ev)
             with torch.cuda.stream(side):
                 work, need_div = self._all_reduce(buf)
-            buf.record_stream(side)
+            # no record_stream: buf stays referenced in self._works until finish() has made the consumer stream wait
         else:
             work, need_div = self._all_reduce(buf)
         self._works.append((work, buf, need_div))

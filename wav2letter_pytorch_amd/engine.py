@@ -14,6 +14,7 @@ overlap, see distributed.py).
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
 from dataclasses import dataclass, field
@@ -153,6 +154,34 @@ _dropout_calls = 0
 # the library's cost model
 AUTOTUNE = os.environ.get('W2L_AUTOTUNE', '1') != '0'
 _tuned_shapes = set()
+# W2L_TUNE_CACHE=<file>: measured choices are loaded at import and written back (atomically) after a step that
+# measured new shapes, so later processes (and the other DP ranks) skip the measuring launches.
+TUNE_CACHE = os.environ.get('W2L_TUNE_CACHE') or None
+_tune_state = {'dirty': False}
+
+
+def load_tune_cache(path: str) -> int:
+    n = lib.w2l_tune_load(path.encode())
+    if n < 0:
+        check(1, 'w2l_tune_load')
+    return n
+
+
+def save_tune_cache(path: str):
+    tmp = '%s.tmp.%d' % (path, os.getpid())
+    check(lib.w2l_tune_save(tmp.encode()), 'w2l_tune_save')
+    os.replace(tmp, path)
+
+
+def _flush_tune_cache():
+    if _tune_state['dirty'] and TUNE_CACHE:
+        save_tune_cache(TUNE_CACHE)
+    _tune_state['dirty'] = False
+
+
+if TUNE_CACHE and os.path.exists(TUNE_CACHE):
+    load_tune_cache(TUNE_CACHE)
+atexit.register(_flush_tune_cache)
 
 # optional kernel timer (bench.py): list of (kernel_name, flops, start_event, end_event)
 KERNEL_TIMER: Optional[list] = None
@@ -235,6 +264,7 @@ def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw
             key = (n, Cin, Cout, Tout, Kw, stride, dil, stats is not None, x.hi.device.index)
             if key not in _tuned_shapes:       # once per shape and device, during the first (warm-up) step
                 _tuned_shapes.add(key)
+                _tune_state['dirty'] = True
                 check(lib.w2l_conv1d_igemm_tune(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y),
                                                 int(y.dtype == torch.float32), ptr(bias), ptr(stats), n, Cin, Cout, Tout,
                                                 Kw, stride, dil, 2, st), 'w2l_conv1d_igemm_tune')
@@ -268,6 +298,8 @@ class StackEngine:
         # on a side HIP stream so their blocks fill the tail rounds of the dgrad / elementwise kernels
         self.overlap_wgrad = True
         self._side = None
+        self._side_used = False
+        self._held: list = []        # tensors in use by side-stream kernels; released after the join in backward()
 
     # ------------------------------------------------------------------ parameters
     def parameters(self) -> List[torch.Tensor]:
@@ -625,13 +657,11 @@ class StackEngine:
                 if self._needs_grad(u.res_src, ctx):
                     act_grads[u.res_src].append(self._dgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc))
         ctx['input_grad'] = self.input_grad(ctx, act_grads[0]) if ctx.get('want_dx') and act_grads[0] else None
-        if getattr(self, '_side_used', False):
-            main = torch.cuda.current_stream(dev)
-            main.wait_stream(self._side)
-            for g in grads.values():
-                if g is not None and g.is_cuda:
-                    g.record_stream(main)
+        if self._side_used:
+            torch.cuda.current_stream(dev).wait_stream(self._side)
             self._side_used = False
+        self._held.clear()
+        _flush_tune_cache()
         if self.backward_done is not None:
             self.backward_done()
         return [grads.get(id(p)) for p in self.parameters()]
@@ -678,25 +708,24 @@ class StackEngine:
         return g
 
     def _wgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, grads):
-        """dW on the side stream (ordered after everything enqueued so far on the current stream)."""
+        """dW, optionally on the side stream (ordered after everything enqueued so far on the current stream).
+
+        No record_stream: dW is allocated (and zero-filled) on the main stream before the fork, and every tensor the
+        side-stream kernel touches is kept alive in self._held until backward() joins the streams, so the caching
+        allocator never has to poll cross-stream events (that polling stalled small-batch steps by 2-3x)."""
         if not self.overlap_wgrad or not dy_hi.is_cuda:
             return self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads)
         main = torch.cuda.current_stream(dy_hi.device)
         if self._side is None or self._side.device != dy_hi.device:
             self._side = torch.cuda.Stream(device=dy_hi.device)
         side = self._side
-        ev = torch.cuda.Event()
-        ev.record(main)
-        side.wait_event(ev)
-        with torch.cuda.stream(side):
-            self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads)
-        for t in (dy_hi, dy_lo, src.hi, src.lo):
-            if t is not None:
-                t.record_stream(side)
+        self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads, fork=(main, side))
+        self._held.extend(t for t in (dy_hi, dy_lo, src.hi, src.lo) if t is not None)
         self._side_used = True
 
-    def _wgrad_now(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, grads):
-        """dW through w2l_conv1d_wgrad, written in the parameter's own physical layout when possible."""
+    def _wgrad_now(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, grads, fork=None):
+        """dW through w2l_conv1d_wgrad, written in the parameter's own physical layout when possible.
+        fork=(main, side): allocate on main, launch on side after an event recorded on main."""
         w = conv.weight
         cout, cin, kw = w.shape
         dev = w.device
@@ -710,6 +739,7 @@ class StackEngine:
             key = ('wgrad', N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, dev.index)
             if key not in _tuned_shapes:       # once per shape and device, during the first (warm-up) step
                 _tuned_shapes.add(key)
+                _tune_state['dirty'] = True
                 scratch = torch.empty(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
                 check(lib.w2l_conv1d_wgrad_tune(C.c_void_p(dy_hi.data_ptr() + halo * pk.coutp * 2), dy_bstride,
                                                 C.c_void_p(src.hi.data_ptr() + row_off * src.CP * 2), x_bstride, x_rows_total,
@@ -718,6 +748,22 @@ class StackEngine:
         need_zero = bool(lib.w2l_wgrad_needs_zero(N, pk.cinp, pk.coutp, Tout, kw)) or self.precise
         alloc = torch.zeros if need_zero else torch.empty
         dw = alloc(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
+        if fork is not None:
+            ev = torch.cuda.Event()
+            ev.record(fork[0])
+            fork[1].wait_event(ev)
+            self._held.append(dw)
+            with torch.cuda.stream(fork[1]):
+                return self._wgrad_launch(conv, pk, dw, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total,
+                                          dy_bstride, row_off, direct)
+        return self._wgrad_launch(conv, pk, dw, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total, dy_bstride,
+                                  row_off, direct)
+
+    def _wgrad_launch(self, conv, pk, dw, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total, dy_bstride, row_off,
+                      direct):
+        w = conv.weight
+        cout, cin, kw = w.shape
+        N = src.N
         st = stream_ptr()
 
         def run(dy, x, acc):
