@@ -175,10 +175,11 @@ def main():
         print('enqueue %.3f ms/step, with drain %.3f ms/step' % ((t1 - t0) / args.steps * 1e3, (t2 - t0) / args.steps * 1e3),
               file=sys.stderr)
         pr = cProfile.Profile()
-        pr.enable()
-        for _ in range(args.steps):
-            step()
-        pr.disable()
+        with torch.autograd.set_multithreading_enabled(False):    # backward on this thread so the profile sees it
+            pr.enable()
+            for _ in range(args.steps):
+                step()
+            pr.disable()
         torch.cuda.synchronize()
         pstats.Stats(pr, stream=sys.stderr).sort_stats('tottime').print_stats(50)
         return

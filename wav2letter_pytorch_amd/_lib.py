@@ -109,7 +109,9 @@ def ptr(t):
 
 
 def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """hipStream_t of torch's current stream on the current device (raw getters: ~20x cheaper than
+    torch.cuda.current_stream(), and this is called for every launch)."""
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def require_device(*tensors):

@@ -16,6 +16,7 @@
 // Replaces the weight-gradient half of aten::convolution_backward for the
 // nn.Conv1d call sites wav2letter.py:35-36,42 / jasper.py:96-105,127.
 #include "common.h"
+#include <type_traits>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -38,20 +39,32 @@ struct WgradParams {
     int64_t x_max_row;
     int N, Cin, Cout, Tout, Kw, stride, dil;
     int tiles_m, tiles_n, kgroups, tsteps, total_steps, steps_per_split, atomic;
+    int order;                 // block order inside a split: 1 = tap group fastest, 0 = co tile fastest
     int xrows_lds;
 };
 
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
+// 16 B per lane global -> LDS (LDS-DMA): lane l lands at lds_wave_base + 16*l.  Written as inline asm on purpose: with
+// the builtin the compiler (which cannot prove that the DMA destination and the buffer being read are different
+// halves of the double buffer) puts s_waitcnt vmcnt(0) in front of the ds_read_b64_tr_b16 that FOLLOW the prefetch,
+// i.e. it waits for the loads just issued and the prefetch hides nothing.  The loop's own vmcnt(0) + barrier at the
+// top of every step is what orders the DMA against its readers.
+__device__ __forceinline__ void glds16(const void* gbase_uniform, unsigned voff, unsigned lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(voff), "s"(gbase_uniform), "s"(lds_wave_base)
+                 : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }
 
 // swizzle key of an LDS row: spreads the 8 rows one tr-read half-wave touches
 // (r..r+3 and r+8..r+11) over the 8 aligned 32-byte column pairs of a bank row.
 __device__ __forceinline__ int row_key(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
-__device__ __forceinline__ bf16x4 tr_read(const char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+__device__ __forceinline__ bf16x4 tr_read(unsigned lds_byte_addr) {      // 32-bit LDS address
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(size_t)lds_byte_addr);
 }
 
 template <int KWB>
@@ -62,14 +75,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    // blockIdx.x -> (tap, ci tile, co tile); neighbouring blocks share dy / x panels through L2
-    int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = tile % p.tiles_m;
-    tile /= p.tiles_m;
-    const int tn = tile % p.tiles_n;
-    const int kw0 = (tile / p.tiles_n) * KWB;      // first tap of this block's group
+    // (blockIdx.y, blockIdx.x) -> (split, tile).  The XCD remap runs on the linear block id because that is what the
+    // hardware deals round-robin to the XCDs: the ~64 blocks resident on one XCD are then consecutive tiles of ONE split.
+    // order 1 (tap group fastest): they cover all tap groups of a few co tiles of one ci tile, i.e. stream the same few
+    //          dy tiles and overlapping x windows through that XCD's L2;
+    // order 0 (co tile fastest, then ci tile, then tap group): all (co, ci) tiles of one or two tap groups.
+    // Which one wins depends on the shape (measured by w2l_conv1d_wgrad_tune).
+    int lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int split = lin / gridDim.x;
+    int tile = lin - split * gridDim.x;
+    int tm, tn, kw0;
+    if (p.order) {
+        kw0 = (tile % p.kgroups) * KWB;            // first tap of this block's group
+        tile /= p.kgroups;
+        tm = tile % p.tiles_m;
+        tn = tile / p.tiles_m;
+    } else {
+        tm = tile % p.tiles_m;
+        tile /= p.tiles_m;
+        tn = tile % p.tiles_n;
+        kw0 = (tile / p.tiles_n) * KWB;
+    }
     const int ntaps = (p.Kw - kw0) < KWB ? (p.Kw - kw0) : KWB;
-    const int split = blockIdx.y;
     const int m0 = tm * BM, c0 = tn * BNC;
     const int s = p.stride, d = p.dil;
     const int shift = kw0 * d;
@@ -98,8 +125,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         const int t0 = ts * BT;
         // dy rows t0..t0+63 (rows >= Tout are zero by contract)
         const char* abase = reinterpret_cast<const char*>(p.dy) + ((int64_t)n * p.dy_rows_per_utt + t0) * p.Cout * 2;
+        const unsigned a_lds = __builtin_amdgcn_readfirstlane(lds_addr(adst) + wave * (BT / 16) * 1024);
 #pragma unroll
-        for (int i = 0; i < BT / 16; ++i) glds16(abase + a_voff[i], adst + (wave * (BT / 16) + i) * 1024);
+        for (int i = 0; i < BT / 16; ++i) glds16(abase, a_voff[i], a_lds + i * 1024);
+        const unsigned b_lds = __builtin_amdgcn_readfirstlane(lds_addr(bdst));
         const unsigned xrow0 = (unsigned)(n * p.x_rows_per_utt) + (unsigned)(t0 * s + shift);
         const int ngrp = xrows >> 2;
         for (int grp = wave; grp < ngrp; grp += 4) {
@@ -110,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
             int ci = c0 + g * 8;
             ci = ci < p.Cin ? ci : p.Cin - 8;
             const unsigned voff = (fr * (unsigned)p.Cin + (unsigned)ci) * 2u;
-            glds16(reinterpret_cast<const char*>(p.x) + voff, bdst + grp * 1024);
+            glds16(p.x, voff, b_lds + grp * 1024);
         }
     };
 
@@ -134,77 +163,102 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     const int q = l16 >> 2, pp = l16 & 3;
     const int kgrp = lane >> 4;                    // k octet of this lane group
     const int lrow = kgrp * 8 + q;
-    int a_lane[4], b_lane[KWB][2][4];
+    // read pointers into buffer 0; toggled in place between the two buffers after every step (no second copy of the
+    // lane constants stays live: the kernel is VGPR-bound)
+    unsigned pa[4];
+    unsigned pb[KWB][2][4];
+    const unsigned abase0 = lds_addr(abuf0), bbase0 = lds_addr(bbuf0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int acol = (wm * 64 + i * 16 + pp * 4) * 2;
-        a_lane[i] = lrow * ROWB + (acol ^ (row_key(lrow) << 5));
+        pa[i] = abase0 + lrow * ROWB + (acol ^ (row_key(lrow) << 5));
 #pragma unroll
         for (int tp = 0; tp < KWB; ++tp)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int rb = (lrow + h * 4) * s + tp * d;                   // row at ks = 0
                 const int bcol = (wn * 64 + i * 16 + pp * 4) * 2;
-                b_lane[tp][h][i] = rb * ROWB + (bcol ^ (row_key(rb) << 5));   // ks*32*s rows further: same key (multiple of 16)
+                pb[tp][h][i] = bbase0 + rb * ROWB + (bcol ^ (row_key(rb) << 5));   // ks*32*s rows further: same key (multiple of 16)
             }
     }
+    int a_toggle = BT * ROWB, b_toggle = xrows * ROWB;
 
-    int n_cur = step_begin / p.tsteps;
-    int ts_cur = step_begin - n_cur * p.tsteps;
-    if (step_begin < step_end) stage(abuf0, bbuf0, n_cur, ts_cur);
-    for (int step = step_begin; step < step_end; ++step) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int par = (step - step_begin) & 1;
-        int ts_n = ts_cur + 1, n_n = n_cur;
-        if (ts_n == p.tsteps) { ts_n = 0; ++n_n; }
-        if (step + 1 < step_end) stage(par ? abuf0 : abuf1, par ? bbuf0 : bbuf1, n_n, ts_n);
-        n_cur = n_n; ts_cur = ts_n;
-        const char* ab = par ? abuf1 : abuf0;
-        const char* bb = par ? bbuf1 : bbuf0;
-        // one address add per distinct lane constant and step; (ks, h) offsets are ds_read immediates
-        const char* pa[4];
-        const char* pb[KWB][2][4];
+    // One K step (64 rows) of the block for NT live taps, software-pipelined inside the wave: the transposing reads of
+    // fragment group g+1 are issued before the 16 MFMAs of group g (groups ordered ks-major, tap-minor; A fragments
+    // are re-read only when ks changes), so LDS latency hides behind this wave's own MFMAs and not only behind the
+    // other resident block's.  NT is a template-like constant (branch-free body: the compiler may not move reads
+    // across a branch).
+    auto compute = [&](auto nt_tag) {
+        constexpr int NT = decltype(nt_tag)::value;
+        bf16x8 a[4], b[2][4];
+        auto load_a1 = [&](int i, int ks) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            pa[i] = ab + a_lane[i];
+            for (int h = 0; h < 2; ++h) {
+                const bf16x4 va = tr_read(pa[i] + (ks * 32 + h * 4) * ROWB);
 #pragma unroll
-            for (int tp = 0; tp < KWB; ++tp)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) pb[tp][h][i] = bb + b_lane[tp][h][i];
-        }
-#pragma unroll
-        for (int ks = 0; ks < BT / 32; ++ks) {
-            bf16x8 a[4];
+                for (int e = 0; e < 4; ++e) a[i][h * 4 + e] = va[e];
+            }
+        };
+        auto load_b = [&](bf16x8* dst, int tp, int ks) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const bf16x4 va = tr_read(pa[i] + (ks * 32 + h * 4) * ROWB);
+                    const bf16x4 vb = tr_read(pb[tp][h][i] + ks * 32 * s * ROWB);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) a[i][h * 4 + e] = va[e];
+                    for (int e = 0; e < 4; ++e) dst[i][h * 4 + e] = vb[e];
                 }
+        };
+        constexpr int NG = (BT / 32) * NT;
 #pragma unroll
-            for (int tp = 0; tp < KWB; ++tp) {
-                if (tp < ntaps) {                                   // wave-uniform
-                    bf16x8 b[4];
+        for (int i = 0; i < 4; ++i) load_a1(i, 0);
+        load_b(b[0], 0, 0);
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
+        for (int g = 0; g < NG; ++g) {
+            const int ks = g / NT, tp = g % NT;
+            const bool more = g + 1 < NG;
+            const int ks2 = (g + 1) / NT, tp2 = (g + 1) % NT;
+            if (more) load_b(b[(g + 1) & 1], tp2, ks2);          // B fragments are double-buffered
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const bf16x4 vb = tr_read(pb[tp][h][i] + ks * 32 * s * ROWB);
+            for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) b[i][h * 4 + e] = vb[e];
-                        }
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni)
-                            acc[tp][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[tp][mi][ni], 0, 0, 0);
-                }
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[tp][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[g & 1][ni], acc[tp][mi][ni], 0, 0, 0);
+                // A fragments are refilled in place, row by row, as the last tap group of this ks retires them
+                if (more && ks2 != ks) load_a1(mi, ks2);
             }
         }
-    }
+    };
+
+    // the whole K loop exists once per live-tap count (the branch sits outside the loop so that each loop body is
+    // straight-line code with in-place accumulators)
+    auto run = [&](auto nt_tag) {
+        int n_cur = step_begin / p.tsteps;
+        int ts_cur = step_begin - n_cur * p.tsteps;
+        if (step_begin < step_end) stage(abuf0, bbuf0, n_cur, ts_cur);
+        for (int step = step_begin; step < step_end; ++step) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int par = (step - step_begin) & 1;
+            int ts_n = ts_cur + 1, n_n = n_cur;
+            if (ts_n == p.tsteps) { ts_n = 0; ++n_n; }
+            if (step + 1 < step_end) stage(par ? abuf0 : abuf1, par ? bbuf0 : bbuf1, n_n, ts_n);
+            n_cur = n_n; ts_cur = ts_n;
+            compute(nt_tag);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pa[i] += a_toggle;
+#pragma unroll
+                for (int tp = 0; tp < KWB; ++tp)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) pb[tp][h][i] += b_toggle;
+            }
+            a_toggle = -a_toggle;
+            b_toggle = -b_toggle;
+        }
+    };
+    if (KWB == 1 || ntaps == KWB) run(std::integral_constant<int, KWB>{});
+    else run(std::integral_constant<int, 1>{});
 
     // ---- epilogue: acc[tp][mi][ni][r] = dw[kw0+tp][co = m0+wm*64+mi*16+fq*4+r][ci = c0+wn*64+ni*16+fr] ----
     const int fr = lane & 15, fq = lane >> 4;
@@ -233,21 +287,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
 // Split the (n,t) reduction over `splits` blocks per tile so that the grid fills whole rounds of the
 // 512 resident blocks (256 CUs x 2): cost = rounds x steps-per-block (+ the fp32 atomic traffic of the
 // extra partial tiles, ~1.3 TB/s chip-wide).  Non-power-of-two splits are allowed.
-// measured choices (w2l_conv1d_wgrad_tune): shape -> split count
+// measured choices (w2l_conv1d_wgrad_tune): shape -> split count | block order << 16
 typedef std::tuple<int, int, int, int, int> WShapeKey;
 std::map<WShapeKey, int> g_wtuned;
 std::mutex g_wtuned_mu;
 int g_force_splits = 0;
+int g_force_order = -1;
+constexpr int kDefaultOrder = 1;
 
-int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out) {
+int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out, int* order_out = nullptr) {
     const int kwb = Kw > 1 ? KWB_DEFAULT : 1;
+    if (order_out) *order_out = g_force_order >= 0 ? g_force_order : kDefaultOrder;
     {
         const int ts = (Tout + BT - 1) / BT;
         if (tsteps_out) *tsteps_out = ts;
         if (g_force_splits > 0) return g_force_splits <= N * ts ? g_force_splits : N * ts;
         std::lock_guard<std::mutex> lock(g_wtuned_mu);
         auto it = g_wtuned.find(WShapeKey(N, Cin, Cout, Tout, Kw));
-        if (it != g_wtuned.end()) return it->second;
+        if (it != g_wtuned.end()) {
+            if (order_out && g_force_order < 0) *order_out = it->second >> 16;
+            return it->second & 0xffff;
+        }
     }
     const int tiles = ((Cout + BM - 1) / BM) * ((Cin + BNC - 1) / BNC) * ((Kw + kwb - 1) / kwb);
     const int tsteps = (Tout + BT - 1) / BT;
@@ -294,7 +354,7 @@ extern "C" int w2l_conv1d_wgrad(const void* dy, int64_t dy_bstride, const void* 
     p.N = N; p.Cin = Cin; p.Cout = Cout; p.Tout = Tout; p.Kw = Kw; p.stride = stride; p.dil = dil;
     p.tiles_m = (Cout + BM - 1) / BM;
     p.tiles_n = (Cin + BNC - 1) / BNC;
-    const int splits = plan_splits(N, Cin, Cout, Tout, Kw, &p.tsteps);
+    const int splits = plan_splits(N, Cin, Cout, Tout, Kw, &p.tsteps, &p.order);
     p.total_steps = N * p.tsteps;
     p.steps_per_split = (p.total_steps + splits - 1) / splits;
     p.atomic = (splits > 1) || accumulate;
@@ -335,9 +395,11 @@ extern "C" int w2l_conv1d_wgrad_tune(const void* dy, int64_t dy_bstride, const v
     float best_ms = 1e30f;
     if (reps < 1) reps = 1;
     const size_t bytes = (size_t)Kw * Cout * Cin * sizeof(float);
-    for (int s : cands) {
-        if (s > total || (s > 1 && total / s < 4)) break;
+    for (int ci = 0; ci < 2 * (int)(sizeof(cands) / sizeof(cands[0])); ++ci) {
+        const int s = cands[ci >> 1], order = ci & 1;
+        if (s > total || s > 0xffff || (s > 1 && total / s < 4)) break;
         g_force_splits = s;
+        g_force_order = order;
         int rc = w2l_conv1d_wgrad(dy, dy_bstride, xp, x_bstride, x_rows_total, dw_scratch, N, Cin, Cout, Tout, Kw, stride, dil,
                                   0, stream);
         if (rc != 0) continue;
@@ -351,9 +413,10 @@ extern "C" int w2l_conv1d_wgrad_tune(const void* dy, int64_t dy_bstride, const v
         if (hipEventSynchronize(e1) != hipSuccess) continue;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
-        if (ms < best_ms) { best_ms = ms; best = s; }
+        if (ms < best_ms) { best_ms = ms; best = s | (order << 16); }
     }
     g_force_splits = 0;
+    g_force_order = -1;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     W2L_CHECK_ARG(best >= 1, "conv1d_wgrad_tune: no candidate ran");
@@ -367,16 +430,16 @@ void w2l_wgrad_tune_dump(FILE* f) {
     std::lock_guard<std::mutex> lock(g_wtuned_mu);
     for (const auto& kv : g_wtuned) {
         const WShapeKey& k = kv.first;
-        fprintf(f, "wgrad %d %d %d %d %d %d\n", std::get<0>(k), std::get<1>(k), std::get<2>(k), std::get<3>(k),
-                std::get<4>(k), kv.second);
+        fprintf(f, "wgrad %d %d %d %d %d %d %d\n", std::get<0>(k), std::get<1>(k), std::get<2>(k), std::get<3>(k),
+                std::get<4>(k), kv.second & 0xffff, kv.second >> 16);
     }
 }
 
-bool w2l_wgrad_tune_put(const int* v) {          // v[0..4] = key, v[5] = split count
-    if (v[5] < 1 || v[0] < 1 || v[3] < 1) return false;
+bool w2l_wgrad_tune_put(const int* v) {          // v[0..4] = key, v[5] = split count, v[6] = block order
+    if (v[5] < 1 || v[5] > 0xffff || v[0] < 1 || v[3] < 1 || v[6] < 0 || v[6] > 1) return false;
     const int ts = (v[3] + BT - 1) / BT;
     if ((int64_t)v[5] > (int64_t)v[0] * ts) return false;
     std::lock_guard<std::mutex> lock(g_wtuned_mu);
-    g_wtuned[WShapeKey(v[0], v[1], v[2], v[3], v[4])] = v[5];
+    g_wtuned[WShapeKey(v[0], v[1], v[2], v[3], v[4])] = v[5] | (v[6] << 16);
     return true;
 }

@@ -64,7 +64,7 @@ extern "C" int w2l_tune_load(const char* path) {
         int v[9];
         if (sscanf(line, "igemm %d %d %d %d %d %d %d %d %d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8) == 9)
             taken += w2l_igemm_tune_put(v) ? 1 : 0;
-        else if (sscanf(line, "wgrad %d %d %d %d %d %d", v, v + 1, v + 2, v + 3, v + 4, v + 5) == 6)
+        else if (sscanf(line, "wgrad %d %d %d %d %d %d %d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6) == 7)
             taken += w2l_wgrad_tune_put(v) ? 1 : 0;
     }
     fclose(f);
