@@ -88,7 +88,9 @@ int w2l_conv1d_igemm_tune(const void* xp, int64_t x_bstride, int64_t x_rows_tota
                           const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout, int Kw, int stride,
                           int dil, int reps, void* stream);
 
-/* tuning hook: force block-shape candidate idx (>= 0) for every later w2l_conv1d_igemm call; -1 = automatic */
+/* tuning hook: force configuration idx (>= 0) for every later w2l_conv1d_igemm call; -1 = automatic.
+ * idx = block shape (0..20) + 21 * K-loop structure (0: barrier at the top of a step, 1: barrier mid-step);
+ * a call whose problem the forced configuration cannot run returns an error. */
 void w2l_conv_force_tile_config(int idx);
 
 /* Conv1d weight gradient (autograd of the same call sites):
@@ -103,7 +105,10 @@ int w2l_conv1d_wgrad(const void* dy, int64_t dy_bstride, const void* xp, int64_t
                      float* dw, int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int accumulate,
                      void* stream);
 
-/* Autotune of the split-K factor, like w2l_conv1d_igemm_tune (SYNCHRONISING, warm-up only); dw_scratch is a
+/* Testing / profiling hook: pin the split count (0 = automatic) and the block order (0/1; -1 = automatic). */
+void w2l_wgrad_force_plan(int splits, int order);
+
+/* Autotune of the split-K factor and block order, like w2l_conv1d_igemm_tune (SYNCHRONISING, warm-up only); dw_scratch is a
  * throw-away [Kw][Cout][Cin] fp32 buffer.  Call before w2l_wgrad_needs_zero() / w2l_conv1d_wgrad for the shape. */
 int w2l_conv1d_wgrad_tune(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride, int64_t x_rows_total,
                           float* dw_scratch, int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int reps,

@@ -156,6 +156,75 @@ def test_conv_igemm_forward(L, case, precise):
     assert relerr(s2, r2) < (2e-2 if not precise else 1e-3)
 
 
+@pytest.mark.parametrize('with_stats', [True, False])
+def test_conv_igemm_every_configuration(L, with_stats):
+    """every block shape x both K-loop structures the autotuner may pick, on a problem with ragged edges in both
+    tile dimensions (Cout = 320: 2.5 / 1.25 / 0.6 tiles; T = 300), stride 1 and the stride-2 shape"""
+    ran = 0
+    for (s, d, Kw, pl, pr) in [(1, 2, 5, 4, 4), (2, 1, 11, 4, 5)]:
+        N, Cin, Cout, T = 2, 128, 320, 300
+        x, w, b = conv_inputs(N, Cin, Cout, Kw, T, pl, pr, 11)
+        xp = to_ntc_padded(x, pl, pr, 1)
+        rows = xp.shape[1]
+        Tout = (rows - (Kw - 1) * d - 1) // s + 1
+        fh, _, _, _, coutp, cinp = pack(L, w, False)
+        xh = xp.to(torch.bfloat16).cuda()
+        bd = b.cuda()
+        ref = F.conv1d(F.pad(bf(x), (pl, pr), mode='reflect'), bf(w), b, stride=s, dilation=d)
+        r1, r2 = ref.sum((0, 2)), (ref * ref).sum((0, 2))
+        tiles = L.lib.w2l_conv_stat_tiles(N, Tout)
+        for idx in range(42):
+            y = torch.full((N, Tout, coutp), float('nan'), dtype=torch.bfloat16, device='cuda')
+            stats = torch.zeros(tiles, 2, coutp, device='cuda')
+            L.lib.w2l_conv_force_tile_config(idx)
+            try:
+                rc = L.lib.w2l_conv1d_igemm(L.ptr(xh), rows * cinp, N * rows, L.ptr(fh), L.ptr(y), 0, 0, L.ptr(bd),
+                                            L.ptr(stats) if with_stats else None, N, cinp, coutp, Tout, Kw, s, d, L.stream_ptr())
+            finally:
+                L.lib.w2l_conv_force_tile_config(-1)
+            if rc != 0:
+                continue                      # this configuration cannot run the problem (statistics need 128-column tiles, ...)
+            torch.cuda.synchronize()
+            ran += 1
+            got = y.float().cpu().transpose(1, 2)
+            assert torch.isfinite(got).all(), idx
+            assert relerr(got, ref) < 1e-2, (idx, relerr(got, ref))
+            if with_stats:
+                assert relerr(stats[:, 1].sum(0).cpu(), r2) < 2e-2, idx
+                assert (stats[:, 0].sum(0).cpu() - r1).abs().max() <= 5e-3 * r2.sqrt().max() * (N * Tout) ** 0.5, idx
+    assert ran >= (28 if with_stats else 40), ran
+
+
+def test_conv_wgrad_every_plan(L):
+    """split counts x both block orders (the autotuner's search space), odd tap count so the last tap group is partial"""
+    N, Cin, Cout, Kw, s, d, T, pl, pr = 3, 192, 320, 5, 1, 2, 333, 4, 4
+    x, w, b = conv_inputs(N, Cin, Cout, Kw, T, pl, pr, 12)
+    xp = to_ntc_padded(x, pl, pr, 1)
+    rows = xp.shape[1]
+    Tout = rows - (Kw - 1) * d
+    dy = torch.randn(N, Cout, Tout, generator=torch.Generator().manual_seed(13))
+    hb = (Kw - 1) * d
+    ha = max(hb, (Tout + 63) // 64 * 64 - Tout)
+    dyp = to_ntc_padded(dy, hb, ha, 0, Cout)
+    drows = dyp.shape[1]
+    dyh, xh = dyp.to(torch.bfloat16).cuda(), xp.to(torch.bfloat16).cuda()
+    wr = bf(w).requires_grad_(True)
+    F.conv1d(F.pad(bf(x), (pl, pr), mode='reflect'), wr, None, dilation=d).backward(bf(dy))
+    for splits in (1, 2, 3, 5, 18):
+        for order in (0, 1):
+            dw = torch.zeros(Kw, Cout, Cin, device='cuda')
+            L.lib.w2l_wgrad_force_plan(splits, order)
+            try:
+                assert L.lib.w2l_wgrad_needs_zero(N, Cin, Cout, Tout, Kw) == int(splits > 1)
+                L.check(L.lib.w2l_conv1d_wgrad(C.c_void_p(dyh.data_ptr() + hb * Cout * 2), drows * Cout, L.ptr(xh), rows * Cin,
+                                               N * rows, L.ptr(dw), N, Cin, Cout, Tout, Kw, s, d, 0, L.stream_ptr()))
+            finally:
+                L.lib.w2l_wgrad_force_plan(0, -1)
+            torch.cuda.synchronize()
+            got = dw.cpu().permute(1, 2, 0)
+            assert relerr(got, wr.grad) < 2e-3, (splits, order, relerr(got, wr.grad))
+
+
 @pytest.mark.parametrize('case', [c for c in CONV_CASES if c[4] == 1])
 @pytest.mark.parametrize('precise', [False, True])
 def test_conv_dgrad(L, case, precise):

@@ -52,6 +52,7 @@ _SIGNATURES = {
     'w2l_conv1d_igemm': (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'w2l_conv1d_igemm_tune': (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'w2l_conv_force_tile_config': (None, [c_i]),
+    'w2l_wgrad_force_plan': (None, [c_i, c_i]),
     'w2l_wgrad_needs_zero': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'w2l_conv1d_wgrad': (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'w2l_conv1d_wgrad_tune': (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -45,7 +45,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base
 
 // MW x NW waves, each owning MS x NS MFMA tiles of 16x16: block tile BM = 16*MW*MS (co) x BN = 16*NW*NS (t)
 // S = conv stride (compile time: the fragment reads then use immediate LDS offsets)
-template <int MW, int NW, int MS, int NS, int S>
+template <int MW, int NW, int MS, int NS, int S, int PIPE>
 __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams p) {
     constexpr int BM = 16 * MW * MS, BN = 16 * NW * NS, NWAVES = MW * NW, NT = 64 * NWAVES;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -122,60 +122,143 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
     const int a_lane1 = (wm * MS * 16 + fr) * ROWB + (((4 + fq) ^ (fr & 7)) << 4);    // k-substep 1: chunk 4+fq
     const int b_row0 = (wn * NS * 16 + fr) * s;      // tile rows ni*16*s further down share (row & 7): NS reads per base
 
-    stage_x(xbuf0, 0);
-    stage_w(wbuf0, 0, 0);
+    // Two K-loop structures are built for every block shape; which one is faster depends on the shape and the
+    // pass (measured by w2l_conv1d_igemm_tune): PIPE = 0 keeps the barrier at the top of a step, PIPE = 1 moves it
+    // to the middle so that the next step's first fragment reads overlap this step's last MFMAs.
+    if constexpr (PIPE == 0) {
+        stage_x(xbuf0, 0);
+        stage_w(wbuf0, 0, 0);
 
-    int kw = 0, c = 0;
-    for (int step = 0; step < nsteps; ++step) {
+        int kw = 0, c = 0;
+        for (int step = 0; step < nsteps; ++step) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // prefetch the next step's tiles into the other buffers
+            int kw_n = kw + 1, c_n = c;
+            if (kw_n == Kw) { kw_n = 0; c_n = c + 1; }
+            if (step + 1 < nsteps) {
+                stage_w((step & 1) ? wbuf0 : wbuf1, kw_n, c_n);
+                if (kw_n == 0) stage_x((c_n & 1) ? xbuf1 : xbuf0, c_n);
+            }
+            const char* wb = (step & 1) ? wbuf1 : wbuf0;
+            const char* xb = (c & 1) ? xbuf1 : xbuf0;
+            const char* A0 = wb + a_lane0;
+            const char* A1 = wb + a_lane1;
+            const int tsh = b_row0 + kw * d;             // LDS row of this lane's first B tile for this tap
+            const int sw0 = ((fq ^ (tsh & 7)) << 4);
+            const char* Bb = xb + (tsh << 7);
+            const char* B0 = Bb + sw0;
+            const char* B1 = Bb + (sw0 ^ 64);            // chunk 4+fq == (chunk fq) ^ 4
+            // both k-substeps' fragments are requested up front (16 ds_read_b128 in flight); the second half lands
+            // while the first half's MFMAs run.  sched_barrier pins that order against the register-pressure scheduler.
+            bf16x8 a0[MS], b0[NS], a1[MS], b1[NS];
+    #pragma unroll
+            for (int mi = 0; mi < MS; ++mi) a0[mi] = *reinterpret_cast<const bf16x8*>(A0 + mi * 16 * ROWB);
+    #pragma unroll
+            for (int ni = 0; ni < NS; ++ni) b0[ni] = *reinterpret_cast<const bf16x8*>(B0 + ni * 16 * S * ROWB);
+    #pragma unroll
+            for (int mi = 0; mi < MS; ++mi) a1[mi] = *reinterpret_cast<const bf16x8*>(A1 + mi * 16 * ROWB);
+    #pragma unroll
+            for (int ni = 0; ni < NS; ++ni) b1[ni] = *reinterpret_cast<const bf16x8*>(B1 + ni * 16 * S * ROWB);
+    #pragma unroll
+            for (int mi = 0; mi < MS; ++mi)
+    #pragma unroll
+                for (int ni = 0; ni < NS; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
+    #pragma unroll
+            for (int mi = 0; mi < MS; ++mi)
+    #pragma unroll
+                for (int ni = 0; ni < NS; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
+            // schedule: ks0 fragment reads, then ks1 reads slotted one per MFMA into the ks0 MFMAs, then the rest
+            __builtin_amdgcn_sched_group_barrier(0x100, MS + NS, 0);
+    #pragma unroll
+            for (int i = 0; i < MS + NS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MS * NS - (MS + NS), 0);
+            kw = kw_n;
+            c = c_n;
+        }
+
+    } else {
+        // fragments of k-substep ks (0/1) of the step whose weights sit in W buffer (stp & 1), for tap kk of chunk cc
+        auto load_frags = [&](int ks, int stp, int cc, int kk, bf16x8* a, bf16x8* b) {
+            const char* wb = (stp & 1) ? wbuf1 : wbuf0;
+            const char* xb = (cc & 1) ? xbuf1 : xbuf0;
+            const char* A = wb + (ks ? a_lane1 : a_lane0);
+            const int tsh = b_row0 + kk * d;             // LDS row of this lane's first B tile for this tap
+            const int sw0 = ((fq ^ (tsh & 7)) << 4);
+            const char* B = xb + (tsh << 7) + (ks ? (sw0 ^ 64) : sw0);      // chunk 4+fq == (chunk fq) ^ 4
+    #pragma unroll
+            for (int mi = 0; mi < MS; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(A + mi * 16 * ROWB);
+    #pragma unroll
+            for (int ni = 0; ni < NS; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(B + ni * 16 * S * ROWB);
+        };
+        auto mfma_all = [&](const bf16x8* a, const bf16x8* b) {
+    #pragma unroll
+            for (int mi = 0; mi < MS; ++mi)
+    #pragma unroll
+                for (int ni = 0; ni < NS; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        };
+        // schedule of one half step: MS+NS fragment reads slotted one per MFMA into the first MFMAs, then the rest
+        auto sched_half = [&]() {
+    #pragma unroll
+            for (int i = 0; i < MS + NS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, MS * NS - (MS + NS), 0);
+        };
+        auto advance = [&](int kk, int cc, int& kk2, int& cc2) {
+            kk2 = kk + 1;
+            cc2 = cc;
+            if (kk2 == Kw) { kk2 = 0; cc2 = cc + 1; }
+        };
+
+        // ---- K loop.  The block-wide barrier sits in the MIDDLE of a step: while the MFMAs of k-substep 1 run, the LDS-DMA
+        // for step+2 is issued and the k-substep-0 fragments of step+1 are already being read, so neither the barrier
+        // skew nor the first fragment reads of a step are exposed (they used to be, once per step, right after the barrier).
+        //   top of step:  a0/b0 (substep 0 of this step) requested; DMA of step+1 in flight into the other buffers
+        //   1. request a1/b1 (substep 1, same buffers), run the substep-0 MFMAs
+        //   2. vmcnt(0) + barrier: every wave has finished READING this step's buffers, and step+1's tiles have landed
+        //   3. DMA step+2 into this step's (now dead) buffers; request a0/b0 of step+1; run the substep-1 MFMAs
+        stage_x(xbuf0, 0);
+        stage_w(wbuf0, 0, 0);
+        int kw = 0, c = 0, kw_n, c_n;
+        advance(kw, c, kw_n, c_n);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        // prefetch the next step's tiles into the other buffers
-        int kw_n = kw + 1, c_n = c;
-        if (kw_n == Kw) { kw_n = 0; c_n = c + 1; }
-        if (step + 1 < nsteps) {
-            stage_w((step & 1) ? wbuf0 : wbuf1, kw_n, c_n);
+        if (nsteps > 1) {
+            stage_w(wbuf1, kw_n, c_n);
             if (kw_n == 0) stage_x((c_n & 1) ? xbuf1 : xbuf0, c_n);
         }
-        const char* wb = (step & 1) ? wbuf1 : wbuf0;
-        const char* xb = (c & 1) ? xbuf1 : xbuf0;
-        const char* A0 = wb + a_lane0;
-        const char* A1 = wb + a_lane1;
-        const int tsh = b_row0 + kw * d;             // LDS row of this lane's first B tile for this tap
-        const int sw0 = ((fq ^ (tsh & 7)) << 4);
-        const char* Bb = xb + (tsh << 7);
-        const char* B0 = Bb + sw0;
-        const char* B1 = Bb + (sw0 ^ 64);            // chunk 4+fq == (chunk fq) ^ 4
-        // both k-substeps' fragments are requested up front (16 ds_read_b128 in flight); the second half lands
-        // while the first half's MFMAs run.  sched_barrier pins that order against the register-pressure scheduler.
         bf16x8 a0[MS], b0[NS], a1[MS], b1[NS];
-#pragma unroll
-        for (int mi = 0; mi < MS; ++mi) a0[mi] = *reinterpret_cast<const bf16x8*>(A0 + mi * 16 * ROWB);
-#pragma unroll
-        for (int ni = 0; ni < NS; ++ni) b0[ni] = *reinterpret_cast<const bf16x8*>(B0 + ni * 16 * S * ROWB);
-#pragma unroll
-        for (int mi = 0; mi < MS; ++mi) a1[mi] = *reinterpret_cast<const bf16x8*>(A1 + mi * 16 * ROWB);
-#pragma unroll
-        for (int ni = 0; ni < NS; ++ni) b1[ni] = *reinterpret_cast<const bf16x8*>(B1 + ni * 16 * S * ROWB);
-#pragma unroll
-        for (int mi = 0; mi < MS; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NS; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-        for (int mi = 0; mi < MS; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NS; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
-        // schedule: ks0 fragment reads, then ks1 reads slotted one per MFMA into the ks0 MFMAs, then the rest
-        __builtin_amdgcn_sched_group_barrier(0x100, MS + NS, 0);
-#pragma unroll
-        for (int i = 0; i < MS + NS; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        load_frags(0, 0, c, kw, a0, b0);
+        for (int step = 0; step + 1 < nsteps; ++step) {
+            load_frags(1, step, c, kw, a1, b1);
+            mfma_all(a0, b0);
+            sched_half();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int kw_nn, c_nn;
+            advance(kw_n, c_n, kw_nn, c_nn);
+            if (step + 2 < nsteps) {
+                stage_w((step & 1) ? wbuf1 : wbuf0, kw_nn, c_nn);
+                if (kw_nn == 0) stage_x((c_nn & 1) ? xbuf1 : xbuf0, c_nn);
+            }
+            load_frags(0, step + 1, c_n, kw_n, a0, b0);
+            mfma_all(a1, b1);
+            sched_half();
+            kw = kw_n; c = c_n;
+            kw_n = kw_nn; c_n = c_nn;
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MS * NS - (MS + NS), 0);
-        kw = kw_n;
-        c = c_n;
+        load_frags(1, nsteps - 1, c, kw, a1, b1);
+        mfma_all(a0, b0);
+        mfma_all(a1, b1);
+
     }
 
     // ---- epilogue: bias, optional accumulate, store, BatchNorm partial statistics ----
@@ -268,11 +351,11 @@ constexpr TileCfg kCfgs[] = {
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-template <int MW, int NW, int MS, int NS>
-int launch_cfg(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream) {
+template <int MW, int NW, int MS, int NS, int PIPE>
+int launch_cfg1(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream) {
     if (p.stride == 2) {
         if constexpr (MW == 2 && NW == 2 && MS == 4 && NS == 4) {
-            auto kern2 = conv_igemm_kernel<2, 2, 4, 4, 2>;
+            auto kern2 = conv_igemm_kernel<2, 2, 4, 4, 2, PIPE>;
             W2L_CHECK_HIP(w2l_allow_big_lds((const void*)kern2));
             hipLaunchKernelGGL(kern2, dim3(tiles_m * p.ncols), dim3(256), lds, stream, p);
             W2L_CHECK_LAUNCH();
@@ -282,15 +365,21 @@ int launch_cfg(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream
             return 1;
         }
     }
-    auto kern = conv_igemm_kernel<MW, NW, MS, NS, 1>;
+    auto kern = conv_igemm_kernel<MW, NW, MS, NS, 1, PIPE>;
     W2L_CHECK_HIP(w2l_allow_big_lds((const void*)kern));
     hipLaunchKernelGGL(kern, dim3(tiles_m * p.ncols), dim3(64 * MW * NW), lds, stream, p);
     W2L_CHECK_LAUNCH();
     return 0;
 }
 
+template <int MW, int NW, int MS, int NS>
+int launch_cfg(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream, int pipe) {
+    return pipe ? launch_cfg1<MW, NW, MS, NS, 1>(p, tiles_m, lds, stream) : launch_cfg1<MW, NW, MS, NS, 0>(p, tiles_m, lds, stream);
+}
+
 }  // namespace
 
+// A configuration index is (block shape) + kNumCfgs * (K-loop structure PIPE).
 static int g_force_cfg = -1;
 extern "C" void w2l_conv_force_tile_config(int idx) { g_force_cfg = idx; }
 
@@ -304,7 +393,9 @@ typedef std::tuple<int, int, int, int, int, int, int, int> ShapeKey;
 static std::map<ShapeKey, int> g_tuned;
 static std::mutex g_tuned_mu;
 
-static bool cfg_feasible(int i, int Kw, int stride, int dil, bool need_bn128) {
+static bool cfg_feasible(int idx, int Kw, int stride, int dil, bool need_bn128) {
+    if (idx < 0 || idx >= 2 * kNumCfgs) return false;
+    const int i = idx % kNumCfgs;
     const TileCfg& c = kCfgs[i];
     const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
     if (need_bn128 && bn % 128 != 0) return false;
@@ -322,14 +413,15 @@ static int choose_cfg(int N, int Cin, int Cout, int Tout, int Kw, int stride, in
         auto it = g_tuned.find(ShapeKey(N, Cin, Cout, Tout, Kw, stride, dil, need_bn128 ? 1 : 0));
         if (it != g_tuned.end()) return it->second;
     }
-    int best = -1;
+    if (g_force_cfg >= 0) return cfg_feasible(g_force_cfg, Kw, stride, dil, need_bn128) ? g_force_cfg : -1;
+    int best = -1;                                     // the cost model only ranks the PIPE = 0 variants
     double best_cost = 1e30;
     for (int i = 0; i < kNumCfgs; ++i) {
         const TileCfg& c = kCfgs[i];
         const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
         if (need_bn128 && bn % 128 != 0) continue;     // BatchNorm partial statistics are per 128-column tile
         if (stride != 1 && i != 2) continue;          // strided convs (first layer only) use the 128x128 shape
-        if (g_force_cfg >= 0 && g_force_cfg < kNumCfgs && i != g_force_cfg) continue;
+        if (i == 20) continue;
         const size_t lds = 2 * (size_t)bm * ROWB + 2 * (size_t)cfg_xrows(c, stride, Kw, dil) * ROWB;
         if (lds > 160 * 1024) continue;
         const int waves = c.mw * c.nw;
@@ -378,7 +470,8 @@ extern "C" int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_row
     // BatchNorm partial statistics are laid out per 128-row column tile (w2l_conv_stat_tiles)
     const int ci = choose_cfg(N, Cin, Cout, Tout, Kw, stride, dil, stats_partial != nullptr);
     W2L_CHECK_ARG(ci >= 0, "conv1d_igemm: no block shape fits LDS (Kw=%d dil=%d stride=%d)", Kw, dil, stride);
-    const TileCfg& c = kCfgs[ci];
+    const int pipe = ci / kNumCfgs;
+    const TileCfg& c = kCfgs[ci % kNumCfgs];
     const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
     p.tiles_t = (Tout + bn - 1) / bn;
     p.ncols = N * p.tiles_t;
@@ -386,28 +479,28 @@ extern "C" int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_row
     const int tiles_m = (Cout + bm - 1) / bm;
     const size_t lds = 2 * (size_t)bm * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
     hipStream_t st = (hipStream_t)stream;
-    switch (ci) {
-        case 0: return launch_cfg<2, 2, 2, 4>(p, tiles_m, lds, st);
-        case 1: return launch_cfg<2, 2, 3, 4>(p, tiles_m, lds, st);
-        case 2: return launch_cfg<2, 2, 4, 4>(p, tiles_m, lds, st);
-        case 3: return launch_cfg<2, 2, 5, 4>(p, tiles_m, lds, st);
-        case 4: return launch_cfg<4, 2, 3, 4>(p, tiles_m, lds, st);
-        case 5: return launch_cfg<4, 2, 4, 4>(p, tiles_m, lds, st);
-        case 6: return launch_cfg<2, 3, 2, 3>(p, tiles_m, lds, st);
-        case 7: return launch_cfg<2, 3, 3, 3>(p, tiles_m, lds, st);
-        case 8: return launch_cfg<2, 3, 4, 3>(p, tiles_m, lds, st);
-        case 9: return launch_cfg<2, 3, 5, 3>(p, tiles_m, lds, st);
-        case 10: return launch_cfg<2, 4, 2, 4>(p, tiles_m, lds, st);
-        case 11: return launch_cfg<2, 4, 3, 4>(p, tiles_m, lds, st);
-        case 12: return launch_cfg<2, 4, 4, 4>(p, tiles_m, lds, st);
-        case 13: return launch_cfg<2, 4, 5, 4>(p, tiles_m, lds, st);
-        case 14: return launch_cfg<2, 4, 6, 4>(p, tiles_m, lds, st);
-        case 15: return launch_cfg<2, 4, 7, 4>(p, tiles_m, lds, st);
-        case 16: return launch_cfg<2, 4, 8, 4>(p, tiles_m, lds, st);
-        case 17: return launch_cfg<2, 3, 4, 6>(p, tiles_m, lds, st);
-        case 18: return launch_cfg<2, 3, 5, 6>(p, tiles_m, lds, st);
-        case 19: return launch_cfg<2, 3, 6, 6>(p, tiles_m, lds, st);
-        default: return launch_cfg<2, 3, 7, 6>(p, tiles_m, lds, st);
+    switch (ci % kNumCfgs) {
+        case 0: return launch_cfg<2, 2, 2, 4>(p, tiles_m, lds, st, pipe);
+        case 1: return launch_cfg<2, 2, 3, 4>(p, tiles_m, lds, st, pipe);
+        case 2: return launch_cfg<2, 2, 4, 4>(p, tiles_m, lds, st, pipe);
+        case 3: return launch_cfg<2, 2, 5, 4>(p, tiles_m, lds, st, pipe);
+        case 4: return launch_cfg<4, 2, 3, 4>(p, tiles_m, lds, st, pipe);
+        case 5: return launch_cfg<4, 2, 4, 4>(p, tiles_m, lds, st, pipe);
+        case 6: return launch_cfg<2, 3, 2, 3>(p, tiles_m, lds, st, pipe);
+        case 7: return launch_cfg<2, 3, 3, 3>(p, tiles_m, lds, st, pipe);
+        case 8: return launch_cfg<2, 3, 4, 3>(p, tiles_m, lds, st, pipe);
+        case 9: return launch_cfg<2, 3, 5, 3>(p, tiles_m, lds, st, pipe);
+        case 10: return launch_cfg<2, 4, 2, 4>(p, tiles_m, lds, st, pipe);
+        case 11: return launch_cfg<2, 4, 3, 4>(p, tiles_m, lds, st, pipe);
+        case 12: return launch_cfg<2, 4, 4, 4>(p, tiles_m, lds, st, pipe);
+        case 13: return launch_cfg<2, 4, 5, 4>(p, tiles_m, lds, st, pipe);
+        case 14: return launch_cfg<2, 4, 6, 4>(p, tiles_m, lds, st, pipe);
+        case 15: return launch_cfg<2, 4, 7, 4>(p, tiles_m, lds, st, pipe);
+        case 16: return launch_cfg<2, 4, 8, 4>(p, tiles_m, lds, st, pipe);
+        case 17: return launch_cfg<2, 3, 4, 6>(p, tiles_m, lds, st, pipe);
+        case 18: return launch_cfg<2, 3, 5, 6>(p, tiles_m, lds, st, pipe);
+        case 19: return launch_cfg<2, 3, 6, 6>(p, tiles_m, lds, st, pipe);
+        default: return launch_cfg<2, 3, 7, 6>(p, tiles_m, lds, st, pipe);
     }
 }
 
@@ -431,7 +524,7 @@ extern "C" int w2l_conv1d_igemm_tune(const void* xp, int64_t x_bstride, int64_t 
     float best_ms = 1e30f;
     const int saved = g_force_cfg;
     if (reps < 1) reps = 1;
-    for (int i = 0; i < kNumCfgs; ++i) {
+    for (int i = 0; i < 2 * kNumCfgs; ++i) {
         if (!cfg_feasible(i, Kw, stride, dil, need128)) continue;
         g_force_cfg = i;
         int rc = w2l_conv1d_igemm(xp, x_bstride, x_rows_total, w, y, y_f32, 0, bias, stats_partial, N, Cin, Cout, Tout, Kw,
@@ -467,7 +560,7 @@ void w2l_igemm_tune_dump(FILE* f) {
 }
 
 bool w2l_igemm_tune_put(const int* v) {          // v[0..7] = key, v[8] = block-shape index
-    if (v[8] < 0 || v[8] >= kNumCfgs || !cfg_feasible(v[8], v[4], v[5], v[6], v[7] != 0)) return false;
+    if (!cfg_feasible(v[8], v[4], v[5], v[6], v[7] != 0)) return false;
     std::lock_guard<std::mutex> lock(g_tuned_mu);
     g_tuned[ShapeKey(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])] = v[8];
     return true;

@@ -331,6 +331,12 @@ int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out, int
 
 }  // namespace
 
+// testing / profiling hook: pin the split count (0 = automatic) and the block order (-1 = automatic)
+extern "C" void w2l_wgrad_force_plan(int splits, int order) {
+    g_force_splits = splits > 0 ? splits : 0;
+    g_force_order = order >= 0 ? (order ? 1 : 0) : -1;
+}
+
 extern "C" int w2l_wgrad_needs_zero(int N, int Cin, int Cout, int Tout, int Kw) {
     return plan_splits(N, Cin, Cout, Tout, Kw, nullptr) > 1;
 }
