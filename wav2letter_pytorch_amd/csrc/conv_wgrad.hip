@@ -183,79 +183,96 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     }
     int a_toggle = BT * ROWB, b_toggle = xrows * ROWB;
 
-    // One K step (64 rows) of the block for NT live taps, software-pipelined inside the wave: the transposing reads of
-    // fragment group g+1 are issued before the 16 MFMAs of group g (groups ordered ks-major, tap-minor; A fragments
-    // are re-read only when ks changes), so LDS latency hides behind this wave's own MFMAs and not only behind the
-    // other resident block's.  NT is a template-like constant (branch-free body: the compiler may not move reads
-    // across a branch).
-    auto compute = [&](auto nt_tag) {
-        constexpr int NT = decltype(nt_tag)::value;
-        bf16x8 a[4], b[2][4];
-        auto load_a1 = [&](int i, int ks) {
+    // ---- K loop, software-pipelined inside the wave and across the block barrier -------------------------------
+    // A step (64 rows) is NG = 2*NT fragment groups (ks-major, tap-minor), 16 MFMAs each.
+    //  * the transposing reads of group g+1 are issued before the MFMAs of group g (B fragments double-buffered;
+    //    A fragments are refilled in place, row by row, as the last group that uses them retires each row);
+    //  * the block barrier sits BEFORE THE LAST GROUP of a step: by then every read of the step's buffers has been
+    //    issued and completed, so after the barrier the LDS-DMA for step+2 goes into those buffers, the first
+    //    fragments of step+1 are requested from the other buffers, and all of it hides behind the last 16 MFMAs.
+    // NT / LAST are compile-time so that each body is straight-line code with in-place accumulators (the compiler
+    // does not move reads across a branch).
+    bf16x8 a[4], b[2][4];
+    auto load_a1 = [&](int i, int ks) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const bf16x4 va = tr_read(pa[i] + (ks * 32 + h * 4) * ROWB);
+        for (int h = 0; h < 2; ++h) {
+            const bf16x4 va = tr_read(pa[i] + (ks * 32 + h * 4) * ROWB);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a[i][h * 4 + e] = va[e];
+            for (int e = 0; e < 4; ++e) a[i][h * 4 + e] = va[e];
+        }
+    };
+    auto load_b = [&](bf16x8* dst, int tp, int ks) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x4 vb = tr_read(pb[tp][h][i] + ks * 32 * s * ROWB);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[i][h * 4 + e] = vb[e];
             }
-        };
-        auto load_b = [&](bf16x8* dst, int tp, int ks) {
+    };
+    auto toggle = [&]() {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+        for (int i = 0; i < 4; ++i) {
+            pa[i] += a_toggle;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bf16x4 vb = tr_read(pb[tp][h][i] + ks * 32 * s * ROWB);
+            for (int tp = 0; tp < KWB; ++tp)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dst[i][h * 4 + e] = vb[e];
-                }
-        };
+                for (int h = 0; h < 2; ++h) pb[tp][h][i] += b_toggle;
+        }
+        a_toggle = -a_toggle;
+        b_toggle = -b_toggle;
+    };
+    // one step; on entry a[] = A(ks 0) and b[0] = B(tap 0, ks 0) of this step are requested
+    auto step_body = [&](auto nt_tag, auto last_tag, char* adst, char* bdst, int n_nn, int ts_nn, bool have_nn) {
+        constexpr int NT = decltype(nt_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;
         constexpr int NG = (BT / 32) * NT;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) load_a1(i, 0);
-        load_b(b[0], 0, 0);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int ks = g / NT, tp = g % NT;
-            const bool more = g + 1 < NG;
+            const bool lastg = g + 1 == NG;
             const int ks2 = (g + 1) / NT, tp2 = (g + 1) % NT;
-            if (more) load_b(b[(g + 1) & 1], tp2, ks2);          // B fragments are double-buffered
+            if (!lastg) load_b(b[(g + 1) & 1], tp2, ks2);
+            if (lastg && !LAST) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step+1's tiles (this wave's part) have landed
+                __syncthreads();                                    // ... everyone's; and nobody reads this step's buffers any more
+                toggle();                                           // read pointers -> step+1's buffers
+                if (have_nn) stage(adst, bdst, n_nn, ts_nn);        // step+2 -> this step's buffers
+                load_b(b[(g + 1) & 1], 0, 0);
+            }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
                     acc[tp][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[g & 1][ni], acc[tp][mi][ni], 0, 0, 0);
-                // A fragments are refilled in place, row by row, as the last tap group of this ks retires them
-                if (more && ks2 != ks) load_a1(mi, ks2);
+                if (!lastg && ks2 != ks) load_a1(mi, ks2);
+                if (lastg && !LAST) load_a1(mi, 0);
             }
         }
     };
-
-    // the whole K loop exists once per live-tap count (the branch sits outside the loop so that each loop body is
-    // straight-line code with in-place accumulators)
+    auto advance = [&](int& n, int& ts) {
+        if (++ts == p.tsteps) { ts = 0; ++n; }
+    };
+    // the whole K loop exists once per live-tap count (branch outside the loop)
     auto run = [&](auto nt_tag) {
-        int n_cur = step_begin / p.tsteps;
-        int ts_cur = step_begin - n_cur * p.tsteps;
-        if (step_begin < step_end) stage(abuf0, bbuf0, n_cur, ts_cur);
-        for (int step = step_begin; step < step_end; ++step) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+        if (step_begin >= step_end) return;
+        int n = step_begin / p.tsteps;
+        int ts = step_begin - n * p.tsteps;
+        stage(abuf0, bbuf0, n, ts);
+        advance(n, ts);                                   // (n, ts): coordinates of step+1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (step_begin + 1 < step_end) stage(abuf1, bbuf1, n, ts);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_a1(i, 0);
+        load_b(b[0], 0, 0);
+        for (int step = step_begin; step + 1 < step_end; ++step) {
             const int par = (step - step_begin) & 1;
-            int ts_n = ts_cur + 1, n_n = n_cur;
-            if (ts_n == p.tsteps) { ts_n = 0; ++n_n; }
-            if (step + 1 < step_end) stage(par ? abuf0 : abuf1, par ? bbuf0 : bbuf1, n_n, ts_n);
-            n_cur = n_n; ts_cur = ts_n;
-            compute(nt_tag);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                pa[i] += a_toggle;
-#pragma unroll
-                for (int tp = 0; tp < KWB; ++tp)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) pb[tp][h][i] += b_toggle;
-            }
-            a_toggle = -a_toggle;
-            b_toggle = -b_toggle;
+            advance(n, ts);                               // now step+2
+            step_body(nt_tag, std::false_type{}, par ? abuf1 : abuf0, par ? bbuf1 : bbuf0, n, ts, step + 2 < step_end);
         }
+        step_body(nt_tag, std::true_type{}, nullptr, nullptr, 0, 0, false);
     };
     if (KWB == 1 || ntaps == KWB) run(std::integral_constant<int, KWB>{});
     else run(std::integral_constant<int, 1>{});
