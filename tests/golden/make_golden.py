@@ -329,9 +329,72 @@ def novograd_fixture():
     print('novograd_cases.npz', out['plain/p4_1'])
 
 
+def features_fixture():
+    """Feature front-end, collate and augmentation vectors from the reference's own data/data_loader.py and
+    data/augmentations.py.  data_loader.py needs three things this image lacks: librosa (absent), soundfile (absent; not
+    used by the functions called here) and the scipy.signal window aliases removed from modern scipy (module-level dict,
+    data_loader.py:18; aliased to scipy.signal.windows.* -- never called).  librosa.filters.mel is given the oracle's
+    restatement of librosa's published algorithm (oracle/features_oracle.py), so the fixture pins everything EXCEPT the
+    mel matrix itself, which is saved alongside."""
+    import random
+    import scipy.signal
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import features_oracle as FO
+    _install_stubs()
+    for w in ('hamming', 'hann', 'blackman', 'bartlett'):
+        if not hasattr(scipy.signal, w):
+            setattr(scipy.signal, w, getattr(scipy.signal.windows, w))
+    librosa = sys.modules['librosa']
+    filt = types.ModuleType('librosa.filters')
+    filt.mel = lambda sr, n_fft, n_mels, fmin, fmax: FO.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    librosa.filters = filt
+    sys.modules['librosa.filters'] = filt
+    sys.modules.pop('data', None)
+    data = types.ModuleType('data')
+    data.__path__ = [os.path.join(REF, 'data')]
+    sys.modules['data'] = data
+    dl = importlib.import_module('data.data_loader')
+    aug = importlib.import_module('data.augmentations')
+    conf = Cfg(window='hamming', window_stride=0.01, window_size=0.02, sample_rate=16000)
+    ext = dl.SpectrogramExtractor(conf, mel_spec=64)
+    out = {'fb': ext.fb[0].numpy().copy(), 'window': ext.window.numpy().copy(), 'n_fft': np.array(ext.n_fft)}
+    g = np.random.default_rng(5)
+    specs = []
+    for i, L in enumerate((4000, 16000, 1237, 9613)):
+        t = np.arange(L) / 16000.0
+        audio = (0.3 * np.sin(2 * np.pi * (200 + 150 * i) * t * (1 + 0.5 * t)) + 0.05 * g.standard_normal(L)).astype(np.float32)
+        torch.manual_seed(100 + i)
+        noise = torch.randn(audio.shape).numpy().copy()
+        torch.manual_seed(100 + i)
+        spect = ext.extract(audio)
+        spect = spect.numpy() if torch.is_tensor(spect) else np.asarray(spect)
+        out[f'audio{i}'], out[f'noise{i}'], out[f'spect{i}'] = audio, noise, spect.astype(np.float32)
+        specs.append(spect.astype(np.float32))
+    out['n_cases'] = np.array(4)
+    # _collator (data_loader.py:149-158)
+    targets = [[3, 5, 7], [1], [2, 2, 9, 28, 4], [6, 6]]
+    batch_ = [(specs[i], targets[i], 'f%d.wav' % i, 't%d' % i) for i in range(4)]
+    inputs, il, tg, tl, paths, texts = dl._collator(batch_)
+    out['col_inputs'], out['col_il'], out['col_tg'], out['col_tl'] = inputs.numpy(), il.numpy(), tg.numpy(), tl.numpy()
+    out['col_targets'] = np.array(targets, dtype=object)
+    # SpecAugment / SpecCutout (augmentations.py) with a seeded random.Random
+    gx = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 64, 211, generator=gx)
+    out['aug_x'] = x.numpy().copy()
+    out['specaug'] = aug.SpecAugment(freq_masks=2, time_masks=2, freq_width=15, time_width=50, rng=random.Random(11))(x).numpy()
+    out['speccut'] = aug.SpecCutout(rect_masks=5, rect_time=60, rect_freq=25, rng=random.Random(12))(x).numpy()
+    xs = torch.randn(2, 64, 37, generator=gx)          # shorter than time_width: negative lefts, Python slice semantics
+    out['aug_xs'] = xs.numpy().copy()
+    out['specaug_short'] = aug.SpecAugment(freq_masks=1, time_masks=2, freq_width=15, time_width=50, rng=random.Random(13))(xs).numpy()
+    np.savez_compressed(os.path.join(HERE, 'features.npz'), **out)
+    print('features.npz', [out[f'spect{i}'].shape for i in range(4)], float(np.abs(out['spect1']).max()))
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'novograd':
         novograd_fixture()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'features':
+        features_fixture()
     else:
         main()
         novograd_fixture()

@@ -300,6 +300,8 @@ class StackEngine:
         self._side = None
         self._side_used = False
         self._held: list = []        # tensors in use by side-stream kernels; released after the join in backward()
+        self._nbt_pending: list = []  # num_batches_tracked buffers to bump (one fused launch per forward)
+        self._zero_pool = None       # (buffer, offset): the identically-zero conv-bias gradients of one backward
 
     # ------------------------------------------------------------------ parameters
     def parameters(self) -> List[torch.Tensor]:
@@ -411,6 +413,9 @@ class StackEngine:
         out = torch.empty(N, Th, self.n_labels, dtype=torch.float32, device=dev)
         check(lib.w2l_log_softmax_fwd(ptr(logits), N, Th, self.n_labels, logits.shape[2], softmax_mode, ptr(out), st()),
               'w2l_log_softmax_fwd')
+        if self._nbt_pending:
+            torch._foreach_add_(self._nbt_pending, 1)
+            self._nbt_pending = []
         ctx['acts'] = acts
         ctx['out'] = out
         ctx['softmax_mode'] = softmax_mode
@@ -526,7 +531,7 @@ class StackEngine:
                 rm.copy_(rm_p[: rm.numel()])
                 rv.copy_(rv_p[: rv.numel()])
             if conv.num_batches_tracked is not None:
-                conv.num_batches_tracked += 1
+                self._nbt_pending.append(conv.num_batches_tracked)     # one foreach add at the end of forward
         else:
             check(lib.w2l_bn_finalize(None, 0, cp, 1, ptr(gamma), ptr(beta), conv.eps, conv.momentum, ptr(rm_p),
                                       ptr(rv_p), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), stream_ptr()),
@@ -637,7 +642,7 @@ class StackEngine:
             self._wgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, grads)
             if main.bias is not None:
                 if main.has_bn:      # sum(dy) == 0 identically under BatchNorm
-                    self._set(grads, main.bias, torch.zeros(main.cout, dtype=torch.float32, device=dev))
+                    self._set(grads, main.bias, self._zeros(main.cout, dev))
                 else:
                     dyv = dy_hi[h1:].view(N, Tout + h1, coutp)[:, :Tout, : main.cout]
                     self._set(grads, main.bias, dyv.float().sum((0, 1)))
@@ -653,7 +658,7 @@ class StackEngine:
                 rsrc = acts[u.res_src]
                 self._wgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc, grads)
                 if res.bias is not None:
-                    self._set(grads, res.bias, torch.zeros(res.cout, dtype=torch.float32, device=dev))
+                    self._set(grads, res.bias, self._zeros(res.cout, dev))
                 if self._needs_grad(u.res_src, ctx):
                     act_grads[u.res_src].append(self._dgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc))
         ctx['input_grad'] = self.input_grad(ctx, act_grads[0]) if ctx.get('want_dx') and act_grads[0] else None
@@ -661,6 +666,7 @@ class StackEngine:
             torch.cuda.current_stream(dev).wait_stream(self._side)
             self._side_used = False
         self._held.clear()
+        self._zero_pool = None
         _flush_tune_cache()
         if self.backward_done is not None:
             self.backward_done()
@@ -691,6 +697,22 @@ class StackEngine:
             total = total * (t < a0.lens.long()[:, None, None])
         return total.transpose(1, 2).contiguous()
 
+    def _zeros(self, n: int, dev) -> torch.Tensor:
+        """an fp32 zero vector carved from one zero-filled buffer per backward (one fill launch instead of one per layer)"""
+        need = roundup(n, 64)
+        pool = self._zero_pool
+        if pool is None or pool[0].device != dev or pool[1] + need > pool[0].numel():
+            total = 0
+            for u in self.units:
+                for c in (u.main, u.res):
+                    if c is not None and c.bias is not None and c.has_bn:
+                        total += roundup(c.cout, 64)
+            pool = [torch.zeros(max(total, need), dtype=torch.float32, device=dev), 0]
+            self._zero_pool = pool
+        out = pool[0][pool[1]: pool[1] + n]
+        pool[1] += need
+        return out
+
     def _notify(self, param, grad, storage=None):
         if self.grad_ready is not None:
             self.grad_ready(param, grad, storage)
@@ -717,6 +739,8 @@ class StackEngine:
             return self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads)
         main = torch.cuda.current_stream(dy_hi.device)
         if self._side is None or self._side.device != dy_hi.device:
+            # a stream from torch's pool at default priority: streams created with hipStreamCreateWithPriority (lowest OR
+            # highest) made the whole step 30 % slower on MI355X (18.8 vs 14.3 ms, profiles/r01 notes in DESIGN.md)
             self._side = torch.cuda.Stream(device=dy_hi.device)
         side = self._side
         self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads, fork=(main, side))
@@ -746,16 +770,21 @@ class StackEngine:
                                                 ptr(scratch), N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, 2,
                                                 stream_ptr()), 'w2l_conv1d_wgrad_tune')
         need_zero = bool(lib.w2l_wgrad_needs_zero(N, pk.cinp, pk.coutp, Tout, kw)) or self.precise
-        alloc = torch.zeros if need_zero else torch.empty
-        dw = alloc(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
         if fork is not None:
+            # allocated on the main stream (the caching allocator then owns it there), zero-filled on the side stream:
+            # the fill of a split-K gradient is as far off the critical path as the kernel that accumulates into it
+            dw = torch.empty(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
             ev = torch.cuda.Event()
             ev.record(fork[0])
             fork[1].wait_event(ev)
             self._held.append(dw)
             with torch.cuda.stream(fork[1]):
+                if need_zero:
+                    dw.zero_()
                 return self._wgrad_launch(conv, pk, dw, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total,
                                           dy_bstride, row_off, direct)
+        alloc = torch.zeros if need_zero else torch.empty
+        dw = alloc(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
         return self._wgrad_launch(conv, pk, dw, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total, dy_bstride,
                                   row_off, direct)
 
