@@ -213,6 +213,28 @@ int w2l_argmax(const float* probs, int64_t rows, int C, int32_t* idx, void* stre
 /* host-side edit distance over int32 symbol arrays */
 int w2l_levenshtein_host(const int32_t* a_host, int na, const int32_t* b_host, int nb);
 
+/* ---- feature front-end (SpectrogramExtractor, data/data_loader.py:33-88) and augmentation masks ----------------
+ * w2l_logmel: per utterance n (n_samples[n] samples of audio[n*audio_stride ...], fp32, device):
+ *   x = audio + dither * noise (noise = N(0,1) draws, may be NULL: no dither)   data_loader.py:67
+ *   x[i] -= preemph * x[i-1] for i >= 1                                         data_loader.py:68
+ *   torch.stft(n_fft, hop, win_length, window, center=True [reflect pad n_fft/2]) -> 1 + n_samples/hop frames   :55-63,69
+ *   power = (sqrt(re^2 + im^2))^2; mel = fb . power  (_get_spect's result: take_log == 0)            :70-72
+ *   logmel = log1p(mel + log_guard)                  (take_log != 0)                                  :78-79
+ * fbT is the filterbank transposed, [n_fft/2 + 1][n_mels]; fb_range (optional) [n_mels][2] int32 = first and one-past-last
+ * non-zero bin of each filter (only that run is summed; NULL = all bins).  Output logmel[N][Tmax][n_mels]; frames past an utterance's
+ * own count are written as 0.  Requires n_samples[n] > n_fft/2 (torch's reflect-pad rule), n_fft a power of two <= 1024.
+ * w2l_feature_normalize: per (utterance, feature) mean and UNBIASED std over the utterance's frames, std += eps,
+ *   out[n][m][t] = (logmel - mean) / std for t < frames(n), 0 beyond: the right-zero-padded batch layout of _collator
+ *   (data_loader.py:80-88,149-158).  mean_ws / std_ws: [N][n_mels] fp32 workspaces (returned filled). */
+int w2l_logmel(const float* audio, const int32_t* n_samples, const float* noise, float dither, float preemph, int N,
+               int64_t audio_stride, const float* window, int win_length, int n_fft, int hop, const float* fbT,
+               const int32_t* fb_range, int n_mels, int take_log, float log_guard, float* logmel, int Tmax, void* stream);
+int w2l_feature_normalize(const float* logmel, const int32_t* n_samples, int hop, int N, int Tmax, int n_mels, float eps,
+                          float* mean_ws, float* std_ws, float* out_nct, void* stream);
+/* x[n][f0:f1][t0:t1] = 0 for each of R rectangles rects[r] = {n, f0, f1, t0, t1} (int32, device; clipped to the tensor):
+ * the masked_fill of SpecAugment.forward / SpecCutout.forward (data/augmentations.py:56,97); x fp32 [N][C][T]. */
+int w2l_zero_rects(float* x, int N, int C, int T, const int32_t* rects, int R, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

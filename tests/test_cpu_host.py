@@ -278,3 +278,27 @@ def test_tune_cache_roundtrip(tmp_path):
     bad = tmp_path / 'bad.txt'
     bad.write_text('something else\n')
     assert L.lib.w2l_tune_load(str(bad).encode()) == -1
+
+
+def test_data_loader_host_side(tmp_path):
+    """load_audio (stdlib WAV path), manifest parsing, target mapping and the host collate (data_loader.py:20-31,90-158)"""
+    import wave
+    from wav2letter_pytorch_amd.data import data_loader as DL
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'features.npz'), allow_pickle=True)
+    sig = (np.sin(np.arange(3200) * 0.01) * 0.5).astype(np.float32)
+    p = str(tmp_path / 'a.wav')
+    with wave.open(p, 'wb') as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes((sig * 32767).astype('<i2').tobytes())
+    a = DL.load_audio(p)
+    assert a.dtype == np.float32 and a.shape == (3200,) and np.abs(a - sig).max() < 1e-4
+    assert DL.load_audio(p, duration=0.05, offset=0.1).shape == (800,)
+    assert DL._sample_rate(p) == 16000
+    items = [(torch.from_numpy(z[f'spect{i}']), list(z['col_targets'][i]), 'f', 't') for i in range(int(z['n_cases']))]
+    inputs, il, tg, tl, _, _ = DL._collator(items)
+    np.testing.assert_array_equal(inputs.numpy(), z['col_inputs'])
+    np.testing.assert_array_equal(il.numpy(), z['col_il'])
+    np.testing.assert_array_equal(tg.numpy(), z['col_tg'])
+    np.testing.assert_array_equal(tl.numpy(), z['col_tl'])
+    with pytest.raises(RuntimeError):                   # no CPU feature path
+        DL.SpectrogramExtractor(dict(window='hamming', window_stride=0.01, window_size=0.02, sample_rate=16000), 64)

@@ -1,0 +1,177 @@
+"""Feature front-end and augmentation masks on the GPU vs the CPU oracle and the reference-generated
+fixture tests/golden/features.npz (data/data_loader.py:33-88,149-158; data/augmentations.py)."""
+import json
+import os
+import random
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CONF = dict(window='hamming', window_stride=0.01, window_size=0.02, sample_rate=16000)
+# fp32 features after mean/std normalisation are O(1); the device FFT (radix-2 in LDS) and torch's CPU FFT differ by
+# ~1e-6 of the largest bin, which log1p + the division by the per-feature std turn into a few 1e-5 absolute
+TOL = 2e-4
+
+
+@pytest.fixture(scope='module')
+def fx():
+    return np.load(os.path.join(HERE, 'golden', 'features.npz'), allow_pickle=True)
+
+
+@pytest.fixture(scope='module')
+def ext():
+    from wav2letter_pytorch_amd.data.data_loader import SpectrogramExtractor
+    return SpectrogramExtractor(CONF, mel_spec=64)
+
+
+def test_extract_matches_reference_fixture(fx, ext):
+    assert ext.n_fft == int(fx['n_fft'])
+    np.testing.assert_array_equal(ext.fb[0].cpu().numpy(), fx['fb'])
+    np.testing.assert_allclose(ext.window.cpu().numpy(), fx['window'], rtol=0, atol=1e-7)
+    for i in range(int(fx['n_cases'])):
+        got = ext.extract(fx[f'audio{i}'], noise=fx[f'noise{i}']).cpu().numpy()
+        want = fx[f'spect{i}']
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() < TOL, (i, np.abs(got - want).max())
+
+
+def test_mel_power_matches_oracle(fx, ext):
+    from oracle import features_oracle as FO
+    for i in range(int(fx['n_cases'])):
+        got = ext._get_spect(fx[f'audio{i}'], noise=fx[f'noise{i}'])[0].cpu().numpy()
+        want = FO.mel_power(fx[f'audio{i}'], fx[f'noise{i}'], CONF).numpy()
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+
+
+def test_batch_layout_is_the_collators(fx, ext):
+    n = int(fx['n_cases'])
+    audio = [fx[f'audio{i}'] for i in range(n)]
+    noise = [fx[f'noise{i}'] for i in range(n)]
+    inputs, lens = ext.extract_batch(audio, noise=noise)
+    assert lens.dtype == torch.int32 and not lens.is_cuda
+    np.testing.assert_array_equal(lens.numpy(), fx['col_il'])
+    got = inputs.cpu().numpy()
+    want = fx['col_inputs']
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < TOL
+    for i in range(n):                                   # the padding is exactly zero
+        assert not got[i, :, int(lens[i]):].any()
+
+
+def test_collator_on_device_tensors(fx, ext):
+    from wav2letter_pytorch_amd.data.data_loader import _collator
+    n = int(fx['n_cases'])
+    items = [(torch.from_numpy(fx[f'spect{i}']).cuda(), list(fx['col_targets'][i]), 'f%d.wav' % i, 't%d' % i) for i in range(n)]
+    inputs, il, tg, tl, paths, texts = _collator(items)
+    np.testing.assert_array_equal(inputs.cpu().numpy(), fx['col_inputs'])
+    np.testing.assert_array_equal(il.numpy(), fx['col_il'])
+    np.testing.assert_array_equal(tg.numpy(), fx['col_tg'])
+    np.testing.assert_array_equal(tl.numpy(), fx['col_tl'])
+    assert tg.dtype == torch.int32 and tl.dtype == torch.int32
+
+
+def test_spec_augment_and_cutout_bit_exact(fx):
+    from wav2letter_pytorch_amd.data.augmentations import Identity, SpecAugment, SpecCutout
+    x = torch.from_numpy(fx['aug_x']).cuda()
+    got = SpecAugment(freq_masks=2, time_masks=2, freq_width=15, time_width=50, rng=random.Random(11))(x)
+    np.testing.assert_array_equal(got.cpu().numpy(), fx['specaug'])
+    np.testing.assert_array_equal(x.cpu().numpy(), fx['aug_x'])          # input untouched (masked_fill semantics)
+    got = SpecCutout(rect_masks=5, rect_time=60, rect_freq=25, rng=random.Random(12))(x)
+    np.testing.assert_array_equal(got.cpu().numpy(), fx['speccut'])
+    xs = torch.from_numpy(fx['aug_xs']).cuda()          # T < time_width: negative starts follow Python slice rules
+    got = SpecAugment(freq_masks=1, time_masks=2, freq_width=15, time_width=50, rng=random.Random(13))(xs)
+    np.testing.assert_array_equal(got.cpu().numpy(), fx['specaug_short'])
+    assert Identity()(x) is x
+
+
+def _write_wav(path, samples, sr=16000):
+    with wave.open(path, 'wb') as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(sr)
+        w.writeframes((np.clip(samples, -1, 1) * 32767).astype('<i2').tobytes())
+
+
+def test_dataset_and_loader_end_to_end(tmp_path):
+    from oracle import features_oracle as FO
+    from wav2letter_pytorch_amd.data import label_sets
+    from wav2letter_pytorch_amd.data.data_loader import BatchAudioDataLoader, SpectrogramDataset, load_audio
+    labels = label_sets.labels_map['english_lowercase']
+    g = np.random.default_rng(0)
+    texts = ['hello world', 'a_b', 'mi three fifty five x', "it's"]
+    rows = []
+    for i, L in enumerate((8000, 12345, 4001, 16000)):
+        p = str(tmp_path / f'u{i}.wav')
+        _write_wav(p, 0.2 * g.standard_normal(L))
+        rows.append({'audio_filepath': p, 'text': texts[i]})
+    man = str(tmp_path / 'm.json')
+    with open(man, 'w') as f:
+        for r in rows:
+            f.write(json.dumps(r) + '\n')
+    ds = SpectrogramDataset(man, CONF, labels, mel_spec=64)
+    ds.extractor.dithering = 0.0                        # the dither is random; everything else must match the oracle
+    assert len(ds) == 4 and ds.data_channels() == 64
+    spect, target, path, text = ds[1]
+    want1 = FO.extract(load_audio(rows[1]['audio_filepath']), None, CONF)
+    assert spect.shape == want1.shape and np.abs(spect.cpu().numpy() - want1).max() < TOL
+    # '_' is the blank (index 0) and is dropped by filter(None, ...) like unknown characters (data_loader.py:127)
+    assert target == [labels.index('a'), labels.index('b')]
+    loader = BatchAudioDataLoader(ds, batch_size=3)
+    batches = list(loader)
+    assert [b[0].shape[0] for b in batches] == [3, 1]
+    inputs, il, tg, tl, paths, txts = batches[0]
+    assert inputs.is_cuda and inputs.dtype == torch.float32 and il.dtype == torch.int32
+    assert tuple(paths) == tuple(r['audio_filepath'] for r in rows[:3]) and tuple(txts) == tuple(texts[:3])
+    specs = [FO.extract(load_audio(r['audio_filepath']), None, CONF) for r in rows[:3]]
+    tgt = [[labels.index(c) for c in t if c in labels and labels.index(c) != 0] for t in texts[:3]]
+    wx, wil, wtg, wtl = FO.collate(specs, tgt)
+    assert np.abs(inputs.cpu().numpy() - wx).max() < TOL
+    np.testing.assert_array_equal(il.numpy(), wil)
+    np.testing.assert_array_equal(tg.numpy(), wtg)
+    np.testing.assert_array_equal(tl.numpy(), wtl)
+    # csv manifest with offset / duration columns
+    import pandas as pd
+    pd.DataFrame([dict(r, offset=0.1, duration=0.3) for r in rows]).to_csv(str(tmp_path / 'm.csv'))
+    ds2 = SpectrogramDataset(str(tmp_path / 'm.csv'), CONF, labels, mel_spec=64)
+    ds2.extractor.dithering = 0.0
+    a = load_audio(rows[0]['audio_filepath'], 0.3, 0.1)
+    assert a.shape[0] == 4800
+    assert np.abs(ds2[0][0].cpu().numpy() - FO.extract(a, None, CONF)).max() < TOL
+
+
+def test_short_utterance_is_rejected(ext):
+    with pytest.raises(ValueError):
+        ext.extract(np.zeros(200, dtype=np.float32))
+
+
+def test_full_size_batch_properties(ext):
+    """BASELINE shape: 32 utterances x 10 s -> 64 mel x 1001 frames; size-independent properties."""
+    g = torch.Generator().manual_seed(0)
+    lens = [160000] + [int(v) for v in torch.randint(80000, 160001, (31,), generator=g)]
+    audio = [(0.1 * torch.randn(L, generator=g)).numpy() for L in lens]
+    inputs, il = ext.extract_batch(audio)
+    assert inputs.shape == (32, 64, 1001)
+    np.testing.assert_array_equal(il.numpy(), 1 + np.array(lens) // 160)
+    x = inputs.cpu()
+    assert torch.isfinite(x).all()
+    for n in (0, 7, 31):
+        t = int(il[n])
+        v = x[n, :, :t]
+        sd = v.std(1)                                   # = s / (s + 1e-5) with s the raw feature's std: at most 1
+        assert v.mean(1).abs().max() < 1e-3 and sd.max() <= 1 + 1e-4 and sd.min() > 0.5
+        assert not x[n, :, t:].any()
+    # linearity of the un-normalised power path: scaling the audio by 2 scales mel power by 4
+    a = audio[1][:20000]
+    p1 = ext._get_spect(a, noise=np.zeros_like(a))
+    p2 = ext._get_spect(2 * a, noise=np.zeros_like(a))
+    assert ((p2 - 4 * p1).abs().max() <= 1e-5 * p2.abs().max())
+    # per-utterance result does not depend on its batch neighbours
+    solo = ext.extract(audio[5], noise=np.zeros_like(audio[5]))
+    both, _ = ext.extract_batch([audio[5], audio[0]], noise=[np.zeros_like(audio[5]), np.zeros_like(audio[0])])
+    assert torch.equal(solo, both[0, :, :solo.shape[1]])

@@ -142,3 +142,38 @@ def test_padding_rule_full_table():
         pads.append(sum(O.conv1d_block_padding(cin, k, s, d)))
         cin = c
     assert pads == [9, 10, 10, 10, 12, 12, 12, 16, 16, 16, 20, 20, 20, 24, 24, 24, 56, 56, 56, 0]
+
+
+# ---- feature front-end / augmentation oracle vs the reference-generated fixture (features.npz) ----
+def test_features_oracle_matches_reference_fixture():
+    import random
+    from oracle import features_oracle as FO
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'features.npz'), allow_pickle=True)
+    conf = dict(window='hamming', window_stride=0.01, window_size=0.02, sample_rate=16000)
+    specs = []
+    for i in range(int(z['n_cases'])):
+        s = FO.extract(z[f'audio{i}'], z[f'noise{i}'], conf)
+        assert s.shape == z[f'spect{i}'].shape
+        assert np.abs(s - z[f'spect{i}']).max() < 5e-6
+        specs.append(z[f'spect{i}'])
+    x, il, tg, tl = FO.collate(specs, [list(t) for t in z['col_targets']])
+    np.testing.assert_array_equal(x, z['col_inputs'])
+    np.testing.assert_array_equal(il, z['col_il'])
+    np.testing.assert_array_equal(tg, z['col_tg'])
+    np.testing.assert_array_equal(tl, z['col_tl'])
+    ax = z['aug_x']
+    np.testing.assert_array_equal(FO.apply_rects(ax, FO.spec_augment_rects(ax.shape, random.Random(11), 2, 2, 15, 50)), z['specaug'])
+    np.testing.assert_array_equal(FO.apply_rects(ax, FO.spec_cutout_rects(ax.shape, random.Random(12), 5, 60, 25)), z['speccut'])
+    xs = z['aug_xs']
+    np.testing.assert_array_equal(FO.apply_rects(xs, FO.spec_augment_rects(xs.shape, random.Random(13), 1, 2, 15, 50)),
+                                  z['specaug_short'])
+
+
+def test_product_mel_filterbank_equals_oracle_restatement():
+    from oracle import features_oracle as FO
+    from wav2letter_pytorch_amd.data.mel import mel_filterbank
+    for sr, n_fft, n_mels in ((16000, 512, 64), (8000, 256, 40), (22050, 1024, 80)):
+        a, b = mel_filterbank(sr, n_fft, n_mels, 0.0, sr / 2), FO.mel_filterbank(sr, n_fft, n_mels, 0.0, sr / 2)
+        assert a.shape == (n_mels, n_fft // 2 + 1)
+        assert np.abs(a - b).max() <= 1e-9
+        assert (a >= 0).all() and (a.sum(1) > 0).all()

@@ -71,6 +71,9 @@ _SIGNATURES = {
     'w2l_ctc_workspace_bytes': (c_i64, [c_i, c_i, c_i]),
     'w2l_ctc_loss': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     'w2l_argmax': (c_i, [c_p, c_i64, c_i, c_p, c_p]),
+    'w2l_logmel': (c_i, [c_p, c_p, c_p, c_f, c_f, c_i, c_i64, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_f, c_p, c_i, c_p]),
+    'w2l_feature_normalize': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
+    'w2l_zero_rects': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
     'w2l_levenshtein_host': (c_i, [c_p, c_i, c_p, c_i]),
 }
 
