@@ -24,34 +24,13 @@ BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense b
 
 
 def w2l_cfg(mid_layers, dropout=True):
-    from oracle.w2l_oracle import ENGLISH_LOWERCASE, W2L_LAYERS
-    from wav2letter_pytorch_amd.config import to_cfg
-    labels = ENGLISH_LOWERCASE
-    layers = [dict(output_size=c, kernel_size=k, stride=s, dilation=d, dropout=(p if dropout else 0.0))
-              for c, k, s, d, p in W2L_LAYERS]
-    return to_cfg(dict(name='wav2letter', mid_layers=mid_layers, input_size=64, labels=labels, precision='bf16',
-                       layers=layers,
-                       audio_conf=dict(window='hamming', window_stride=0.01, window_size=0.02, sample_rate=16000),
-                       decoder=dict(_target_='decoder.GreedyDecoder', labels=labels),
-                       optimizer=dict(_target_='torch.optim.SGD', lr=1e-5, momentum=0.9, nesterov=True, weight_decay=1e-5),
-                       scheduler=dict(_target_='torch.optim.lr_scheduler.ExponentialLR', gamma=0.999)))
+    from wav2letter_pytorch_amd.defaults import wav2letter_model
+    return wav2letter_model(mid_layers, dropout=dropout)
 
 
 def jasper10x5_cfg():
-    """Jasper 10x5 (BASELINE config 4) through the reference's own jasper_blocks keys: 13 dense blocks, 322 M params"""
-    from oracle.w2l_oracle import ENGLISH_LOWERCASE
-    from wav2letter_pytorch_amd.config import to_cfg
-    labels = ENGLISH_LOWERCASE
-    blocks = [dict(layer_size=256, kernel_size=11, stride=2, residual=False, separable=False, repeat=1)]
-    for c, k in ((256, 11), (384, 13), (512, 17), (640, 21), (768, 25)):
-        blocks += [dict(layer_size=c, kernel_size=k, stride=1, residual=True, separable=False, repeat=5)] * 2
-    blocks += [dict(layer_size=896, kernel_size=29, stride=1, dilation=2, residual=False, separable=False, repeat=1),
-               dict(layer_size=1024, kernel_size=1, stride=1, residual=False, separable=False, repeat=1)]
-    return to_cfg(dict(name='jasper', mid_layers=len(blocks), jasper_blocks=blocks, input_size=64, labels=labels, precision='bf16',
-                       audio_conf=dict(window='hamming', window_stride=0.01, window_size=0.02, sample_rate=16000),
-                       decoder=dict(_target_='decoder.GreedyDecoder', labels=labels),
-                       optimizer=dict(_target_='torch.optim.SGD', lr=1e-5, momentum=0.9, nesterov=True, weight_decay=1e-5),
-                       scheduler=dict(_target_='torch.optim.lr_scheduler.ExponentialLR', gamma=0.999)))
+    from wav2letter_pytorch_amd.defaults import jasper10x5_model
+    return jasper10x5_model()
 
 
 def cpu_baseline(budget_s=20.0):
@@ -101,7 +80,7 @@ def main():
     from wav2letter_pytorch_amd import Jasper, Wav2Letter, engine as E
     from wav2letter_pytorch_amd.distributed import GradReducer, broadcast_parameters, init_process_group_from_env
     import torch.distributed as dist
-    from oracle.w2l_oracle import synthetic_batch
+    from wav2letter_pytorch_amd.defaults import synthetic_batch      # the GPU leg never touches oracle/
 
     rank, world = init_process_group_from_env(force=args.force_dp)
     local = int(os.environ.get('LOCAL_RANK', '0'))

@@ -452,3 +452,34 @@ def test_bn_act_fwd_bwd(L, N, T, C, pl, pr, mode, act, f32):
     dyu = dy[h:].view(N, T + h, C)
     assert (dyu[:, T:] == 0).all()
     assert relerr(dyu[:, :T].transpose(1, 2), yr.grad) < 1e-4, relerr(dyu[:, :T].transpose(1, 2), yr.grad)
+
+
+@pytest.mark.parametrize('N,T,S', [(2, 2500, 700), (2, 8000, 2600), (1, 8000, 4000)])
+def test_ctc_long_transcripts(L, N, T, S):
+    """transcripts beyond 511 labels (1024-thread blocks, 2-8 states per thread) and frames beyond LDS capacity:
+    the T' = 8 000 utterances of BASELINE config 5.  Loss 1e-4 relative, gradient 1e-3 of its scale, vs torch CPU CTC."""
+    g = torch.Generator().manual_seed(N * 1000 + S)
+    lp = torch.randn(N, T, 29, generator=g).log_softmax(-1)
+    tl = torch.tensor([S] + [max(1, S - 37 * (i + 1)) for i in range(N - 1)], dtype=torch.int32)
+    tg = torch.randint(1, 29, (N, S), generator=g, dtype=torch.int32)
+    il = torch.tensor([T] + [T - 13 * (i + 1) for i in range(N - 1)], dtype=torch.int32)
+    def cpu(dtype):
+        r = lp.detach().clone().to(dtype).requires_grad_(True)
+        v = torch.nn.functional.ctc_loss(r.transpose(0, 1), tg, il, tl, blank=0, reduction='mean', zero_infinity=True)
+        v.backward()
+        return float(v), r.grad
+
+    ref, gref = cpu(torch.float32)           # what the reference executes
+    ref64, g64 = cpu(torch.float64)
+    from wav2letter_pytorch_amd.ctc_loss import CTCLoss
+    dlp = lp.cuda().requires_grad_(True)
+    loss = CTCLoss(blank=0, reduction='mean', zero_infinity=True)(dlp.transpose(0, 1), tg, il, tl)
+    loss.backward()
+    assert abs(float(loss) - ref) <= 1e-4 * abs(ref)
+    # alpha/beta reach ~ -T * 3.5 nats: one fp32 ulp there is ~1e-3 of a posterior, so two correct fp32 evaluations
+    # differ by a few 1e-3 of the gradient's scale on these lengths.  Judge both against float64: the device must be no
+    # further from it than 1e-3 of scale or 1.5x the reference's own fp32 error, whichever is larger.
+    scale = float(g64.abs().max())
+    err_dev = float((dlp.grad.cpu().double() - g64).abs().max())
+    err_ref = float((gref.double() - g64).abs().max())
+    assert err_dev <= max(1e-3 * scale, 1.5 * err_ref), (err_dev / scale, err_ref / scale)

@@ -29,8 +29,10 @@ def load(name):
     return np.load(os.path.join(GOLD, name), allow_pickle=True)
 
 
-def check(errs, stats, precision):
-    t = TOL[precision]
+def check(errs, stats, precision, grad_tol=None):
+    t = dict(TOL[precision])
+    if grad_tol is not None:
+        t['grad'] = grad_tol
     assert errs['log_probs'] < t['lp'], errs['log_probs']
     assert errs['loss'] < t['loss'], errs['loss']
     worst = max((v, k) for k, v in errs.items() if k not in ('log_probs', 'loss'))
@@ -324,3 +326,37 @@ def test_infeasible_and_empty_targets_end_to_end():
     errs, stats, out, out_lens, ref = compare_step(model, layers, sd, x, il, tg, tl, 'fp32')
     check(errs, stats, 'fp32')
     assert float(ref['loss']) > 0
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_jasper_long_utterance_T16000(precision):
+    """BASELINE config 5's sequence length (T = 16 000 input frames -> T' = 8 000): the conv kernels tile time, BatchNorm
+    reduces over 2 x 8 000 frames, and the CTC kernel streams log-probs from HBM (8 000 x 29 fp32 no longer fits LDS).
+    Parameters of the reference-generated Jasper fixture, a new ragged batch, checked against the oracle."""
+    from gpu_helpers import build_jasper, compare_jasper_step
+    from oracle import w2l_oracle as O
+    z = load('jasper_dense.npz')
+    meta = ast.literal_eval(str(z['meta']))
+    sd = {k[3:]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith('p0/')}
+    model = build_jasper(meta['blocks'], sd, precision).train()
+    x, il, tg, tl = O.synthetic_batch(2, 16000, seed=77, s_lo=900, s_hi=1500)
+    il[1] = 12345
+    x[1, :, 12345:] = 0
+    errs, stats, out, out_lens = compare_jasper_step(model, meta['blocks'], sd, x, il, tg, tl, precision)
+    # log-probs and loss at the usual bounds.  Gradients: at T' = 8 000 alpha/beta reach -3e4 nats, where one fp32 ulp is
+    # 2e-3 of a posterior; torch's own fp32 CPU CTC gradient (what the reference runs, and what the oracle replays) is 4e-2
+    # of scale away from its float64 evaluation at this length, so two correct fp32 pipelines agree to a few 1e-2 only.
+    check(errs, stats, precision, grad_tol=5e-2 if precision == 'fp32' else 1.2e-1)
+    assert out.shape == (2, 8000, 29) and [int(v) for v in out_lens] == [8000, 6173]
+
+
+def test_w2l_long_utterance_T16000_fp32():
+    """same length through the Wav2Letter stack (reflect padding, stride 2, dilation 2)"""
+    from oracle import w2l_oracle as O
+    layers = [(64, 11, 2, 1, 0.0), (128, 13, 1, 1, 0.0), (64, 29, 1, 2, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=31)
+    model = build_w2l(layers, sd, 'fp32').train()
+    x, il, tg, tl = O.synthetic_batch(2, 16000, seed=78, s_lo=1000, s_hi=2000)
+    errs, stats, out, out_lens, ref = compare_step(model, layers, sd, x, il, tg, tl, 'fp32')
+    check(errs, stats, 'fp32', grad_tol=5e-2)           # see test_jasper_long_utterance_T16000
+    assert out.shape == (2, 8000, 29)

@@ -84,11 +84,11 @@ struct CtcParams {
     float* nll;                // [N]
 };
 
-// SPT = states per thread (blockDim = 256).  LP_LDS: the utterance's whole log-prob matrix (T x C fp32,
+// NT = block size (256, or 1024 for long transcripts), SPT = states per thread.  LP_LDS: the utterance's whole log-prob matrix (T x C fp32,
 // 58 KB at T'=500) is staged in LDS once, so a time step never waits on an L2 round trip; otherwise the
 // emissions are prefetched from global memory one step ahead (long utterances, T*C*4 > ~150 KB).
-template <int SPT, bool LP_LDS>
-__global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(CtcParams p) {
+template <int NT, int SPT, bool LP_LDS>
+__global__ __launch_bounds__(NT) void ctc_alpha_beta_kernel(CtcParams p) {
     extern __shared__ float sh[];              // [2][Lpad + 4] (two guard cells on each side) | [T*C] log-probs
     const int n = blockIdx.x;
     const bool is_beta = blockIdx.y == 1;
@@ -96,14 +96,14 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(CtcParams p) {
     const int S = min(max(p.tg_len[n], 0), p.Smax);
     const int Tn = min(max(p.in_len[n], 0), p.T);
     const int L = 2 * S + 1;
-    const int Lp = SPT * 256 + 4;
+    const int Lp = SPT * NT + 4;
     float* buf0 = sh + 2;
     float* buf1 = sh + Lp + 2;
     const float* lp = p.lp + (int64_t)n * p.T * p.C;
     if (LP_LDS) {
         float* lds_lp = sh + 2 * Lp;
         const int total = Tn * p.C;            // rows are contiguous: one linear, coalesced copy
-        for (int i = tid; i < total; i += 256) lds_lp[i] = lp[i];
+        for (int i = tid; i < total; i += NT) lds_lp[i] = lp[i];
         lp = lds_lp;
         __syncthreads();
     }
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(CtcParams p) {
     bool skip[SPT];
 #pragma unroll
     for (int k = 0; k < SPT; ++k) {
-        const int s = tid + k * 256;
+        const int s = tid + k * NT;
         lab[k] = p.blank;
         skip[k] = false;
         if (s < L && (s & 1)) {
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(CtcParams p) {
     float cur[SPT], nxt_lp[SPT];
 #pragma unroll
     for (int k = 0; k < SPT; ++k) {
-        const int s = tid + k * 256;
+        const int s = tid + k * NT;
         float v = NEG_INF;
         if (s < L) {
             const bool init = is_beta ? (s >= L - 2) : (s <= 1);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(CtcParams p) {
     if (Tn > 1) {
 #pragma unroll
         for (int k = 0; k < SPT; ++k)
-            if (tid + k * 256 < L) nxt_lp[k] = lp[(int64_t)(t_first + dir) * p.C + lab[k]];
+            if (tid + k * NT < L) nxt_lp[k] = lp[(int64_t)(t_first + dir) * p.C + lab[k]];
     }
     __syncthreads();
     float* prev = buf0;
@@ -164,11 +164,11 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(CtcParams p) {
         if (i + 1 < Tn) {                                   // prefetch the following frame's emissions
 #pragma unroll
             for (int k = 0; k < SPT; ++k)
-                if (tid + k * 256 < L) nxt_lp[k] = lp[(int64_t)(t + dir) * p.C + lab[k]];
+                if (tid + k * NT < L) nxt_lp[k] = lp[(int64_t)(t + dir) * p.C + lab[k]];
         }
 #pragma unroll
         for (int k = 0; k < SPT; ++k) {
-            const int s = tid + k * 256;
+            const int s = tid + k * NT;
             const float a0 = cur[k];
             const float a1 = prev[s - dir];
             const float a2 = skip[k] ? prev[s - 2 * dir] : NEG_INF;
@@ -313,33 +313,47 @@ extern "C" int w2l_ctc_loss(const float* log_probs, const int32_t* targets, cons
     W2L_CHECK_ARG(targets || Smax == 0, "ctc_loss: null targets");
     W2L_CHECK_ARG(N > 0 && T > 0 && C > 0 && C <= 64 && Smax >= 0 && blank >= 0 && blank < C, "ctc_loss: bad sizes");
     const int L = 2 * Smax + 1;
-    W2L_CHECK_ARG(L <= 4 * 256, "ctc_loss: target length %d too long (max 511)", Smax);
+    W2L_CHECK_ARG(L <= 8 * 1024, "ctc_loss: target length %d too long (max 4095)", Smax);
     CtcParams p;
     p.lp = log_probs; p.targets = targets; p.in_len = input_lengths; p.tg_len = target_lengths;
     p.N = N; p.T = T; p.C = C; p.Smax = Smax; p.L = L; p.blank = blank; p.zero_inf = zero_infinity;
     p.alpha = (float*)workspace;
     p.beta = p.alpha + (int64_t)N * T * L;
     p.nll = nll;
-    const int spt = (L + 255) / 256;
-    dim3 grid(N, 2), block(256);
-    size_t lds = 2 * (size_t)(spt * 256 + 4) * sizeof(float);
+    // one thread per extended-label state while 4 x 256 covers them (S <= 511: every utterance of <= ~40 s), else 1024
+    // threads with up to 8 states each (S <= 4095: the T = 16 000 frame utterances of BASELINE config 5)
+    const int nt = L <= 4 * 256 ? 256 : 1024;
+    int spt = (L + nt - 1) / nt;
+    if (nt == 1024) spt = spt <= 4 ? (spt < 2 ? 2 : spt) : (spt <= 6 ? 6 : 8);    // the instantiated variants
+    dim3 grid(N, 2), block(nt);
+    size_t lds = 2 * (size_t)(spt * nt + 4) * sizeof(float);
     const size_t lp_bytes = (size_t)T * C * sizeof(float);
     const bool lp_lds = lds + lp_bytes <= 150 * 1024;
     if (lp_lds) lds += lp_bytes;
-#define W2L_CTC_LAUNCH(SPT)                                                                              \
-    do {                                                                                                 \
-        if (lp_lds) {                                                                                    \
-            W2L_CHECK_HIP(w2l_allow_big_lds((const void*)ctc_alpha_beta_kernel<SPT, true>));             \
-            hipLaunchKernelGGL((ctc_alpha_beta_kernel<SPT, true>), grid, block, lds, (hipStream_t)stream, p);  \
-        } else {                                                                                         \
-            hipLaunchKernelGGL((ctc_alpha_beta_kernel<SPT, false>), grid, block, lds, (hipStream_t)stream, p); \
-        }                                                                                                \
+#define W2L_CTC_LAUNCH(NT, SPT)                                                                              \
+    do {                                                                                                     \
+        if (lp_lds) {                                                                                        \
+            W2L_CHECK_HIP(w2l_allow_big_lds((const void*)ctc_alpha_beta_kernel<NT, SPT, true>));             \
+            hipLaunchKernelGGL((ctc_alpha_beta_kernel<NT, SPT, true>), grid, block, lds, (hipStream_t)stream, p);  \
+        } else {                                                                                             \
+            hipLaunchKernelGGL((ctc_alpha_beta_kernel<NT, SPT, false>), grid, block, lds, (hipStream_t)stream, p); \
+        }                                                                                                    \
     } while (0)
-    switch (spt) {
-        case 1: W2L_CTC_LAUNCH(1); break;
-        case 2: W2L_CTC_LAUNCH(2); break;
-        case 3: W2L_CTC_LAUNCH(3); break;
-        default: W2L_CTC_LAUNCH(4); break;
+    if (nt == 256) {
+        switch (spt) {
+            case 1: W2L_CTC_LAUNCH(256, 1); break;
+            case 2: W2L_CTC_LAUNCH(256, 2); break;
+            case 3: W2L_CTC_LAUNCH(256, 3); break;
+            default: W2L_CTC_LAUNCH(256, 4); break;
+        }
+    } else {
+        switch (spt) {
+            case 2: W2L_CTC_LAUNCH(1024, 2); break;
+            case 3: W2L_CTC_LAUNCH(1024, 3); break;
+            case 4: W2L_CTC_LAUNCH(1024, 4); break;
+            case 6: W2L_CTC_LAUNCH(1024, 6); break;
+            default: W2L_CTC_LAUNCH(1024, 8); break;
+        }
     }
 #undef W2L_CTC_LAUNCH
     W2L_CHECK_LAUNCH();
