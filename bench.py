@@ -70,6 +70,7 @@ def main():
                     help='wav2letter = the headline workload; jasper10x5 = BASELINE config 4 (secondary)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true')
+    ap.add_argument('--no-sgd-overlap', action='store_true', help='keep the fused SGD updates on the main stream')
     ap.add_argument('--force-dp', action='store_true', help='run the RCCL gradient path even with one rank (plumbing check)')
     ap.add_argument('--serial-wgrad', action='store_true', help='keep weight gradients on the main stream (clean per-kernel durations for profiling)')
     ap.add_argument('--trace-steps', action='store_true', help='per-step host-enqueue vs GPU time (stderr), then exit')
@@ -100,6 +101,8 @@ def main():
         model._overlap_wgrad = False
     opt, _ = model.configure_optimizers()
     opt = opt[0]
+    if hasattr(opt, 'overlap') and not args.no_sgd_overlap:
+        opt.overlap = True            # conv-weight updates run on a side stream under the next step's forward (optim.FusedSGD)
     N, T = args.batch, args.frames
     x, il, tg, tl = synthetic_batch(N, T, seed=1234 + rank)
     x = x.to(dev)

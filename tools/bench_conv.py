@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--n', type=int, default=32)
     ap.add_argument('--t', type=int, default=1000)
     ap.add_argument('--sweep', action='store_true', help='time every igemm block-shape candidate per layer')
+    ap.add_argument('--tune', action='store_true', help='let the library measure and pick its configurations first')
     args = ap.parse_args()
     N = args.n
     uniq = []
@@ -96,6 +97,16 @@ def main():
                 res.append(f'{ci}:{flops / a / 1e9:5.0f}/{flops / b / 1e9:5.0f}')
             L.lib.w2l_conv_force_tile_config(-1)
             print('      ' + ' | '.join(res))
+        if args.tune:
+            L.check(L.lib.w2l_conv1d_igemm_tune(L.ptr(x), rows * cin, N * rows, L.ptr(w), L.ptr(y), 0, None, L.ptr(stats), N, cin,
+                                                cout, Tout, kw, s, d, 3, st))
+            if s == 1:
+                L.check(L.lib.w2l_conv1d_igemm_tune(C.c_void_p(dy.data_ptr() + (h - hb) * cout * 2), dy.shape[0] * cout,
+                                                    dy.shape[0] - (h - hb), L.ptr(wd), L.ptr(dx), 0, None, None, 1, cout, cin,
+                                                    N * per, kw, 1, d, 3, st))
+            L.check(L.lib.w2l_conv1d_wgrad_tune(C.c_void_p(dy.data_ptr() + h * cout * 2), per * cout, L.ptr(x), rows * cin,
+                                                N * rows, L.ptr(dw), N, cin, cout, Tout, kw, s, d, 3, st))
+            dw.zero_()
         tf = timeit(fwd, args.reps)
         td = timeit(dgrad, args.reps) if s == 1 else float('nan')
         tw = timeit(wgrad, args.reps)

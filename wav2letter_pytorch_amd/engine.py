@@ -124,6 +124,7 @@ class _PackedW:
     cinp: int
     coutp: int
     src_ptr: int = 0
+    ready: Optional['torch.cuda.Event'] = None      # set by optim.FusedSGD when the pack was written on its side stream
 
 
 @dataclass
@@ -218,6 +219,9 @@ def pack_weights(conv: ConvSpec, precise: bool, need_dgrad: bool = True) -> _Pac
     hit = cache.get(precise)
     if (hit is not None and hit.version == w._version and hit.fwd_hi.device == w.device
             and hit.src_ptr == w.data_ptr()):
+        if hit.ready is not None:          # the optimizer updated + packed this weight on its own stream: order after it
+            torch.cuda.current_stream(w.device).wait_event(hit.ready)
+            hit.ready = None
         return hit
     cout, cin, kw = w.shape
     coutp, cinp = padded_channels(cout), padded_channels(cin)

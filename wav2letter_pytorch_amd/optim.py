@@ -1,7 +1,15 @@
 """FusedSGD: torch.optim.SGD semantics (the reference's optimizer, configuration/optimizer/
 exp_lr_optimizer.yaml:2-7) with the conv-weight update fused with the bf16 operand packing of the
 next step (w2l_sgd_pack).  Non-conv parameters (biases, BatchNorm affine) use torch's own foreach
-update.  State-dict layout is torch.optim.SGD's (``momentum_buffer`` per parameter)."""
+update.  State-dict layout is torch.optim.SGD's (``momentum_buffer`` per parameter).
+
+The conv-weight updates are HBM-bound (24 B per parameter, 3.7 GB per step for the full Wav2Letter table) while the
+forward convolutions that follow them are MFMA-bound, so ``step()`` enqueues them on a side HIP stream in forward order
+and tags each weight's operand pack with an event; the step engine waits for a layer's event just before that layer's
+first convolution (engine.pack_weights).  The next forward therefore starts as soon as layer 0 is updated, and the other
+20 updates stream through HBM underneath it.  This is opt-in (``optimizer.overlap = True``; trainer.Trainer and bench.py
+do): ``join()`` (also called by ``state_dict``) makes the caller's stream wait for the updates in flight, and anything
+that reads the parameters outside the step engine must call it first."""
 from __future__ import annotations
 
 import torch
@@ -19,11 +27,33 @@ def _is_tap_major(t: torch.Tensor) -> bool:
 
 
 class FusedSGD(torch.optim.SGD):
+    overlap = False           # opt-in (trainer.Trainer and bench.py set it): whoever enables it must join() before
+                              # reading parameters outside the step engine (checkpoints, .cpu() copies, ...)
+
     @classmethod
     def from_sgd(cls, opt: torch.optim.SGD) -> 'FusedSGD':
         new = cls.__new__(cls)
         new.__dict__.update(opt.__dict__)
         return new
+
+    def _side_state(self):
+        st = self.__dict__.get('_w2l_side')
+        if st is None:
+            st = {'stream': None, 'held': [], 'pending': False}
+            self.__dict__['_w2l_side'] = st
+        return st
+
+    def join(self):
+        """make the current stream wait for the updates still running on the optimizer's side stream"""
+        st = self._side_state()
+        if st['pending'] and st['stream'] is not None:
+            torch.cuda.current_stream(st['stream'].device).wait_stream(st['stream'])
+        st['pending'] = False
+        st['held'] = []
+
+    def state_dict(self):
+        self.join()
+        return super().state_dict()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -31,22 +61,42 @@ class FusedSGD(torch.optim.SGD):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self.join()                  # (normally a no-op: the forward pass has already waited for every event)
+        st = self._side_state()
         for group in self.param_groups:
             lr, mu, wd = group['lr'], group['momentum'], group['weight_decay']
             nesterov, dampening, maximize = group['nesterov'], group['dampening'], group.get('maximize', False)
             fused_ok = mu != 0 and dampening == 0 and not maximize
-            rest = []
+            rest, fused = [], []
             for p in group['params']:
                 if p.grad is None:
                     continue
                 g = p.grad
                 if (fused_ok and p.is_cuda and p.dtype == torch.float32 and _is_tap_major(p) and g.stride() == p.stride()
                         and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0):
-                    self._fused_conv(p, g, lr, mu, wd, nesterov)
+                    fused.append((p, g))
                 else:
                     rest.append(p)
             if rest:
                 self._plain(rest, lr, mu, wd, nesterov, dampening, maximize)
+            if not fused:
+                continue
+            if not self.overlap:
+                for p, g in fused:
+                    self._fused_conv(p, g, lr, mu, wd, nesterov)
+                continue
+            dev = fused[0][0].device
+            if st['stream'] is None or st['stream'].device != dev:
+                st['stream'] = torch.cuda.Stream(device=dev)
+            side = st['stream']
+            side.wait_stream(torch.cuda.current_stream(dev))     # gradients (wgrad join, all-reduce) are complete there
+            with torch.cuda.stream(side):
+                for p, g in fused:               # parameter order = forward order: layer 0's event fires first
+                    pk = self._fused_conv(p, g, lr, mu, wd, nesterov)
+                    pk.ready = torch.cuda.Event()
+                    pk.ready.record(side)
+                    st['held'].append(g)         # zero_grad() must not hand this memory back while the kernel reads it
+            st['pending'] = True
         return loss
 
     def _fused_conv(self, p, g, lr, mu, wd, nesterov):
@@ -78,7 +128,9 @@ class FusedSGD(torch.optim.SGD):
               'w2l_sgd_pack')
         torch.autograd.graph.increment_version(p)                    # p changed through its raw pointer
         cache.clear()
-        cache[precise] = E._PackedW(p._version, fwd_hi, fwd_lo, dgr_hi, dgr_lo, cin, cout, p.data_ptr())
+        pk = E._PackedW(p._version, fwd_hi, fwd_lo, dgr_hi, dgr_lo, cin, cout, p.data_ptr())
+        cache[precise] = pk
+        return pk
 
     def _plain(self, params, lr, mu, wd, nesterov, dampening, maximize):
         grads = [p.grad for p in params]

@@ -31,6 +31,9 @@ class Trainer:
         optimizers, schedulers = model.configure_optimizers()
         opt = optimizers[0]
         model._optimizers = opt
+        if hasattr(opt, 'overlap'):          # optim.FusedSGD: weight updates stream under the next forward pass
+            opt.overlap = True
+        join = getattr(opt, 'join', lambda: None)
         done = False
         for epoch in range(self.max_epochs):
             model.train()
@@ -50,6 +53,7 @@ class Trainer:
                     break
             for sch in schedulers:
                 sch.step()
+            join()                               # parameters are read below (validation, checkpoint)
             if val_dataloader is not None:
                 model.eval()
                 with torch.no_grad():
@@ -65,4 +69,5 @@ class Trainer:
             print(f'epoch {epoch} done in {time.time() - t0:.1f}s')
             if done:
                 break
+        join()
         return model
