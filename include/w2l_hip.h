@@ -88,6 +88,22 @@ int w2l_conv1d_igemm_tune(const void* xp, int64_t x_bstride, int64_t x_rows_tota
                           const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout, int Kw, int stride,
                           int dil, int reps, void* stream);
 
+/* The same two entry points with a split-K workspace (device memory, owned by the caller, >= 64 KiB, ZERO-FILLED once
+ * when it is allocated; one workspace per stream of execution -- launches that may overlap must not share it).  With
+ * it, the tuner may split the (chunk, tap) reduction of a tile over 2-8 blocks where one block per tile would leave CUs
+ * idle (a partly filled last round -- the flat data gradient has N*(T + halo) rows, never a round number of tiles -- or
+ * small batches with fewer tiles than CUs): partial tiles go through fp32 slabs in the workspace, the block that draws a
+ * tile's last ticket sums them in split order (bit-reproducible) and runs the normal epilogue; no block waits for another.
+ * w2l_conv_splitk_workspace_bytes: a size with which every configuration of the problem is available (any smaller size
+ * just removes the split configurations that do not fit). */
+int w2l_conv1d_igemm_ws(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y, int y_f32,
+                        int accumulate, const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout, int Kw,
+                        int stride, int dil, void* splitk_ws, int64_t splitk_ws_bytes, void* stream);
+int w2l_conv1d_igemm_tune_ws(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y, int y_f32,
+                             const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout, int Kw, int stride,
+                             int dil, int reps, void* splitk_ws, int64_t splitk_ws_bytes, void* stream);
+int64_t w2l_conv_splitk_workspace_bytes(int N, int Cout, int Tout);
+
 /* tuning hook: force configuration idx (>= 0) for every later w2l_conv1d_igemm call; -1 = automatic.
  * idx = block shape (0..20) + 21 * K-loop structure (0: barrier at the top of a step, 1: barrier mid-step);
  * a call whose problem the forced configuration cannot run returns an error. */

@@ -261,7 +261,7 @@ def test_tune_cache_roundtrip(tmp_path):
     src = tmp_path / 'in.txt'
     src.write_text('w2l-tune v1 gfx950\n'
                    'igemm 7 640 768 1000 21 1 1 1 15\n'
-                   'igemm 7 640 768 1000 21 1 1 1 99\n'      # unknown block shape: skipped
+                   'igemm 7 640 768 1000 21 1 1 1 999\n'     # unknown configuration: skipped
                    'igemm 7 640 768 500 21 2 1 0 15\n'       # stride 2 only runs on shape 2: skipped
                    'wgrad 7 640 768 1000 21 3 1\n'
                    'wgrad 1 64 64 10 3 999 0\n'               # more splits than (n,t) steps: skipped

@@ -158,11 +158,13 @@ def test_conv_igemm_forward(L, case, precise):
 
 @pytest.mark.parametrize('with_stats', [True, False])
 def test_conv_igemm_every_configuration(L, with_stats):
-    """every block shape x both K-loop structures the autotuner may pick, on a problem with ragged edges in both
-    tile dimensions (Cout = 320: 2.5 / 1.25 / 0.6 tiles; T = 300), stride 1 and the stride-2 shape"""
-    ran = 0
+    """every block shape x both K-loop structures x every split-K factor the autotuner may pick, on a problem with ragged
+    edges in both tile dimensions (Cout = 320: 2.5 / 1.25 / 0.6 tiles; T = 300), stride 1 and the stride-2 shape.  Split
+    launches run twice on the same workspace: bit-identical results (partials are summed in split order) and the tickets
+    are back at zero afterwards."""
+    ran = split_ran = 0
     for (s, d, Kw, pl, pr) in [(1, 2, 5, 4, 4), (2, 1, 11, 4, 5)]:
-        N, Cin, Cout, T = 2, 128, 320, 300
+        N, Cin, Cout, T = 2, 256, 320, 300
         x, w, b = conv_inputs(N, Cin, Cout, Kw, T, pl, pr, 11)
         xp = to_ntc_padded(x, pl, pr, 1)
         rows = xp.shape[1]
@@ -173,26 +175,39 @@ def test_conv_igemm_every_configuration(L, with_stats):
         ref = F.conv1d(F.pad(bf(x), (pl, pr), mode='reflect'), bf(w), b, stride=s, dilation=d)
         r1, r2 = ref.sum((0, 2)), (ref * ref).sum((0, 2))
         tiles = L.lib.w2l_conv_stat_tiles(N, Tout)
-        for idx in range(42):
-            y = torch.full((N, Tout, coutp), float('nan'), dtype=torch.bfloat16, device='cuda')
-            stats = torch.zeros(tiles, 2, coutp, device='cuda')
-            L.lib.w2l_conv_force_tile_config(idx)
-            try:
-                rc = L.lib.w2l_conv1d_igemm(L.ptr(xh), rows * cinp, N * rows, L.ptr(fh), L.ptr(y), 0, 0, L.ptr(bd),
-                                            L.ptr(stats) if with_stats else None, N, cinp, coutp, Tout, Kw, s, d, L.stream_ptr())
-            finally:
-                L.lib.w2l_conv_force_tile_config(-1)
-            if rc != 0:
-                continue                      # this configuration cannot run the problem (statistics need 128-column tiles, ...)
-            torch.cuda.synchronize()
+        ws = torch.zeros(int(L.lib.w2l_conv_splitk_workspace_bytes(N, coutp, Tout)), dtype=torch.uint8, device='cuda')
+        for idx in range(42 * 7):
+            outs = []
+            for rep in range(2 if idx >= 42 else 1):
+                y = torch.full((N, Tout, coutp), float('nan'), dtype=torch.bfloat16, device='cuda')
+                stats = torch.zeros(tiles, 2, coutp, device='cuda')
+                L.lib.w2l_conv_force_tile_config(idx)
+                try:
+                    rc = L.lib.w2l_conv1d_igemm_ws(L.ptr(xh), rows * cinp, N * rows, L.ptr(fh), L.ptr(y), 0, 0, L.ptr(bd),
+                                                   L.ptr(stats) if with_stats else None, N, cinp, coutp, Tout, Kw, s, d,
+                                                   L.ptr(ws), ws.numel(), L.stream_ptr())
+                finally:
+                    L.lib.w2l_conv_force_tile_config(-1)
+                if rc != 0:
+                    break                     # this configuration cannot run the problem (statistics need 128-column tiles, ...)
+                torch.cuda.synchronize()
+                outs.append((y, stats))
+            if not outs:
+                continue
             ran += 1
+            split_ran += idx >= 42
+            y, stats = outs[0]
             got = y.float().cpu().transpose(1, 2)
             assert torch.isfinite(got).all(), idx
             assert relerr(got, ref) < 1e-2, (idx, relerr(got, ref))
             if with_stats:
                 assert relerr(stats[:, 1].sum(0).cpu(), r2) < 2e-2, idx
                 assert (stats[:, 0].sum(0).cpu() - r1).abs().max() <= 5e-3 * r2.sqrt().max() * (N * Tout) ** 0.5, idx
-    assert ran >= (28 if with_stats else 40), ran
+            if len(outs) == 2:
+                assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), idx
+                assert not ws[:65536].any(), idx
+    assert ran >= (28 if with_stats else 40) * 6, ran
+    assert split_ran >= 100, split_ran
 
 
 def test_conv_wgrad_every_plan(L):

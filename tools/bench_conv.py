@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--n', type=int, default=32)
     ap.add_argument('--t', type=int, default=1000)
     ap.add_argument('--sweep', action='store_true', help='time every igemm block-shape candidate per layer')
+    ap.add_argument('--no-splitk', action='store_true', help='with --tune: measure without the split-K configurations')
     ap.add_argument('--tune', action='store_true', help='let the library measure and pick its configurations first')
     args = ap.parse_args()
     N = args.n
@@ -69,14 +70,17 @@ def main():
         dw = torch.zeros(kw, cout, cin, device='cuda')
         flops = 2.0 * N * Tout * cout * cin * kw
 
+        ws = torch.zeros(min(1 << 30, int(L.lib.w2l_conv_splitk_workspace_bytes(N, max(cin, cout), max(N * per, Tout)))),
+                         dtype=torch.uint8, device='cuda')
+
         def fwd():
-            L.check(L.lib.w2l_conv1d_igemm(L.ptr(x), rows * cin, N * rows, L.ptr(w), L.ptr(y), 0, 0, None, L.ptr(stats), N,
-                                           cin, cout, Tout, kw, s, d, st))
+            L.check(L.lib.w2l_conv1d_igemm_ws(L.ptr(x), rows * cin, N * rows, L.ptr(w), L.ptr(y), 0, 0, None, L.ptr(stats), N,
+                                              cin, cout, Tout, kw, s, d, L.ptr(ws), ws.numel(), st))
 
         def dgrad():
-            L.check(L.lib.w2l_conv1d_igemm(C.c_void_p(dy.data_ptr() + (h - hb) * cout * 2), dy.shape[0] * cout,
-                                           dy.shape[0] - (h - hb), L.ptr(wd), L.ptr(dx), 0, 0, None, None, 1, cout, cin,
-                                           N * per, kw, 1, d, st))
+            L.check(L.lib.w2l_conv1d_igemm_ws(C.c_void_p(dy.data_ptr() + (h - hb) * cout * 2), dy.shape[0] * cout,
+                                              dy.shape[0] - (h - hb), L.ptr(wd), L.ptr(dx), 0, 0, None, None, 1, cout, cin,
+                                              N * per, kw, 1, d, L.ptr(ws), ws.numel(), st))
 
         def wgrad():
             L.check(L.lib.w2l_conv1d_wgrad(C.c_void_p(dy.data_ptr() + h * cout * 2), per * cout, L.ptr(x),
@@ -98,12 +102,13 @@ def main():
             L.lib.w2l_conv_force_tile_config(-1)
             print('      ' + ' | '.join(res))
         if args.tune:
-            L.check(L.lib.w2l_conv1d_igemm_tune(L.ptr(x), rows * cin, N * rows, L.ptr(w), L.ptr(y), 0, None, L.ptr(stats), N, cin,
-                                                cout, Tout, kw, s, d, 3, st))
+            wsa = (L.ptr(ws), ws.numel()) if not args.no_splitk else (None, 0)
+            L.check(L.lib.w2l_conv1d_igemm_tune_ws(L.ptr(x), rows * cin, N * rows, L.ptr(w), L.ptr(y), 0, None, L.ptr(stats), N,
+                                                   cin, cout, Tout, kw, s, d, 3, *wsa, st))
             if s == 1:
-                L.check(L.lib.w2l_conv1d_igemm_tune(C.c_void_p(dy.data_ptr() + (h - hb) * cout * 2), dy.shape[0] * cout,
-                                                    dy.shape[0] - (h - hb), L.ptr(wd), L.ptr(dx), 0, None, None, 1, cout, cin,
-                                                    N * per, kw, 1, d, 3, st))
+                L.check(L.lib.w2l_conv1d_igemm_tune_ws(C.c_void_p(dy.data_ptr() + (h - hb) * cout * 2), dy.shape[0] * cout,
+                                                       dy.shape[0] - (h - hb), L.ptr(wd), L.ptr(dx), 0, None, None, 1, cout, cin,
+                                                       N * per, kw, 1, d, 3, *wsa, st))
             L.check(L.lib.w2l_conv1d_wgrad_tune(C.c_void_p(dy.data_ptr() + h * cout * 2), per * cout, L.ptr(x), rows * cin,
                                                 N * rows, L.ptr(dw), N, cin, cout, Tout, kw, s, d, 3, st))
             dw.zero_()

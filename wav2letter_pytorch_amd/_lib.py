@@ -51,6 +51,10 @@ _SIGNATURES = {
     'w2l_conv_stat_tiles': (c_i, [c_i, c_i]),
     'w2l_conv1d_igemm': (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'w2l_conv1d_igemm_tune': (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'w2l_conv1d_igemm_ws': (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p]),
+    'w2l_conv1d_igemm_tune_ws': (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p,
+                                       c_i64, c_p]),
+    'w2l_conv_splitk_workspace_bytes': (c_i64, [c_i, c_i, c_i]),
     'w2l_conv_force_tile_config': (None, [c_i]),
     'w2l_wgrad_force_plan': (None, [c_i, c_i]),
     'w2l_wgrad_needs_zero': (c_i, [c_i, c_i, c_i, c_i, c_i]),

@@ -36,6 +36,11 @@ struct IgemmParams {
     int N, Cin, Cout, Tout, Kw, stride, dil;
     int tiles_t, ncols, xrows_lds;
     int y_f32, accumulate;
+    // split-K (w2l_conv1d_igemm_ws): `splits` blocks share one output tile, each reducing a contiguous range of the
+    // (chunk, tap) steps; partial tiles go through fp32 slabs, the block that draws the last ticket sums and stores
+    int splits;
+    float* slabs;             // [tiles][splits][BM*BN]
+    unsigned* tickets;        // [tiles], zero between launches
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base) {
@@ -54,7 +59,11 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / NW, wn = wave % NW;
 
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    // consecutive logical ids share an XCD (xcd_remap): the `splits` blocks of one tile run next to each other in time and
+    // place, so their slabs meet in that XCD's L2
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = p.splits > 1 ? lin % p.splits : 0;
+    const int tile = p.splits > 1 ? lin / p.splits : lin;
     const int tm = tile / p.ncols;
     const int col = tile - tm * p.ncols;
     const int n = col / p.tiles_t;
@@ -114,7 +123,12 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
         for (int j = 0; j < NS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = Cin / BK;
-    const int nsteps = nchunks * Kw;
+    // this block's share of the nchunks * Kw (chunk-major) steps; a range may start in the middle of a chunk
+    const int total_steps = nchunks * Kw;
+    const int s_begin = p.splits > 1 ? (int)(((int64_t)total_steps * split) / p.splits) : 0;
+    const int s_end = p.splits > 1 ? (int)(((int64_t)total_steps * (split + 1)) / p.splits) : total_steps;
+    const int nsteps = s_end - s_begin;
+    const int c_first = s_begin / Kw, kw_first = s_begin - c_first * Kw;
 
     // per-lane fragment offsets (constant over the whole K loop)
     const int fr = lane & 15, fq = lane >> 4;
@@ -126,10 +140,10 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
     // pass (measured by w2l_conv1d_igemm_tune): PIPE = 0 keeps the barrier at the top of a step, PIPE = 1 moves it
     // to the middle so that the next step's first fragment reads overlap this step's last MFMAs.
     if constexpr (PIPE == 0) {
-        stage_x(xbuf0, 0);
-        stage_w(wbuf0, 0, 0);
+        stage_x((c_first & 1) ? xbuf1 : xbuf0, c_first);
+        stage_w(wbuf0, kw_first, c_first);
 
-        int kw = 0, c = 0;
+        int kw = kw_first, c = c_first;
         for (int step = 0; step < nsteps; ++step) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -225,9 +239,9 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
         //   1. request a1/b1 (substep 1, same buffers), run the substep-0 MFMAs
         //   2. vmcnt(0) + barrier: every wave has finished READING this step's buffers, and step+1's tiles have landed
         //   3. DMA step+2 into this step's (now dead) buffers; request a0/b0 of step+1; run the substep-1 MFMAs
-        stage_x(xbuf0, 0);
-        stage_w(wbuf0, 0, 0);
-        int kw = 0, c = 0, kw_n, c_n;
+        stage_x((c_first & 1) ? xbuf1 : xbuf0, c_first);
+        stage_w(wbuf0, kw_first, c_first);
+        int kw = kw_first, c = c_first, kw_n, c_n;
         advance(kw, c, kw_n, c_n);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -259,6 +273,49 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
         mfma_all(a0, b0);
         mfma_all(a1, b1);
 
+    }
+
+    // ---- split-K: publish the partial tile, draw a ticket; the last arriver sums all partials IN SPLIT ORDER (so the result
+    // does not depend on which block arrived last) and goes on to the epilogue.  No block ever waits for another one.
+    // (agent-scope release before the ticket, agent-scope acquire after it: correct for any placement of the blocks on XCDs)
+    if (p.splits > 1) {
+        float* slab = p.slabs + ((int64_t)tile * p.splits + split) * (BM * BN);
+#pragma unroll
+        for (int mi = 0; mi < MS; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NS; ++ni)
+                *reinterpret_cast<f32x4*>(slab + ((mi * NS + ni) * NT + tid) * 4) = acc[mi][ni];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // every wave's stores are issued and complete; main-loop LDS is dead
+        unsigned* flag = reinterpret_cast<unsigned*>(smem);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *flag = __hip_atomic_fetch_add(&p.tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const unsigned ticket = *flag;
+        if (ticket != (unsigned)(p.splits - 1)) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&p.tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+        }
+        __syncthreads();
+        const float* base = p.slabs + (int64_t)tile * p.splits * (BM * BN);
+#pragma unroll
+        for (int mi = 0; mi < MS; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NS; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < p.splits; ++sp) {
+            const float* sl = base + (int64_t)sp * (BM * BN);
+#pragma unroll
+            for (int mi = 0; mi < MS; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NS; ++ni)
+                    acc[mi][ni] += *reinterpret_cast<const f32x4*>(sl + ((mi * NS + ni) * NT + tid) * 4);
+        }
+        __syncthreads();                               // `flag` shares LDS with the statistics scratch below
     }
 
     // ---- epilogue: bias, optional accumulate, store, BatchNorm partial statistics ----
@@ -379,7 +436,11 @@ int launch_cfg(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream
 
 }  // namespace
 
-// A configuration index is (block shape) + kNumCfgs * (K-loop structure PIPE).
+// A configuration index is (block shape) + kNumCfgs * (K-loop structure PIPE) + 2 * kNumCfgs * (split-K option).
+constexpr int kSplits[] = {1, 2, 3, 4, 5, 6, 8};
+constexpr int kNumSplits = sizeof(kSplits) / sizeof(kSplits[0]);
+constexpr int kBaseCfgs = 2 * kNumCfgs;
+constexpr size_t kTicketBytes = 64 * 1024;              // head of the split-K workspace: one counter per output tile
 static int g_force_cfg = -1;
 extern "C" void w2l_conv_force_tile_config(int idx) { g_force_cfg = idx; }
 
@@ -394,7 +455,7 @@ static std::map<ShapeKey, int> g_tuned;
 static std::mutex g_tuned_mu;
 
 static bool cfg_feasible(int idx, int Kw, int stride, int dil, bool need_bn128) {
-    if (idx < 0 || idx >= 2 * kNumCfgs) return false;
+    if (idx < 0 || idx >= kBaseCfgs * kNumSplits) return false;
     const int i = idx % kNumCfgs;
     const TileCfg& c = kCfgs[i];
     const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
@@ -443,9 +504,27 @@ static int choose_cfg(int N, int Cin, int Cout, int Tout, int Kw, int stride, in
 
 extern "C" int w2l_conv_stat_tiles(int N, int Tout) { return N * ((Tout + 127) / 128); }
 
-extern "C" int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y,
-                                int y_f32, int accumulate, const float* bias, float* stats_partial, int N, int Cin,
-                                int Cout, int Tout, int Kw, int stride, int dil, void* stream) {
+// bytes of split-K workspace that let every configuration of this problem run (slabs of the largest split + the tickets)
+static size_t splitk_bytes(int cfg_i, int splits, int N, int Cout, int Tout) {
+    const TileCfg& c = kCfgs[cfg_i];
+    const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
+    const size_t tiles = (size_t)((Cout + bm - 1) / bm) * N * ((Tout + bn - 1) / bn);
+    return kTicketBytes + tiles * splits * bm * bn * sizeof(float);
+}
+
+static bool split_feasible(int cfg_i, int splits, int N, int Cin, int Cout, int Tout, int Kw, const void* ws, int64_t ws_bytes) {
+    if (splits == 1) return true;
+    if (ws == nullptr || (Cin / BK) * Kw < 2 * splits) return false;
+    const TileCfg& c = kCfgs[cfg_i];
+    const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
+    const size_t tiles = (size_t)((Cout + bm - 1) / bm) * N * ((Tout + bn - 1) / bn);
+    return tiles * sizeof(unsigned) <= kTicketBytes && splitk_bytes(cfg_i, splits, N, Cout, Tout) <= (size_t)ws_bytes;
+}
+
+extern "C" int w2l_conv1d_igemm_ws(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y,
+                                   int y_f32, int accumulate, const float* bias, float* stats_partial, int N, int Cin,
+                                   int Cout, int Tout, int Kw, int stride, int dil, void* splitk_ws, int64_t splitk_ws_bytes,
+                                   void* stream) {
     W2L_CHECK_ARG(xp && w && y, "conv1d_igemm: null pointer");
     W2L_CHECK_ARG(N > 0 && Tout > 0 && Kw > 0 && (stride == 1 || stride == 2) && dil > 0,
                   "conv1d_igemm: bad sizes (stride must be 1 or 2)");
@@ -470,13 +549,19 @@ extern "C" int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_row
     // BatchNorm partial statistics are laid out per 128-row column tile (w2l_conv_stat_tiles)
     const int ci = choose_cfg(N, Cin, Cout, Tout, Kw, stride, dil, stats_partial != nullptr);
     W2L_CHECK_ARG(ci >= 0, "conv1d_igemm: no block shape fits LDS (Kw=%d dil=%d stride=%d)", Kw, dil, stride);
-    const int pipe = ci / kNumCfgs;
+    const int pipe = (ci % kBaseCfgs) / kNumCfgs;
     const TileCfg& c = kCfgs[ci % kNumCfgs];
     const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
     p.tiles_t = (Tout + bn - 1) / bn;
     p.ncols = N * p.tiles_t;
     p.xrows_lds = cfg_xrows(c, stride, Kw, dil);
-    const int tiles_m = (Cout + bm - 1) / bm;
+    // a split-K choice (measured with a workspace) silently degrades to one block per tile when the caller brings none
+    int splits = kSplits[ci / kBaseCfgs];
+    if (!split_feasible(ci % kNumCfgs, splits, N, Cin, Cout, Tout, Kw, splitk_ws, splitk_ws_bytes)) splits = 1;
+    p.splits = splits;
+    p.tickets = (unsigned*)splitk_ws;
+    p.slabs = splitk_ws ? (float*)((char*)splitk_ws + kTicketBytes) : nullptr;
+    const int tiles_m = ((Cout + bm - 1) / bm) * splits;        // grid = tiles x splits (launch_cfg multiplies by ncols)
     const size_t lds = 2 * (size_t)bm * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
     hipStream_t st = (hipStream_t)stream;
     switch (ci % kNumCfgs) {
@@ -504,12 +589,29 @@ extern "C" int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_row
     }
 }
 
+extern "C" int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y,
+                                int y_f32, int accumulate, const float* bias, float* stats_partial, int N, int Cin,
+                                int Cout, int Tout, int Kw, int stride, int dil, void* stream) {
+    return w2l_conv1d_igemm_ws(xp, x_bstride, x_rows_total, w, y, y_f32, accumulate, bias, stats_partial, N, Cin, Cout, Tout,
+                               Kw, stride, dil, nullptr, 0, stream);
+}
+
+extern "C" int64_t w2l_conv_splitk_workspace_bytes(int N, int Cout, int Tout) {
+    size_t need = 0;
+    for (int i = 0; i < kNumCfgs; ++i) {
+        const size_t b = splitk_bytes(i, kSplits[kNumSplits - 1], N, Cout, Tout);
+        if (b > need) need = b;
+    }
+    return (int64_t)need;
+}
+
 // Measure every feasible block shape for this problem on the caller's device and remember the fastest.
 // EXPLICITLY synchronising (hipEventSynchronize): call it once per shape during warm-up, never inside a
 // captured / latency-critical region.  Only for accumulate == 0 launches (the output is simply rewritten).
-extern "C" int w2l_conv1d_igemm_tune(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y,
-                                     int y_f32, const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout,
-                                     int Kw, int stride, int dil, int reps, void* stream) {
+extern "C" int w2l_conv1d_igemm_tune_ws(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y,
+                                        int y_f32, const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout,
+                                        int Kw, int stride, int dil, int reps, void* splitk_ws, int64_t splitk_ws_bytes,
+                                        void* stream) {
     const bool need128 = stats_partial != nullptr;
     const ShapeKey key(N, Cin, Cout, Tout, Kw, stride, dil, need128 ? 1 : 0);
     {
@@ -524,16 +626,32 @@ extern "C" int w2l_conv1d_igemm_tune(const void* xp, int64_t x_bstride, int64_t 
     float best_ms = 1e30f;
     const int saved = g_force_cfg;
     if (reps < 1) reps = 1;
-    for (int i = 0; i < 2 * kNumCfgs; ++i) {
+    if (splitk_ws) (void)hipMemsetAsync(splitk_ws, 0, kTicketBytes, st);     // tickets start from zero whatever ran before
+    for (int i = 0; i < kBaseCfgs * kNumSplits; ++i) {
         if (!cfg_feasible(i, Kw, stride, dil, need128)) continue;
+        const int ci = i % kNumCfgs, splits = kSplits[i / kBaseCfgs];
+        if (splits > 1) {
+            // split-K is only a candidate where one block per tile leaves CUs idle (a partly filled last round, or fewer
+            // tiles than CUs) and where it does not flood the chip with short blocks
+            if (!split_feasible(ci, splits, N, Cin, Cout, Tout, Kw, splitk_ws, splitk_ws_bytes)) continue;
+            const TileCfg& c = kCfgs[ci];
+            const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
+            const size_t lds = 2 * (size_t)bm * ROWB + 2 * (size_t)cfg_xrows(c, stride, Kw, dil) * ROWB;
+            int per_cu = (int)((160 * 1024) / lds);
+            if (per_cu > 16 / (c.mw * c.nw)) per_cu = 16 / (c.mw * c.nw);
+            const long slots = 256L * (per_cu < 1 ? 1 : per_cu);
+            const long blocks = (long)((Cout + bm - 1) / bm) * N * ((Tout + bn - 1) / bn);
+            const double util = (double)blocks / (double)(((blocks + slots - 1) / slots) * slots);
+            if (util > 0.92 || blocks * splits > 6 * slots || (Cin / BK) * Kw / splits < 8) continue;
+        }
         g_force_cfg = i;
-        int rc = w2l_conv1d_igemm(xp, x_bstride, x_rows_total, w, y, y_f32, 0, bias, stats_partial, N, Cin, Cout, Tout, Kw,
-                                  stride, dil, stream);                        // warm-up (also validates the launch)
+        int rc = w2l_conv1d_igemm_ws(xp, x_bstride, x_rows_total, w, y, y_f32, 0, bias, stats_partial, N, Cin, Cout, Tout, Kw,
+                                     stride, dil, splitk_ws, splitk_ws_bytes, stream);   // warm-up (also validates the launch)
         if (rc != 0) continue;
         (void)hipEventRecord(e0, st);
         for (int r = 0; r < reps; ++r)
-            w2l_conv1d_igemm(xp, x_bstride, x_rows_total, w, y, y_f32, 0, bias, stats_partial, N, Cin, Cout, Tout, Kw,
-                             stride, dil, stream);
+            w2l_conv1d_igemm_ws(xp, x_bstride, x_rows_total, w, y, y_f32, 0, bias, stats_partial, N, Cin, Cout, Tout, Kw,
+                                stride, dil, splitk_ws, splitk_ws_bytes, stream);
         (void)hipEventRecord(e1, st);
         if (hipEventSynchronize(e1) != hipSuccess) continue;
         float ms = 0.f;
@@ -547,6 +665,13 @@ extern "C" int w2l_conv1d_igemm_tune(const void* xp, int64_t x_bstride, int64_t 
     std::lock_guard<std::mutex> lock(g_tuned_mu);
     g_tuned[key] = best;
     return 0;
+}
+
+extern "C" int w2l_conv1d_igemm_tune(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y,
+                                     int y_f32, const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout,
+                                     int Kw, int stride, int dil, int reps, void* stream) {
+    return w2l_conv1d_igemm_tune_ws(xp, x_bstride, x_rows_total, w, y, y_f32, bias, stats_partial, N, Cin, Cout, Tout, Kw,
+                                    stride, dil, reps, nullptr, 0, stream);
 }
 
 // Tuning-cache (de)serialisation used by w2l_tune_save / w2l_tune_load (runtime.hip).

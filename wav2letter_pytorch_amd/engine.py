@@ -252,8 +252,23 @@ def _padded_vec(v: Optional[torch.Tensor], cp: int, fill: float) -> Optional[tor
     return out
 
 
+SPLITK_WS_CAP = 1 << 30            # bytes; larger problems simply lose the split configurations that do not fit
+_splitk_ws = {}                    # device index -> zero-initialised workspace (tickets + fp32 slabs) of the main stream
+
+
+def _splitk_workspace(dev, n, cout, tout):
+    """The split-K workspace of ``dev`` (include/w2l_hip.h: w2l_conv1d_igemm_ws), grown on demand.  Every implicit-GEMM launch
+    of the engine is on the caller's stream, so one workspace per device serves them all."""
+    need = min(int(lib.w2l_conv_splitk_workspace_bytes(n, cout, tout)), SPLITK_WS_CAP)
+    ws = _splitk_ws.get(dev.index)
+    if ws is None or ws.numel() < need:
+        ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+        _splitk_ws[dev.index] = ws
+    return ws
+
+
 def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw, stride, dil, precise, alg_flops=0.0):
-    """y = conv(x) through w2l_conv1d_igemm; split-bf16 (3 launches, fp32 accumulate) when precise."""
+    """y = conv(x) through w2l_conv1d_igemm_ws; split-bf16 (3 launches, fp32 accumulate) when precise."""
     n = x.N
     bstride = x.rows * x.CP
     rows_total = n * x.rows - row_off
@@ -264,18 +279,19 @@ def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw
 
     st = stream_ptr()
     if not precise:
+        ws = _splitk_workspace(x.hi.device, n, Cout, Tout)
         if AUTOTUNE:
             key = (n, Cin, Cout, Tout, Kw, stride, dil, stats is not None, x.hi.device.index)
             if key not in _tuned_shapes:       # once per shape and device, during the first (warm-up) step
                 _tuned_shapes.add(key)
                 _tune_state['dirty'] = True
-                check(lib.w2l_conv1d_igemm_tune(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y),
-                                                int(y.dtype == torch.float32), ptr(bias), ptr(stats), n, Cin, Cout, Tout,
-                                                Kw, stride, dil, 2, st), 'w2l_conv1d_igemm_tune')
+                check(lib.w2l_conv1d_igemm_tune_ws(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y),
+                                                   int(y.dtype == torch.float32), ptr(bias), ptr(stats), n, Cin, Cout, Tout,
+                                                   Kw, stride, dil, 2, ptr(ws), ws.numel(), st), 'w2l_conv1d_igemm_tune_ws')
         with _timed('conv_igemm_kernel', alg_flops):
-            check(lib.w2l_conv1d_igemm(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y), int(y.dtype == torch.float32),
-                                       0, ptr(bias), ptr(stats), n, Cin, Cout, Tout, Kw, stride, dil, st),
-                  'w2l_conv1d_igemm')
+            check(lib.w2l_conv1d_igemm_ws(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y), int(y.dtype == torch.float32),
+                                          0, ptr(bias), ptr(stats), n, Cin, Cout, Tout, Kw, stride, dil, ptr(ws), ws.numel(),
+                                          st), 'w2l_conv1d_igemm_ws')
         return
     assert y.dtype == torch.float32
     check(lib.w2l_conv1d_igemm(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y), 1, 0, ptr(bias), None, n, Cin, Cout,
