@@ -109,11 +109,10 @@ def main():
     tg_d, tl_d = tg.to(dev), tl.to(dev)
     ol = model.compute_output_lengths(il).to(dev)
 
-    il_d = il.to(dev)
 
     def step():
         opt.zero_grad(set_to_none=True)
-        out, _ = model(x, il_d if args.model == 'jasper10x5' else None)
+        out, _ = model(x, il if args.model == 'jasper10x5' else None)       # host lengths, as _collator hands them over
         loss = model.criterion(out.transpose(0, 1), tg_d, ol, tl_d)
         loss.backward()
         if not args.no_optimizer:

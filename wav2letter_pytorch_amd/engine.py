@@ -366,9 +366,7 @@ class StackEngine:
         dev = x.device
         st = stream_ptr
         ctx = {'units': [], 'acts': [], 'training': training, 'x_shape': (N, C0, T0), 'want_dx': bool(want_input_grad)}
-        lens_dev = None
-        if lens is not None and any(u.update_lens or u.mask_out for u in self.units):
-            lens_dev = lens.to(device=dev, dtype=torch.int32)
+        lens_dev, mid_lens, out_lens, lens_final = self._plan_lens(lens, dev)
         # ---- activation 0: the spectrogram, channels-last, padded for its consumers
         pl, pr, mode = self._in_pad_for(0)
         cp0 = padded_channels(C0)
@@ -377,8 +375,6 @@ class StackEngine:
         check(lib.w2l_nct_to_ntc(ptr(x), N, C0, T0, cp0, pl, pr, mode, ptr(lens_dev), ptr(a_hi), ptr(a_lo), st()),
               'w2l_nct_to_ntc')
         acts: List[Act] = [Act(a_hi, a_lo, N, T0, C0, cp0, pl, pr, mode, lens_dev)]
-        cur_lens = lens_dev
-        cur_lens_f = lens_dev.float() if lens_dev is not None else None
 
         for ui, u in enumerate(self.units):
             uc = _UnitCtx(unit=u)
@@ -386,10 +382,7 @@ class StackEngine:
             conv = u.main
             if u.dw is not None:            # depthwise conv -> (masked) intermediate activation -> 1x1 pointwise conv
                 dwc = u.dw
-                if u.update_lens and cur_lens_f is not None:
-                    cur_lens_f = (cur_lens_f + (dwc.pad_l + dwc.pad_r) - dwc.dilation * (dwc.kernel - 1) - 1) / dwc.stride + 1
-                    cur_lens = cur_lens_f.to(torch.int32)
-                src = self._dw_forward(dwc, src, cur_lens if u.update_lens else None)
+                src = self._dw_forward(dwc, src, mid_lens[ui])
                 uc.mid = src
             y, stats, Tout = self._conv_forward(conv, src, need_stats=conv.has_bn and training)
             uc.y, uc.Tout = y, Tout
@@ -404,12 +397,7 @@ class StackEngine:
                 uc.y2 = y2
                 if u.res.has_bn:
                     uc.scale2, uc.shift2, uc.mean2, uc.invstd2 = self._bn_finalize(u.res, stats2, N * Tout, coutp, training)
-            # length bookkeeping (jasper.py:109-112: true division, truncated at the next mask)
-            if u.update_lens and cur_lens_f is not None:
-                cur_lens_f = (cur_lens_f + (conv.pad_l + conv.pad_r) - conv.dilation * (conv.kernel - 1) - 1) / conv.stride + 1
-                cur_lens = cur_lens_f.to(torch.int32)
-            if u.mask_out and cur_lens is not None:
-                uc.lens_out = cur_lens
+            uc.lens_out = out_lens[ui]               # length mask of this unit's output (None: not masked)
             # ---- BN-apply + dropout + activation -> padded input of the next conv
             opl, opr, omode = self._in_pad_for(ui + 1)
             out_hi = torch.empty(N, opl + Tout + opr, coutp, dtype=torch.bfloat16, device=dev)
@@ -439,8 +427,46 @@ class StackEngine:
         ctx['acts'] = acts
         ctx['out'] = out
         ctx['softmax_mode'] = softmax_mode
-        ctx['lens_out'] = cur_lens_f if cur_lens_f is not None else None
+        ctx['lens_out'] = lens_final
         return out, ctx
+
+    def _plan_lens(self, lens, dev):
+        """Length bookkeeping of the MaskedConv1d chain (jasper.py:109-121): lens <- (lens + 2p - d(k-1) - 1) / s + 1 in
+        float (true division), truncated to integers where a mask is applied.  Returns (int32 device lengths of the input,
+        per-unit lengths after the depthwise conv, per-unit output mask lengths, final float lengths).
+
+        With host lengths (what _collator hands over, data_loader.py:150) the whole chain is evaluated on the host with the
+        reference's own torch ops and uploaded in ONE copy; device lengths take the same arithmetic as device ops (a few tiny
+        launches per conv, and the caller pays a sync to read the result back)."""
+        n_units = len(self.units)
+        mid, outl = [None] * n_units, [None] * n_units
+        if lens is None or not any(u.update_lens or u.mask_out for u in self.units):
+            return None, mid, outl, None
+        on_host = not lens.is_cuda
+        cur = lens.to(torch.int32) if on_host else lens.to(device=dev, dtype=torch.int32)
+        first = cur
+        cur_f = cur.float()
+        for ui, u in enumerate(self.units):
+            if u.dw is not None and u.update_lens:
+                c = u.dw
+                cur_f = (cur_f + (c.pad_l + c.pad_r) - c.dilation * (c.kernel - 1) - 1) / c.stride + 1
+                cur = cur_f.to(torch.int32)
+                mid[ui] = cur
+            if u.update_lens:
+                c = u.main
+                cur_f = (cur_f + (c.pad_l + c.pad_r) - c.dilation * (c.kernel - 1) - 1) / c.stride + 1
+                cur = cur_f.to(torch.int32)
+            if u.mask_out:
+                outl[ui] = cur
+        if not on_host:
+            return first, mid, outl, cur_f
+        rows = [first] + [t for t in mid if t is not None] + [t for t in outl if t is not None]
+        packed = torch.stack(rows).pin_memory().to(dev, non_blocking=True)
+        it = iter(packed.unbind(0))
+        first_d = next(it)
+        mid = [next(it) if t is not None else None for t in mid]
+        outl = [next(it) if t is not None else None for t in outl]
+        return first_d, mid, outl, cur_f
 
     def _conv_forward(self, conv: ConvSpec, src: Act, need_stats: bool, force_f32: bool = False):
         if src.pad_l < conv.pad_l or src.pad_r < conv.pad_r:
