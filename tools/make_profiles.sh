@@ -17,4 +17,7 @@ bash tools/pmc_conv.sh 11 > $OUT/pmc_layer11.txt 2>&1
 cp gpurun_out/pmc_11/summary.json $OUT/pmc_layer11.json
 python3 bench.py --model jasper10x5 --batch 16 --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_jasper10x5.json
 python3 bench.py --mid-layers 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_w2l_default_mid1.json
+for n in 8 16; do python3 bench.py --batch $n --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_w2l_n$n.json; done
+python3 tools/bench_features.py 2>/dev/null | tail -1 > $OUT/bench_features.txt
+python3 tools/bench_conv.py --tune > $OUT/conv_layers.txt 2>&1
 cat $OUT/bench.json | cut -c1-1200
