@@ -121,6 +121,20 @@ int w2l_conv1d_wgrad(const void* dy, int64_t dy_bstride, const void* xp, int64_t
                      float* dw, int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int accumulate,
                      void* stream);
 
+/* The weight gradient with a split-K workspace (device memory owned by the caller, >= 64 KiB, zero-filled once when
+ * allocated; one per stream of execution): the partial tiles of a split reduction go through fp32 slabs and the block
+ * that draws a tile's last ticket sums them in split order and writes dw with plain stores -- no atomics, no zero-filled
+ * dw, bit-reproducible gradients.  A workspace too small for the chosen split falls back to the atomic path:
+ * w2l_wgrad_needs_zero_ws tells whether dw must be zero-filled for this launch. */
+int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride, int64_t x_rows_total, float* dw,
+                        int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int accumulate, void* ws,
+                        int64_t ws_bytes, void* stream);
+int w2l_conv1d_wgrad_tune_ws(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride, int64_t x_rows_total,
+                             float* dw_scratch, int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int reps,
+                             void* ws, int64_t ws_bytes, void* stream);
+int w2l_wgrad_needs_zero_ws(int N, int Cin, int Cout, int Tout, int Kw, int64_t ws_bytes);
+int64_t w2l_wgrad_workspace_bytes(int Cin, int Cout, int Kw);
+
 /* Testing / profiling hook: pin the split count (0 = automatic) and the block order (0/1; -1 = automatic). */
 void w2l_wgrad_force_plan(int splits, int order);
 

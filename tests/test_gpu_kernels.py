@@ -225,19 +225,40 @@ def test_conv_wgrad_every_plan(L):
     dyh, xh = dyp.to(torch.bfloat16).cuda(), xp.to(torch.bfloat16).cuda()
     wr = bf(w).requires_grad_(True)
     F.conv1d(F.pad(bf(x), (pl, pr), mode='reflect'), wr, None, dilation=d).backward(bf(dy))
+    ws = torch.zeros(int(L.lib.w2l_wgrad_workspace_bytes(Cin, Cout, Kw)), dtype=torch.uint8, device='cuda')
     for splits in (1, 2, 3, 5, 18):
         for order in (0, 1):
+            # (a) without a workspace: fp32 atomics into a zero-filled dw
             dw = torch.zeros(Kw, Cout, Cin, device='cuda')
             L.lib.w2l_wgrad_force_plan(splits, order)
             try:
                 assert L.lib.w2l_wgrad_needs_zero(N, Cin, Cout, Tout, Kw) == int(splits > 1)
                 L.check(L.lib.w2l_conv1d_wgrad(C.c_void_p(dyh.data_ptr() + hb * Cout * 2), drows * Cout, L.ptr(xh), rows * Cin,
                                                N * rows, L.ptr(dw), N, Cin, Cout, Tout, Kw, s, d, 0, L.stream_ptr()))
+                torch.cuda.synchronize()
+                got = dw.cpu().permute(1, 2, 0)
+                assert relerr(got, wr.grad) < 2e-3, (splits, order, relerr(got, wr.grad))
+                # (b) with the workspace: slabs + ticket, plain stores over a NaN-filled dw (nothing may survive), twice:
+                # bit-identical results, tickets back at zero
+                assert L.lib.w2l_wgrad_needs_zero_ws(N, Cin, Cout, Tout, Kw, ws.numel()) == 0
+                outs = []
+                for rep in range(2):
+                    dw2 = torch.full((Kw, Cout, Cin), float('nan'), device='cuda')
+                    L.check(L.lib.w2l_conv1d_wgrad_ws(C.c_void_p(dyh.data_ptr() + hb * Cout * 2), drows * Cout, L.ptr(xh),
+                                                      rows * Cin, N * rows, L.ptr(dw2), N, Cin, Cout, Tout, Kw, s, d, 0, L.ptr(ws),
+                                                      ws.numel(), L.stream_ptr()))
+                    torch.cuda.synchronize()
+                    outs.append(dw2)
+                assert torch.equal(outs[0], outs[1]) and not ws[:65536].any(), (splits, order)
+                assert relerr(outs[0].cpu().permute(1, 2, 0), wr.grad) < 2e-3, (splits, order)
+                # accumulate = 1 adds to what is there
+                L.check(L.lib.w2l_conv1d_wgrad_ws(C.c_void_p(dyh.data_ptr() + hb * Cout * 2), drows * Cout, L.ptr(xh), rows * Cin,
+                                                  N * rows, L.ptr(outs[1]), N, Cin, Cout, Tout, Kw, s, d, 1, L.ptr(ws), ws.numel(),
+                                                  L.stream_ptr()))
+                torch.cuda.synchronize()
+                assert relerr(outs[1].cpu().permute(1, 2, 0), 2 * wr.grad) < 2e-3, (splits, order)
             finally:
                 L.lib.w2l_wgrad_force_plan(0, -1)
-            torch.cuda.synchronize()
-            got = dw.cpu().permute(1, 2, 0)
-            assert relerr(got, wr.grad) < 2e-3, (splits, order, relerr(got, wr.grad))
 
 
 @pytest.mark.parametrize('case', [c for c in CONV_CASES if c[4] == 1])

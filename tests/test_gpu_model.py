@@ -364,3 +364,26 @@ def test_w2l_long_utterance_T16000_fp32():
     errs, stats, out, out_lens, ref = compare_step(model, layers, sd, x, il, tg, tl, 'fp32')
     check(errs, stats, 'fp32', grad_tol=5e-2)           # see test_jasper_long_utterance_T16000
     assert out.shape == (2, 8000, 29)
+
+
+def test_deterministic_mode_is_bit_reproducible(monkeypatch):
+    """W2L_DETERMINISTIC: weight-gradient split reductions summed in a fixed order (slabs + ticket) instead of fp32 atomics:
+    two runs of the same step give bit-identical gradients, and they agree with the default (atomic) path"""
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd import engine as E
+    layers = [(128, 11, 2, 1, 0.0), (256, 13, 1, 1, 0.0), (128, 29, 1, 2, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=41)
+    x, il, tg, tl = O.synthetic_batch(8, 400, seed=42, s_lo=10, s_hi=30)
+
+    def grads(det):
+        monkeypatch.setattr(E, 'DETERMINISTIC_WGRAD', det)
+        model = build_w2l(layers, sd, 'bf16').train()
+        out, ol = model(x.cuda(), il)
+        model.criterion(out.transpose(0, 1), tg, ol, tl).backward()
+        torch.cuda.synchronize()
+        return [p.grad.detach().clone() for p in model.parameters()]
+
+    a, b, c = grads(True), grads(True), grads(False)
+    for ga, gb, gc in zip(a, b, c):
+        assert torch.equal(ga, gb)
+        assert scale_err(ga.cpu().numpy(), gc.cpu().numpy()) < 1e-5

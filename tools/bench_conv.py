@@ -82,9 +82,12 @@ def main():
                                               dy.shape[0] - (h - hb), L.ptr(wd), L.ptr(dx), 0, 0, None, None, 1, cout, cin,
                                               N * per, kw, 1, d, L.ptr(ws), ws.numel(), st))
 
+        wws = torch.zeros(min(1 << 30, int(L.lib.w2l_wgrad_workspace_bytes(cin, cout, kw))), dtype=torch.uint8, device='cuda')
+        wwsa = (L.ptr(wws), wws.numel()) if not args.no_splitk else (None, 0)
+
         def wgrad():
-            L.check(L.lib.w2l_conv1d_wgrad(C.c_void_p(dy.data_ptr() + h * cout * 2), per * cout, L.ptr(x),
-                                           rows * cin, N * rows, L.ptr(dw), N, cin, cout, Tout, kw, s, d, 0, st))
+            L.check(L.lib.w2l_conv1d_wgrad_ws(C.c_void_p(dy.data_ptr() + h * cout * 2), per * cout, L.ptr(x),
+                                              rows * cin, N * rows, L.ptr(dw), N, cin, cout, Tout, kw, s, d, 0, *wwsa, st))
 
         if args.sweep:
             res = []
@@ -109,8 +112,8 @@ def main():
                 L.check(L.lib.w2l_conv1d_igemm_tune_ws(C.c_void_p(dy.data_ptr() + (h - hb) * cout * 2), dy.shape[0] * cout,
                                                        dy.shape[0] - (h - hb), L.ptr(wd), L.ptr(dx), 0, None, None, 1, cout, cin,
                                                        N * per, kw, 1, d, 3, *wsa, st))
-            L.check(L.lib.w2l_conv1d_wgrad_tune(C.c_void_p(dy.data_ptr() + h * cout * 2), per * cout, L.ptr(x), rows * cin,
-                                                N * rows, L.ptr(dw), N, cin, cout, Tout, kw, s, d, 3, st))
+            L.check(L.lib.w2l_conv1d_wgrad_tune_ws(C.c_void_p(dy.data_ptr() + h * cout * 2), per * cout, L.ptr(x), rows * cin,
+                                                   N * rows, L.ptr(dw), N, cin, cout, Tout, kw, s, d, 3, *wwsa, st))
             dw.zero_()
         tf = timeit(fwd, args.reps)
         td = timeit(dgrad, args.reps) if s == 1 else float('nan')

@@ -41,6 +41,11 @@ struct WgradParams {
     int tiles_m, tiles_n, kgroups, tsteps, total_steps, steps_per_split, atomic;
     int order;                 // block order inside a split: 1 = tap group fastest, 0 = co tile fastest
     int xrows_lds;
+    // split-K through a workspace (w2l_conv1d_wgrad_ws): partial tiles go to fp32 slabs, the block that draws a tile's last
+    // ticket sums them in split order and writes dw with plain stores -- no atomics, no zero fill, bit-reproducible
+    int splits, accumulate;
+    float* slabs;              // [tiles][splits][KWB*128*128]; NULL: fp32 atomics into a zero-filled dw
+    unsigned* tickets;         // [tiles], zero between launches
 };
 
 // 16 B per lane global -> LDS (LDS-DMA): lane l lands at lds_wave_base + 16*l.  Written as inline asm on purpose: with
@@ -84,6 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     int lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int split = lin / gridDim.x;
     int tile = lin - split * gridDim.x;
+    const int tile_id = tile;
     int tm, tn, kw0;
     if (p.order) {
         kw0 = (tile % p.kgroups) * KWB;            // first tap of this block's group
@@ -277,6 +283,53 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     if (KWB == 1 || ntaps == KWB) run(std::integral_constant<int, KWB>{});
     else run(std::integral_constant<int, 1>{});
 
+    // ---- split-K through slabs: publish the partial tile, draw a ticket; only the last arriver goes on.  Agent-scope
+    // release before the ticket / acquire after it: correct wherever the tile's blocks ran (they are a whole grid row apart).
+    if (p.slabs != nullptr && p.splits > 1) {
+        constexpr int TILE_F = KWB * BM * BNC;
+        float* slab = p.slabs + ((int64_t)tile_id * p.splits + split) * TILE_F;
+#pragma unroll
+        for (int tp = 0; tp < KWB; ++tp)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    *reinterpret_cast<f32x4*>(slab + (((tp * 4 + mi) * 4 + ni) * 256 + tid) * 4) = acc[tp][mi][ni];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // stores complete; the K loop's LDS is dead
+        unsigned* flag = reinterpret_cast<unsigned*>(smem);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *flag = __hip_atomic_fetch_add(&p.tickets[tile_id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (*flag != (unsigned)(p.splits - 1)) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&p.tickets[tile_id], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tp = 0; tp < KWB; ++tp)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[tp][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* base = p.slabs + (int64_t)tile_id * p.splits * TILE_F;
+        for (int sp = 0; sp < p.splits; ++sp) {
+            const float* sl = base + (int64_t)sp * TILE_F;
+#pragma unroll
+            for (int tp = 0; tp < KWB; ++tp)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[tp][mi][ni] += *reinterpret_cast<const f32x4*>(sl + (((tp * 4 + mi) * 4 + ni) * 256 + tid) * 4);
+        }
+    }
+
     // ---- epilogue: acc[tp][mi][ni][r] = dw[kw0+tp][co = m0+wm*64+mi*16+fq*4+r][ci = c0+wn*64+ni*16+fr] ----
     const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
@@ -293,7 +346,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
                     const int co = m0 + wm * 64 + mi * 16 + fq * 4 + r;
                     if (co < p.Cout && ci < p.Cin) {
                         float* dst = base + (int64_t)co * p.Cin + ci;
-                        if (p.atomic) atomicAdd(dst, acc[tp][mi][ni][r]);
+                        if (p.atomic) atomicAdd(dst, acc[tp][mi][ni][r]);          // several blocks per element (no workspace)
+                        else if (p.accumulate) *dst += acc[tp][mi][ni][r];         // one block per element: plain read-add-store
                         else *dst = acc[tp][mi][ni][r];
                     }
                 }
@@ -358,9 +412,35 @@ extern "C" int w2l_wgrad_needs_zero(int N, int Cin, int Cout, int Tout, int Kw) 
     return plan_splits(N, Cin, Cout, Tout, Kw, nullptr) > 1;
 }
 
-extern "C" int w2l_conv1d_wgrad(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride,
-                                int64_t x_rows_total, float* dw, int N, int Cin, int Cout, int Tout, int Kw,
-                                int stride, int dil, int accumulate, void* stream) {
+constexpr size_t kWgradTicketBytes = 64 * 1024;
+
+static size_t wgrad_ws_need(int Cin, int Cout, int Kw, int splits) {
+    const int kwb = Kw > 1 ? KWB_DEFAULT : 1;
+    const size_t tiles = (size_t)((Cout + BM - 1) / BM) * ((Cin + BNC - 1) / BNC) * ((Kw + kwb - 1) / kwb);
+    return kWgradTicketBytes + tiles * splits * kwb * BM * BNC * sizeof(float);
+}
+
+static bool wgrad_ws_ok(int Cin, int Cout, int Kw, int splits, const void* ws, int64_t ws_bytes) {
+    if (ws == nullptr) return false;
+    const int kwb = Kw > 1 ? KWB_DEFAULT : 1;
+    const size_t tiles = (size_t)((Cout + BM - 1) / BM) * ((Cin + BNC - 1) / BNC) * ((Kw + kwb - 1) / kwb);
+    return tiles * sizeof(unsigned) <= kWgradTicketBytes && wgrad_ws_need(Cin, Cout, Kw, splits) <= (size_t)ws_bytes;
+}
+
+// with a workspace of ws_bytes: does the launch still add into dw with atomics (i.e. need a zero-filled dw)?
+extern "C" int w2l_wgrad_needs_zero_ws(int N, int Cin, int Cout, int Tout, int Kw, int64_t ws_bytes) {
+    const int splits = plan_splits(N, Cin, Cout, Tout, Kw, nullptr);
+    if (splits <= 1) return 0;
+    return wgrad_ws_need(Cin, Cout, Kw, splits) <= (size_t)(ws_bytes > 0 ? ws_bytes : 0) ? 0 : 1;
+}
+
+extern "C" int64_t w2l_wgrad_workspace_bytes(int Cin, int Cout, int Kw) {
+    return (int64_t)wgrad_ws_need(Cin, Cout, Kw, 32);      // 32 = the largest split count the tuner tries
+}
+
+extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride,
+                                   int64_t x_rows_total, float* dw, int N, int Cin, int Cout, int Tout, int Kw,
+                                   int stride, int dil, int accumulate, void* ws, int64_t ws_bytes, void* stream) {
     W2L_CHECK_ARG(dy && xp && dw, "conv1d_wgrad: null pointer");
     W2L_CHECK_ARG(N > 0 && Tout > 0 && Kw > 0 && stride > 0 && dil > 0, "conv1d_wgrad: bad sizes");
     W2L_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && Cin > 0 && Cout > 0,
@@ -380,7 +460,12 @@ extern "C" int w2l_conv1d_wgrad(const void* dy, int64_t dy_bstride, const void* 
     const int splits = plan_splits(N, Cin, Cout, Tout, Kw, &p.tsteps, &p.order);
     p.total_steps = N * p.tsteps;
     p.steps_per_split = (p.total_steps + splits - 1) / splits;
-    p.atomic = (splits > 1) || accumulate;
+    const bool slabs = splits > 1 && wgrad_ws_ok(Cin, Cout, Kw, splits, ws, ws_bytes);
+    p.splits = splits;
+    p.accumulate = accumulate;
+    p.tickets = slabs ? (unsigned*)ws : nullptr;
+    p.slabs = slabs ? (float*)((char*)ws + kWgradTicketBytes) : nullptr;
+    p.atomic = splits > 1 && !slabs;
     const int kwb = Kw > 1 ? KWB_DEFAULT : 1;
     p.kgroups = (Kw + kwb - 1) / kwb;
     const int xr = (BT - 1) * stride + (kwb - 1) * dil + 1;
@@ -398,11 +483,18 @@ extern "C" int w2l_conv1d_wgrad(const void* dy, int64_t dy_bstride, const void* 
     return 0;
 }
 
+extern "C" int w2l_conv1d_wgrad(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride,
+                                int64_t x_rows_total, float* dw, int N, int Cin, int Cout, int Tout, int Kw,
+                                int stride, int dil, int accumulate, void* stream) {
+    return w2l_conv1d_wgrad_ws(dy, dy_bstride, xp, x_bstride, x_rows_total, dw, N, Cin, Cout, Tout, Kw, stride, dil, accumulate,
+                               nullptr, 0, stream);
+}
+
 // Measure candidate split-K factors for this problem on the caller's device and remember the fastest
 // (SYNCHRONISING; warm-up only).  `dw_scratch` is a throw-away [Kw][Cout][Cin] fp32 buffer.
-extern "C" int w2l_conv1d_wgrad_tune(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride,
-                                     int64_t x_rows_total, float* dw_scratch, int N, int Cin, int Cout, int Tout, int Kw,
-                                     int stride, int dil, int reps, void* stream) {
+extern "C" int w2l_conv1d_wgrad_tune_ws(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride,
+                                        int64_t x_rows_total, float* dw_scratch, int N, int Cin, int Cout, int Tout, int Kw,
+                                        int stride, int dil, int reps, void* ws, int64_t ws_bytes, void* stream) {
     const WShapeKey key(N, Cin, Cout, Tout, Kw);
     {
         std::lock_guard<std::mutex> lock(g_wtuned_mu);
@@ -414,6 +506,7 @@ extern "C" int w2l_conv1d_wgrad_tune(const void* dy, int64_t dy_bstride, const v
     hipStream_t st = (hipStream_t)stream;
     const int total = N * ((Tout + BT - 1) / BT);
     const int cands[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32};
+    if (ws) (void)hipMemsetAsync(ws, 0, kWgradTicketBytes, st);
     int best = -1;
     float best_ms = 1e30f;
     if (reps < 1) reps = 1;
@@ -423,14 +516,15 @@ extern "C" int w2l_conv1d_wgrad_tune(const void* dy, int64_t dy_bstride, const v
         if (s > total || s > 0xffff || (s > 1 && total / s < 4)) break;
         g_force_splits = s;
         g_force_order = order;
-        int rc = w2l_conv1d_wgrad(dy, dy_bstride, xp, x_bstride, x_rows_total, dw_scratch, N, Cin, Cout, Tout, Kw, stride, dil,
-                                  0, stream);
+        const bool zero = s > 1 && !wgrad_ws_ok(Cin, Cout, Kw, s, ws, ws_bytes);    // atomics need a zero-filled dw
+        int rc = w2l_conv1d_wgrad_ws(dy, dy_bstride, xp, x_bstride, x_rows_total, dw_scratch, N, Cin, Cout, Tout, Kw, stride,
+                                     dil, 0, ws, ws_bytes, stream);
         if (rc != 0) continue;
         (void)hipEventRecord(e0, st);
         for (int r = 0; r < reps; ++r) {
-            if (s > 1) (void)hipMemsetAsync(dw_scratch, 0, bytes, st);      // the zero fill a split launch needs is part of its cost
-            w2l_conv1d_wgrad(dy, dy_bstride, xp, x_bstride, x_rows_total, dw_scratch, N, Cin, Cout, Tout, Kw, stride, dil, 0,
-                             stream);
+            if (zero) (void)hipMemsetAsync(dw_scratch, 0, bytes, st);       // that fill is part of the launch's cost
+            w2l_conv1d_wgrad_ws(dy, dy_bstride, xp, x_bstride, x_rows_total, dw_scratch, N, Cin, Cout, Tout, Kw, stride, dil, 0,
+                                ws, ws_bytes, stream);
         }
         (void)hipEventRecord(e1, st);
         if (hipEventSynchronize(e1) != hipSuccess) continue;
@@ -446,6 +540,13 @@ extern "C" int w2l_conv1d_wgrad_tune(const void* dy, int64_t dy_bstride, const v
     std::lock_guard<std::mutex> lock(g_wtuned_mu);
     g_wtuned[key] = best;
     return 0;
+}
+
+extern "C" int w2l_conv1d_wgrad_tune(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride,
+                                     int64_t x_rows_total, float* dw_scratch, int N, int Cin, int Cout, int Tout, int Kw,
+                                     int stride, int dil, int reps, void* stream) {
+    return w2l_conv1d_wgrad_tune_ws(dy, dy_bstride, xp, x_bstride, x_rows_total, dw_scratch, N, Cin, Cout, Tout, Kw, stride, dil,
+                                    reps, nullptr, 0, stream);
 }
 
 // Tuning-cache (de)serialisation used by w2l_tune_save / w2l_tune_load (runtime.hip).

@@ -267,6 +267,21 @@ def _splitk_workspace(dev, n, cout, tout):
     return ws
 
 
+_wgrad_ws = {}                     # device index -> workspace of the stream the weight gradients run on
+# W2L_DETERMINISTIC=1: split weight-gradient reductions go through slabs summed in a fixed order instead of fp32 atomics
+# (bit-reproducible gradients, no zero fills) -- measured 6 % slower on the Wav2Letter table (943 vs 1004 TFLOP/s), so opt-in
+DETERMINISTIC_WGRAD = os.environ.get('W2L_DETERMINISTIC', '0') == '1'
+
+
+def _wgrad_workspace(dev, cin, cout, kw):
+    need = min(int(lib.w2l_wgrad_workspace_bytes(cin, cout, kw)), SPLITK_WS_CAP)
+    ws = _wgrad_ws.get(dev.index)
+    if ws is None or ws.numel() < need:
+        ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+        _wgrad_ws[dev.index] = ws
+    return ws
+
+
 def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw, stride, dil, precise, alg_flops=0.0):
     """y = conv(x) through w2l_conv1d_igemm_ws; split-bf16 (3 launches, fp32 accumulate) when precise."""
     n = x.N
@@ -805,17 +820,22 @@ class StackEngine:
         x_bstride = src.rows * src.CP
         x_rows_total = N * src.rows - row_off
         dy_bstride = (Tout + halo) * pk.coutp          # shared-halo layout: utterance n starts at row halo + n*(Tout+halo)
+        ws = _wgrad_workspace(dev, pk.cinp, pk.coutp, kw) if DETERMINISTIC_WGRAD else None
+        ws_bytes = ws.numel() if ws is not None else 0
         if AUTOTUNE and not self.precise:
             key = ('wgrad', N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, dev.index)
             if key not in _tuned_shapes:       # once per shape and device, during the first (warm-up) step
                 _tuned_shapes.add(key)
                 _tune_state['dirty'] = True
                 scratch = torch.empty(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
-                check(lib.w2l_conv1d_wgrad_tune(C.c_void_p(dy_hi.data_ptr() + halo * pk.coutp * 2), dy_bstride,
-                                                C.c_void_p(src.hi.data_ptr() + row_off * src.CP * 2), x_bstride, x_rows_total,
-                                                ptr(scratch), N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, 2,
-                                                stream_ptr()), 'w2l_conv1d_wgrad_tune')
-        need_zero = bool(lib.w2l_wgrad_needs_zero(N, pk.cinp, pk.coutp, Tout, kw)) or self.precise
+                if self._side is not None:         # the workspace is shared with gradients still running on the side stream
+                    torch.cuda.current_stream(dev).wait_stream(self._side)
+                check(lib.w2l_conv1d_wgrad_tune_ws(C.c_void_p(dy_hi.data_ptr() + halo * pk.coutp * 2), dy_bstride,
+                                                   C.c_void_p(src.hi.data_ptr() + row_off * src.CP * 2), x_bstride, x_rows_total,
+                                                   ptr(scratch), N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, 2,
+                                                   ptr(ws), ws_bytes, stream_ptr()), 'w2l_conv1d_wgrad_tune_ws')
+        # with a workspace, split reductions end in plain stores by the last block of a tile: no zero fill, no atomics
+        need_zero = bool(lib.w2l_wgrad_needs_zero_ws(N, pk.cinp, pk.coutp, Tout, kw, ws_bytes)) or self.precise
         if fork is not None:
             # allocated on the main stream (the caching allocator then owns it there), zero-filled on the side stream:
             # the fill of a split-K gradient is as far off the critical path as the kernel that accumulates into it
@@ -828,24 +848,24 @@ class StackEngine:
                 if need_zero:
                     dw.zero_()
                 return self._wgrad_launch(conv, pk, dw, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total,
-                                          dy_bstride, row_off, direct)
+                                          dy_bstride, row_off, direct, ws)
         alloc = torch.zeros if need_zero else torch.empty
         dw = alloc(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
         return self._wgrad_launch(conv, pk, dw, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total, dy_bstride,
-                                  row_off, direct)
+                                  row_off, direct, ws)
 
     def _wgrad_launch(self, conv, pk, dw, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total, dy_bstride, row_off,
-                      direct):
+                      direct, ws):
         w = conv.weight
         cout, cin, kw = w.shape
         N = src.N
         st = stream_ptr()
 
         def run(dy, x, acc):
-            check(lib.w2l_conv1d_wgrad(C.c_void_p(dy.data_ptr() + halo * pk.coutp * 2), dy_bstride,
-                                       C.c_void_p(x.data_ptr() + row_off * src.CP * 2), x_bstride, x_rows_total,
-                                       ptr(dw), N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, acc, st),
-                  'w2l_conv1d_wgrad')
+            check(lib.w2l_conv1d_wgrad_ws(C.c_void_p(dy.data_ptr() + halo * pk.coutp * 2), dy_bstride,
+                                          C.c_void_p(x.data_ptr() + row_off * src.CP * 2), x_bstride, x_rows_total,
+                                          ptr(dw), N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, acc, ptr(ws),
+                                          ws.numel() if ws is not None else 0, st), 'w2l_conv1d_wgrad_ws')
 
         if not self.precise:
             with _timed('conv_wgrad_kernel', 2.0 * N * Tout * cout * cin * kw):
