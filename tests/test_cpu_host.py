@@ -203,10 +203,12 @@ def _dp_worker(rank, world, port, q):
     red.on_grad(conv_w, view, big)
     for t in smalls:
         red.on_grad(None, t)
+    pool = torch.randn(7, generator=g)                                         # the step engine's per-channel pool
+    red.on_flat(pool)
     red.finish()
     # numpy payloads are pickled by value (torch tensors travel as shared-memory handles that die with this process)
     q.put((rank, mod.lin.weight.detach().numpy().copy(), conv_w.detach().numpy().copy(), big.numpy().copy(),
-           [t.numpy().copy() for t in smalls]))
+           [t.numpy().copy() for t in smalls] + [pool.numpy().copy()]))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -81,6 +81,11 @@ class GradReducer:
             return
         self._launch(buf)
 
+    def on_flat(self, buf: torch.Tensor):
+        """a dense buffer holding many small gradients (the step engine's per-channel pool): one collective, in place"""
+        if self.active:
+            self._launch(buf)
+
     def _launch(self, buf: torch.Tensor):
         if buf.is_cuda:
             ev = torch.cuda.Event()

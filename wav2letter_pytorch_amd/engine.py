@@ -328,6 +328,7 @@ class StackEngine:
         self.precise = precise
         # callbacks for data-parallel overlap (distributed.GradReducer): grad_ready(param, grad, dense_storage)
         self.grad_ready: Optional[Callable] = None
+        self.flat_ready: Optional[Callable] = None        # flat_ready(buffer): every per-channel gradient of the step, one message
         self.backward_done: Optional[Callable[[], None]] = None
         # weight gradients are off the backward critical path (only dgrad feeds the next layer): they run
         # on a side HIP stream so their blocks fill the tail rounds of the dgrad / elementwise kernels
@@ -627,6 +628,14 @@ class StackEngine:
         dev = out.device
         st = stream_ptr
         grads = {}
+        # every per-channel gradient of the step (BatchNorm gamma / beta sums, classifier bias) lives in ONE buffer: a
+        # data-parallel run averages it with one collective instead of ~80 small ones (or a gather + scatter of them)
+        pool_elems = roundup(self.head.cout, 64)
+        for uc in ctx['units']:
+            if uc.unit.main.has_bn or (uc.unit.res is not None and uc.unit.res.has_bn):
+                pool_elems += 4 * acts[uc.out_index].CP
+        small_pool = torch.zeros(pool_elems, dtype=torch.float32, device=dev)       # rows of absent residual branches stay 0
+        pool_off = 0
         # ---- (log_)softmax backward -> classifier gradients
         g_out = g_out.contiguous().float()
         glog = torch.empty_like(out)
@@ -637,14 +646,14 @@ class StackEngine:
         hh = roundup(Th, 64) - Th                    # shared-halo layout (include/w2l_hip.h): halo + N*(T+halo) rows
         dy_hi = torch.empty(hh + N * (Th + hh), pk.coutp, dtype=torch.bfloat16, device=dev)
         dy_lo = torch.empty_like(dy_hi) if precise else None
-        colsum = torch.empty(pk.coutp, dtype=torch.float32, device=dev)
+        colsum = small_pool[pool_off: pool_off + pk.coutp]
+        pool_off += roundup(head.cout, 64)
         check(lib.w2l_pad_cast(ptr(glog), N, Th, L, pk.coutp, hh, ptr(dy_hi), ptr(dy_lo), ptr(colsum), st()),
               'w2l_pad_cast')
         last = acts[-1]
         self._wgrad(head, pk, dy_hi, dy_lo, hh, Th, last, grads)
         if head.bias is not None:
-            grads[id(head.bias)] = colsum[: head.cout]
-            self._notify(head.bias, grads[id(head.bias)])
+            grads[id(head.bias)] = colsum[: head.cout]          # travels with the pool
         act_grads: List[List[tuple]] = [[] for _ in acts]
         act_grads[len(acts) - 1].append(self._dgrad(head, pk, dy_hi, dy_lo, hh, Th, last))
 
@@ -670,7 +679,8 @@ class StackEngine:
                 partial = torch.empty(nb, ncomp, coutp, dtype=torch.float32, device=dev)
                 check(lib.w2l_bn_act_bwd_reduce(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(partial),
                                                 st()), 'w2l_bn_act_bwd_reduce')
-                sums = torch.empty(4, coutp, dtype=torch.float32, device=dev)
+                sums = small_pool[pool_off: pool_off + 4 * coutp].view(4, coutp)
+                pool_off += 4 * coutp
                 check(lib.w2l_bn_bwd_finalize(ptr(partial), nb, coutp, ncomp, ptr(sums), st()), 'w2l_bn_bwd_finalize')
                 uc.keep.append((partial, sums))
             main, res = u.main, u.res
@@ -692,18 +702,18 @@ class StackEngine:
             act_grads[oi] = []
             # BN parameter gradients: d beta = sum g, d gamma = sum g * xhat
             if main.has_bn:
-                self._set(grads, main.bn_bias, sums[0, : main.cout])
-                self._set(grads, main.bn_weight, sums[1, : main.cout])
+                grads[id(main.bn_bias)] = sums[0, : main.cout]
+                grads[id(main.bn_weight)] = sums[1, : main.cout]
             if res is not None and res.has_bn:
-                self._set(grads, res.bn_bias, sums[2, : res.cout])
-                self._set(grads, res.bn_weight, sums[3, : res.cout])
+                grads[id(res.bn_bias)] = sums[2, : res.cout]
+                grads[id(res.bn_weight)] = sums[3, : res.cout]
             # main branch
             pkm = pack_weights(main, precise)
             src = acts[u.src] if u.dw is None else uc.mid
             self._wgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, grads)
             if main.bias is not None:
                 if main.has_bn:      # sum(dy) == 0 identically under BatchNorm
-                    self._set(grads, main.bias, self._zeros(main.cout, dev))
+                    grads[id(main.bias)] = self._zeros(main.cout, dev)      # zero on every rank: nothing to average
                 else:
                     dyv = dy_hi[h1:].view(N, Tout + h1, coutp)[:, :Tout, : main.cout]
                     self._set(grads, main.bias, dyv.float().sum((0, 1)))
@@ -719,10 +729,14 @@ class StackEngine:
                 rsrc = acts[u.res_src]
                 self._wgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc, grads)
                 if res.bias is not None:
-                    self._set(grads, res.bias, self._zeros(res.cout, dev))
+                    grads[id(res.bias)] = self._zeros(res.cout, dev)
                 if self._needs_grad(u.res_src, ctx):
                     act_grads[u.res_src].append(self._dgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc))
         ctx['input_grad'] = self.input_grad(ctx, act_grads[0]) if ctx.get('want_dx') and act_grads[0] else None
+        if self.flat_ready is not None:
+            self.flat_ready(small_pool)
+        elif self.grad_ready is not None:
+            self.grad_ready(None, small_pool, small_pool)
         if self._side_used:
             torch.cuda.current_stream(dev).wait_stream(self._side)
             self._side_used = False

@@ -276,6 +276,7 @@ class Jasper(ConvCTCASR):
         reducer = getattr(self, 'grad_reducer', None)
         if reducer is not None:
             eng.grad_ready = reducer.on_grad
+            eng.flat_ready = getattr(reducer, 'on_flat', None)
             eng.backward_done = reducer.finish
         return eng
 

@@ -99,6 +99,7 @@ class Wav2Letter(ConvCTCASR):
             reducer = getattr(self, 'grad_reducer', None)      # set by distributed training drivers
             if reducer is not None:
                 self._engine.grad_ready = reducer.on_grad
+                self._engine.flat_ready = getattr(reducer, 'on_flat', None)
                 self._engine.backward_done = reducer.finish
         return self._engine
 
