@@ -70,6 +70,7 @@ def main():
                     help='wav2letter = the headline workload; jasper10x5 = BASELINE config 4 (secondary)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='replay the step as a captured hipGraph (graph.GraphedTrainStep; Wav2Letter)')
     ap.add_argument('--no-sgd-overlap', action='store_true', help='keep the fused SGD updates on the main stream')
     ap.add_argument('--force-dp', action='store_true', help='run the RCCL gradient path even with one rank (plumbing check)')
     ap.add_argument('--serial-wgrad', action='store_true', help='keep weight gradients on the main stream (clean per-kernel durations for profiling)')
@@ -118,6 +119,17 @@ def main():
         if not args.no_optimizer:
             opt.step()
         return loss
+
+    if args.graph:
+        from wav2letter_pytorch_amd.graph import GraphedTrainStep
+        gstep = GraphedTrainStep(model, opt, x, il, tg_d, tl_d, warmup=max(args.warmup, 2))
+
+        eager_step = step
+
+        def step():                                   # noqa: F811
+            return gstep()
+    else:
+        eager_step = step
 
     def fence():
         torch.cuda.synchronize()
@@ -182,7 +194,7 @@ def main():
         E.KERNEL_TIMER = []
         model._overlap_wgrad = False      # serialise the side stream so per-launch durations are not shared-GPU times
         for _ in range(3):
-            step()
+            eager_step()                  # (the captured graph carries no timing events)
         torch.cuda.synchronize()
         model._overlap_wgrad = not args.serial_wgrad
         agg = {}
@@ -232,7 +244,8 @@ def main():
                                    + f'Wav2Letter mid_layers={args.mid_layers} (configuration/model/wav2letter.yaml table), ' * (args.model == 'wav2letter')
                                    +
                                    f'N={N}/GPU x T={T} x 64 mel, dropout on, fwd+CTC+bwd'
-                                   + ('' if args.no_optimizer else '+fused SGD(nesterov) step'),
+                                   + ('' if args.no_optimizer else '+fused SGD(nesterov) step')
+                                   + (', step replayed as a hipGraph' if args.graph else ''),
                        'global_batch': world * N, 'frames': T, 'parallelism': f'dp{world}',
                        'value_is': 'whole-job frames/s (per-GPU = value / n_gpus)', 'loss': round(float(loss.detach()), 4)},
             'roofline': roof, 'cpu_baseline': cpu,

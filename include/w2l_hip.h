@@ -192,6 +192,8 @@ typedef struct {
     uint64_t seed, offset;  /* Philox4x32-10 key / stream offset */
     uint8_t* mask;          /* keep bits, one byte per 8 channels: [N*T*C/8] */
     const int32_t* lens;    /* optional [N]: rows t >= lens[n] produce 0 / receive 0 gradient */
+    const uint64_t* offset_dev; /* optional device word ADDED to `offset` when the mask is drawn: a step counter that lives
+                               in device memory, so that a captured hipGraph of the step draws fresh masks at every replay */
 } w2l_bnact_t;
 
 /* a = act(dropout(y*scale+shift [+ y2*scale2+shift2])) written to a padded buffer

@@ -387,3 +387,50 @@ def test_deterministic_mode_is_bit_reproducible(monkeypatch):
     for ga, gb, gc in zip(a, b, c):
         assert torch.equal(ga, gb)
         assert scale_err(ga.cpu().numpy(), gc.cpu().numpy()) < 1e-5
+
+
+def test_graphed_train_step():
+    """the step captured into a hipGraph (graph.GraphedTrainStep): replays train like the eager step, and dropout masks
+    change from replay to replay (device-side Philox offset)"""
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd.graph import GraphedTrainStep
+    layers = [(128, 11, 2, 1, 0.0), (128, 13, 1, 2, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=51)
+    x, il, tg, tl = O.synthetic_batch(4, 200, seed=52, s_lo=5, s_hi=15)
+
+    def make(dropout):
+        lay = [(c, k, s, d, 0.3 if dropout else 0.0) for c, k, s, d, _ in layers]
+        m = build_w2l(lay, sd, 'bf16', dropout=dropout).train()
+        m._cfg.optimizer.lr = 0.02
+        return m, m.configure_optimizers()[0][0]
+
+    # (a) no dropout: 3 eager warm-up steps + 4 replays (capturing records, it does not execute) == 7 eager steps
+    mg, og = make(False)
+    step = GraphedTrainStep(mg, og, x, il, tg, tl, warmup=3)
+    losses = [float(step()) for _ in range(4)]
+    me, oe = make(False)
+    ol = me.compute_output_lengths(il)
+    for _ in range(7):
+        oe.zero_grad(set_to_none=True)
+        out, _ = me(x.cuda(), None)
+        le = me.criterion(out.transpose(0, 1), tg, ol, tl)
+        le.backward()
+        oe.step()
+    assert abs(losses[-1] - float(le)) < 2e-2 * abs(float(le)), (losses, float(le))
+    assert losses[-1] < losses[0]
+    for (k, pa), (_, pb) in zip(mg.named_parameters(), me.named_parameters()):
+        assert scale_err(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()) < 2e-2, k
+    assert int(step.counter) == 7 * step.n_units
+    # a new batch of the same shape goes through the static buffers
+    x2, _, tg2, tl2 = O.synthetic_batch(4, 200, seed=53, s_lo=5, s_hi=15)
+    if tg2.shape == tg.shape:
+        l2 = float(step(x2, tg2, tl2))
+        assert np.isfinite(l2) and abs(l2 - losses[-1]) > 1e-6
+    # (b) dropout on, lr 0: the parameters never move, so the loss only changes through the masks
+    md, od = make(True)
+    for g in od.param_groups:
+        g['lr'] = 0.0
+        g['weight_decay'] = 0.0
+    sd_ = GraphedTrainStep(md, od, x, il, tg, tl, warmup=2)
+    vals = [float(sd_()) for _ in range(3)]
+    assert len({round(v, 6) for v in vals}) == 3, vals

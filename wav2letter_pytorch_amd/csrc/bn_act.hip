@@ -110,7 +110,7 @@ __device__ __forceinline__ uint32_t preact8(const w2l_bnact_t& d, const Chan& c1
     if (d.drop_p > 0.f) {
         const int64_t gidx = row * G + cg;
         if (gen_mask) {      // forward: every row (halo copies too) regenerates its bits; the primary row records them
-            bits = dropout_bits(d.seed, d.offset, (uint64_t)gidx, thresh);
+            bits = dropout_bits(d.seed, d.offset + (d.offset_dev ? *d.offset_dev : 0ull), (uint64_t)gidx, thresh);
             if (write_mask) d.mask[gidx] = (uint8_t)bits;
         } else {             // backward: replay the recorded bits
             bits = d.mask[gidx];

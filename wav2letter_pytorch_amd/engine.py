@@ -338,6 +338,9 @@ class StackEngine:
         self._held: list = []        # tensors in use by side-stream kernels; released after the join in backward()
         self._nbt_pending: list = []  # num_batches_tracked buffers to bump (one fused launch per forward)
         self._zero_pool = None       # (buffer, offset): the identically-zero conv-bias gradients of one backward
+        # graph mode (graph.GraphedTrainStep): a uint64 step counter in device memory; dropout offsets become
+        # (unit index) + counter, so a captured step draws new masks at every replay
+        self.dropout_counter: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------ parameters
     def parameters(self) -> List[torch.Tensor]:
@@ -422,8 +425,11 @@ class StackEngine:
             if p > 0.0:
                 uc.mask = torch.empty(N * Tout * (coutp // 8), dtype=torch.uint8, device=dev)
                 uc.seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
-                _dropout_calls += 1
-                uc.offset = _dropout_calls
+                if self.dropout_counter is not None:
+                    uc.offset = ui + 1
+                else:
+                    _dropout_calls += 1
+                    uc.offset = _dropout_calls
             d = self._desc(uc, N, Tout, coutp, p, uc.lens_out)
             check(lib.w2l_bn_act_fwd(C.byref(d), ptr(out_hi), ptr(out_lo), opl + Tout + opr, opl, opr, omode, st()),
                   'w2l_bn_act_fwd')
@@ -614,6 +620,7 @@ class StackEngine:
         d.seed, d.offset = uc.seed, uc.offset
         d.mask = uc.mask.data_ptr() if uc.mask is not None else None
         d.lens = lens.data_ptr() if lens is not None else None
+        d.offset_dev = self.dropout_counter.data_ptr() if (self.dropout_counter is not None and p > 0.0) else None
         uc.keep.append(lens)
         return d
 

@@ -273,6 +273,7 @@ class Jasper(ConvCTCASR):
         head = conv_spec(self.final_layer[0], None, 0, 0, PAD_ZERO, 'head')
         eng = StackEngine(units, head, len(self.labels), precise=self.precision == 'fp32')
         eng.overlap_wgrad = getattr(self, '_overlap_wgrad', True)
+        eng.dropout_counter = getattr(self, '_dropout_counter', None)               # graph.GraphedTrainStep
         reducer = getattr(self, 'grad_reducer', None)
         if reducer is not None:
             eng.grad_ready = reducer.on_grad

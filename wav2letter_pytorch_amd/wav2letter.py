@@ -96,6 +96,7 @@ class Wav2Letter(ConvCTCASR):
             head = conv_spec(head_blk.conv1, None, 0, 0, PAD_REFLECT, 'head')
             self._engine = StackEngine(units, head, len(self.labels), precise=precise)
             self._engine.overlap_wgrad = getattr(self, '_overlap_wgrad', True)
+            self._engine.dropout_counter = getattr(self, '_dropout_counter', None)      # graph.GraphedTrainStep
             reducer = getattr(self, 'grad_reducer', None)      # set by distributed training drivers
             if reducer is not None:
                 self._engine.grad_ready = reducer.on_grad
