@@ -434,3 +434,43 @@ def test_graphed_train_step():
     sd_ = GraphedTrainStep(md, od, x, il, tg, tl, warmup=2)
     vals = [float(sd_()) for _ in range(3)]
     assert len({round(v, 6) for v in vals}) == 3, vals
+
+
+def test_data_parallel_two_ranks_on_one_gpu(tmp_path):
+    """Two ranks (gloo, both on cuda:0) run one data-parallel step through the production path; checked against the
+    same two batches run one after the other in this process: identical replicas after the broadcast, every gradient
+    equal to the mean of the two per-batch gradients, identical parameters after the optimizer step."""
+    import socket
+    import subprocess
+    import sys
+    from oracle import w2l_oracle as O
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    here = os.path.dirname(os.path.abspath(__file__))
+    base = str(tmp_path / 'dp')
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(here, 'dp_gpu_worker.py'), base], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    z = [np.load(base + f'.rank{r}.npz') for r in range(2)]
+    keys = [k[3:] for k in z[0].files if k.startswith('p0/')]
+    layers = [(128, 11, 2, 1, 0.0), (256, 13, 1, 1, 0.0), (128, 29, 1, 2, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=60)               # rank 0's state is what the broadcast distributes
+    single = []
+    for r in range(2):
+        m = build_w2l(layers, sd, 'bf16').train()
+        x, il, tg, tl = O.synthetic_batch(4, 240, seed=70 + r, s_lo=5, s_hi=20)
+        out, ol = m(x.cuda(), il)
+        m.criterion(out.transpose(0, 1), tg, ol, tl).backward()
+        single.append({k: v.grad.detach().cpu().numpy() for k, v in m.named_parameters()})
+    for k in keys:
+        np.testing.assert_array_equal(z[0]['p0/' + k], z[1]['p0/' + k])            # broadcast
+        np.testing.assert_array_equal(z[0]['g/' + k], z[1]['g/' + k])              # same averaged gradient everywhere
+        want = 0.5 * (single[0][k] + single[1][k])
+        assert scale_err(z[0]['g/' + k], want) < 2e-3 or np.abs(want).max() < 1e-12, k
+        np.testing.assert_array_equal(z[0]['p1/' + k], z[1]['p1/' + k])            # replicas stay identical
+        assert not np.array_equal(z[0]['p1/' + k], z[0]['p0/' + k]) or 'conv1.bias' in k, k
