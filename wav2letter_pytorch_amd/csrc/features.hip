@@ -126,6 +126,167 @@ __global__ __launch_bounds__(64 * FRAMES_PER_BLOCK) void logmel_kernel(LogmelPar
     }
 }
 
+// ---- n_fft = 512: the FFT lives in registers -------------------------------------------------------------------------
+// 512 = 8 x 8 x 8.  One wave per frame, eight complex values per lane, three in-register 8-point DFTs separated by two
+// LDS transposes (instead of nine LDS-resident radix-2 stages):
+//   n = 64a + b:            lane b      DFT-8 over a -> Y_b[c],      x W512^(b c)
+//   b = 8e + f:             lane (c,f)  DFT-8 over e -> U_cf[g],     x W64^(f g)
+//                           lane (c,g)  DFT-8 over f -> X[c + 8g + 64h], h = 0..7
+// Transpose images use a row stride of 72 words and a (f + g) mod 8 skew: every ds access below is bank-conflict-free.
+__device__ __forceinline__ void dft8(float (&re)[8], float (&im)[8]) {
+    const float R = 0.70710678118654752f;
+    // length-2
+    const float e0r = re[0] + re[4], e0i = im[0] + im[4], e1r = re[0] - re[4], e1i = im[0] - im[4];
+    const float e2r = re[2] + re[6], e2i = im[2] + im[6], e3r = re[2] - re[6], e3i = im[2] - im[6];
+    const float o0r = re[1] + re[5], o0i = im[1] + im[5], o1r = re[1] - re[5], o1i = im[1] - im[5];
+    const float o2r = re[3] + re[7], o2i = im[3] + im[7], o3r = re[3] - re[7], o3i = im[3] - im[7];
+    // length-4 (W4 = -i: (-i)(a + ib) = b - ia)
+    const float E0r = e0r + e2r, E0i = e0i + e2i, E2r = e0r - e2r, E2i = e0i - e2i;
+    const float E1r = e1r + e3i, E1i = e1i - e3r, E3r = e1r - e3i, E3i = e1i + e3r;
+    const float O0r = o0r + o2r, O0i = o0i + o2i, O2r = o0r - o2r, O2i = o0i - o2i;
+    const float O1r = o1r + o3i, O1i = o1i - o3r, O3r = o1r - o3i, O3i = o1i + o3r;
+    // length-8: W8^1 = (1 - i)/sqrt2, W8^2 = -i, W8^3 = (-1 - i)/sqrt2
+    const float t1r = R * (O1r + O1i), t1i = R * (O1i - O1r);
+    const float t2r = O2i, t2i = -O2r;
+    const float t3r = R * (O3i - O3r), t3i = -R * (O3r + O3i);
+    re[0] = E0r + O0r; im[0] = E0i + O0i; re[4] = E0r - O0r; im[4] = E0i - O0i;
+    re[1] = E1r + t1r; im[1] = E1i + t1i; re[5] = E1r - t1r; im[5] = E1i - t1i;
+    re[2] = E2r + t2r; im[2] = E2i + t2i; re[6] = E2r - t2r; im[6] = E2i - t2i;
+    re[3] = E3r + t3r; im[3] = E3i + t3i; re[7] = E3r - t3r; im[7] = E3i - t3i;
+}
+
+constexpr int TSTRIDE = 72;                       // words per transpose row (64 + 8: spreads rows over the 32 banks)
+constexpr int WAVE_WORDS = 2 * 8 * TSTRIDE;       // re and im images of one wave
+
+__global__ __launch_bounds__(64 * FRAMES_PER_BLOCK) void logmel512_kernel(LogmelParams p) {
+    constexpr int SPAN_MAX = 1024;                                  // samples the block's frames cover: (F-1)*hop + 512
+    __shared__ float lds[512 + FRAMES_PER_BLOCK * WAVE_WORDS + SPAN_MAX];   // W512^m (m < 256): cos | sin, the waves' images,
+    float* tw_c = lds;                                              // and the block's pre-emphasised samples
+    float* tw_s = lds + 256;
+    float* ys = lds + 512 + FRAMES_PER_BLOCK * WAVE_WORDS;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* Are = lds + 512 + wave * WAVE_WORDS;
+    float* Aim = Are + 8 * TSTRIDE;
+    const int n = blockIdx.y;
+    const int t = blockIdx.x * FRAMES_PER_BLOCK + wave;
+    const int L = p.n_samples[n];
+    const int T_n = 1 + L / p.hop;
+    const bool live = t < T_n && t < p.Tmax;
+    {
+        float s_, c_;
+        sincospif(-(float)threadIdx.x / 256.0f, &s_, &c_);          // exp(-2 pi i m / 512), m = threadIdx.x
+        tw_c[threadIdx.x] = c_;
+        tw_s[threadIdx.x] = s_;
+    }
+    auto twiddle = [&](int m, float& wr, float& wi) {                // W512^m for m < 512
+        const int k = m & 255;
+        wr = tw_c[k];
+        wi = tw_s[k];
+        if (m & 256) { wr = -wr; wi = -wi; }
+    };
+    float re[8], im[8];
+    // ---- the block's frames overlap (hop < window): dither + pre-emphasis + reflect padding once per sample, into LDS
+    const float* x = p.audio + (int64_t)n * p.audio_stride;
+    const float* z = p.noise ? p.noise + (int64_t)n * p.audio_stride : nullptr;
+    const int woff = (512 - p.win_length) >> 1;
+    const int span = (FRAMES_PER_BLOCK - 1) * p.hop + 512;
+    const bool staged = span <= SPAN_MAX;                            // (always, for hop <= 170; otherwise straight from memory)
+    const int jb = blockIdx.x * FRAMES_PER_BLOCK * p.hop - 256;      // padded-signal position of ys[0]
+    auto sample = [&](int j) {
+        const int m = reflect_index(j, L);
+        float s0 = x[m];
+        if (z) s0 = __fadd_rn(s0, __fmul_rn(z[m], p.dither));
+        if (m > 0) {
+            float s1 = x[m - 1];
+            if (z) s1 = __fadd_rn(s1, __fmul_rn(z[m - 1], p.dither));
+            s0 = __fsub_rn(s0, __fmul_rn(p.preemph, s1));
+        }
+        return s0;
+    };
+    if (staged && blockIdx.x * FRAMES_PER_BLOCK < T_n)
+        for (int i = threadIdx.x; i < span; i += blockDim.x) ys[i] = sample(jb + i);
+    __syncthreads();                                                 // twiddle table and samples complete
+    // ---- samples n = 64a + b (lane = b), windowed
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const int i = 64 * a + lane;
+        const int wi = i - woff;
+        float v = 0.f;
+        if (live && wi >= 0 && wi < p.win_length)
+            v = (staged ? ys[wave * p.hop + i] : sample(t * p.hop - 256 + i)) * p.window[wi];
+        re[a] = v;
+        im[a] = 0.f;
+    }
+    dft8(re, im);                                                    // Y_b[c]
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float wr, wi_;
+        twiddle(lane * c, wr, wi_);
+        const float r_ = re[c] * wr - im[c] * wi_, i_ = re[c] * wi_ + im[c] * wr;
+        Are[c * TSTRIDE + lane] = r_;
+        Aim[c * TSTRIDE + lane] = i_;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int c1 = lane >> 3, f = lane & 7;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        re[e] = Are[c1 * TSTRIDE + 8 * e + f];
+        im[e] = Aim[c1 * TSTRIDE + 8 * e + f];
+    }
+    dft8(re, im);                                                    // U_cf[g]
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        float wr, wi_;
+        twiddle(8 * f * g, wr, wi_);
+        const float r_ = re[g] * wr - im[g] * wi_, i_ = re[g] * wi_ + im[g] * wr;
+        Are[c1 * TSTRIDE + 8 * g + ((f + g) & 7)] = r_;
+        Aim[c1 * TSTRIDE + 8 * g + ((f + g) & 7)] = i_;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int g1 = lane & 7;
+#pragma unroll
+    for (int ff = 0; ff < 8; ++ff) {
+        re[ff] = Are[c1 * TSTRIDE + 8 * g1 + ((ff + g1) & 7)];
+        im[ff] = Aim[c1 * TSTRIDE + 8 * g1 + ((ff + g1) & 7)];
+    }
+    dft8(re, im);                                                    // X[c1 + 8 g1 + 64 h]
+    __builtin_amdgcn_wave_barrier();
+    // power spectrum, as the reference forms it (sqrt, then squared), bins 0..256 into the wave's image
+    float* P = Are;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const float mag = sqrtf(re[h] * re[h] + im[h] * im[h]);
+        P[c1 + 8 * g1 + 64 * h] = mag * mag;
+    }
+    if (lane == 0) {
+        const float mag = sqrtf(re[4] * re[4] + im[4] * im[4]);
+        P[256] = mag * mag;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (t < p.Tmax) {
+        float* out = p.logmel + ((int64_t)n * p.Tmax + t) * p.n_mels;
+        for (int m = lane; m < p.n_mels; m += 64) {
+            float acc = 0.f;
+            if (live) {
+                const int k0 = p.fb_range ? p.fb_range[2 * m] : 0;
+                const int k1 = p.fb_range ? p.fb_range[2 * m + 1] : 257;
+                // eight filter weights in flight per round trip (the loads are unconditional on a clamped index; a
+                // load under a per-element condition would be waited for one by one); same summation order as a plain loop
+                for (int k = k0; k < k1; k += 8) {
+                    float w[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) w[u] = p.fbT[min(k + u, k1 - 1) * p.n_mels + m];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += (k + u < k1 ? w[u] : 0.f) * P[min(k + u, 256)];
+                }
+                if (p.take_log) acc = log1pf(acc + p.guard);
+            }
+            out[m] = acc;
+        }
+    }
+}
+
 // per (utterance, feature): mean and unbiased std over the utterance's frames (torch.Tensor.std), two-pass.
 // One block of 16 waves per (utterance, 64 features): lane = feature, wave = time phase, 8 loads in flight per lane
 // (the block is alone with a [T][n_mels] slab that other XCDs wrote: every first touch is an L2 miss).
@@ -234,7 +395,10 @@ extern "C" int w2l_logmel(const float* audio, const int32_t* n_samples, const fl
     while ((1 << p.log2n) < n_fft) ++p.log2n;
     const size_t lds = (size_t)(n_fft + FRAMES_PER_BLOCK * 2 * n_fft) * sizeof(float);
     dim3 grid((Tmax + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK, N);
-    hipLaunchKernelGGL(logmel_kernel, grid, dim3(64 * FRAMES_PER_BLOCK), lds, (hipStream_t)stream, p);
+    if (n_fft == 512)
+        hipLaunchKernelGGL(logmel512_kernel, grid, dim3(64 * FRAMES_PER_BLOCK), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(logmel_kernel, grid, dim3(64 * FRAMES_PER_BLOCK), lds, (hipStream_t)stream, p);
     W2L_CHECK_LAUNCH();
     return 0;
 }
