@@ -268,6 +268,7 @@ def _splitk_workspace(dev, n, cout, tout):
 
 
 _wgrad_ws = {}                     # device index -> workspace of the stream the weight gradients run on
+_retired_ws = []                   # outgrown workspaces (grown only while shapes are new, i.e. a handful of times)
 # W2L_DETERMINISTIC=1: split weight-gradient reductions go through slabs summed in a fixed order instead of fp32 atomics
 # (bit-reproducible gradients, no zero fills) -- measured 6 % slower on the Wav2Letter table (943 vs 1004 TFLOP/s), so opt-in
 DETERMINISTIC_WGRAD = os.environ.get('W2L_DETERMINISTIC', '0') == '1'
@@ -277,6 +278,8 @@ def _wgrad_workspace(dev, cin, cout, kw):
     need = min(int(lib.w2l_wgrad_workspace_bytes(cin, cout, kw)), SPLITK_WS_CAP)
     ws = _wgrad_ws.get(dev.index)
     if ws is None or ws.numel() < need:
+        if ws is not None:
+            _retired_ws.append(ws)         # side-stream kernels may still be using it: never hand the memory back
         ws = torch.zeros(need, dtype=torch.uint8, device=dev)
         _wgrad_ws[dev.index] = ws
     return ws
