@@ -267,6 +267,17 @@ def _splitk_workspace(dev, n, cout, tout):
     return ws
 
 
+_side_streams = {}                 # device index -> the stream weight gradients run on
+
+
+def _side_stream(dev) -> 'torch.cuda.Stream':
+    st = _side_streams.get(dev.index)
+    if st is None:
+        st = torch.cuda.Stream(device=dev)
+        _side_streams[dev.index] = st
+    return st
+
+
 _wgrad_ws = {}                     # device index -> workspace of the stream the weight gradients run on
 _retired_ws = []                   # outgrown workspaces (grown only while shapes are new, i.e. a handful of times)
 # W2L_DETERMINISTIC=1: split weight-gradient reductions go through slabs summed in a fixed order instead of fp32 atomics
@@ -824,9 +835,11 @@ class StackEngine:
             return self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads)
         main = torch.cuda.current_stream(dy_hi.device)
         if self._side is None or self._side.device != dy_hi.device:
-            # a stream from torch's pool at default priority: streams created with hipStreamCreateWithPriority (lowest OR
-            # highest) made the whole step 30 % slower on MI355X (18.8 vs 14.3 ms, profiles/r01 notes in DESIGN.md)
-            self._side = torch.cuda.Stream(device=dy_hi.device)
+            # ONE stream per device for the life of the process (engines are rebuilt per forward).  HIP multiplexes streams
+            # onto 4 hardware queues round-robin: a fresh pool stream per step lands on the main stream's queue every fourth
+            # step and that step loses the overlap (14.8 instead of 13.8 ms; Jasper 23.4 instead of 19.7).  Default priority:
+            # streams created with hipStreamCreateWithPriority (lowest OR highest) made the whole step 30 % slower.
+            self._side = _side_stream(dy_hi.device)
         side = self._side
         self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads, fork=(main, side))
         self._held.extend(t for t in (dy_hi, dy_lo, src.hi, src.lo) if t is not None)
