@@ -22,7 +22,7 @@ def main():
     rank, world = init_process_group_from_env(backend='gloo')
     layers = [(128, 11, 2, 1, 0.0), (256, 13, 1, 1, 0.0), (128, 29, 1, 2, 0.0)]
     sd = O.init_wav2letter_state(layers, seed=60 + rank)          # different on purpose: the broadcast must fix it
-    model = build_w2l(layers, sd, 'bf16').train()
+    model = build_w2l(layers, sd, 'fp32').train()       # split-bf16 mode: no tuner-dependent bf16 roundings
     broadcast_parameters(model)
     model.grad_reducer = GradReducer()
     model._cfg.optimizer.lr = 0.05

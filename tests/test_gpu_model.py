@@ -462,7 +462,7 @@ def test_data_parallel_two_ranks_on_one_gpu(tmp_path):
     sd = O.init_wav2letter_state(layers, seed=60)               # rank 0's state is what the broadcast distributes
     single = []
     for r in range(2):
-        m = build_w2l(layers, sd, 'bf16').train()
+        m = build_w2l(layers, sd, 'fp32').train()
         x, il, tg, tl = O.synthetic_batch(4, 240, seed=70 + r, s_lo=5, s_hi=20)
         out, ol = m(x.cuda(), il)
         m.criterion(out.transpose(0, 1), tg, ol, tl).backward()
