@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--n', type=int, default=32)
     ap.add_argument('--t', type=int, default=1000)
     ap.add_argument('--sweep', action='store_true', help='time every igemm block-shape candidate per layer')
+    ap.add_argument('--deterministic', action='store_true', help='weight gradients through slabs + ticket (W2L_DETERMINISTIC=1 path)')
     ap.add_argument('--no-splitk', action='store_true', help='with --tune: measure without the split-K configurations')
     ap.add_argument('--tune', action='store_true', help='let the library measure and pick its configurations first')
     args = ap.parse_args()
@@ -83,7 +84,7 @@ def main():
                                               N * per, kw, 1, d, L.ptr(ws), ws.numel(), st))
 
         wws = torch.zeros(min(1 << 30, int(L.lib.w2l_wgrad_workspace_bytes(cin, cout, kw))), dtype=torch.uint8, device='cuda')
-        wwsa = (L.ptr(wws), wws.numel()) if not args.no_splitk else (None, 0)
+        wwsa = (L.ptr(wws), wws.numel()) if args.deterministic else (None, 0)     # the engine's default is the atomic path
 
         def wgrad():
             L.check(L.lib.w2l_conv1d_wgrad_ws(C.c_void_p(dy.data_ptr() + h * cout * 2), per * cout, L.ptr(x),
