@@ -72,7 +72,9 @@ __device__ __forceinline__ bf16x4 tr_read(unsigned lds_byte_addr) {      // 32-b
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(size_t)lds_byte_addr);
 }
 
-template <int KWB>
+// S1: the conv stride is 1 (every layer but a model's first): the row offsets of the k-substeps become ds_read immediates
+// instead of per-step VALU adds (the K loop is issue-bound).
+template <int KWB, bool S1>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     }
     const int ntaps = (p.Kw - kw0) < KWB ? (p.Kw - kw0) : KWB;
     const int m0 = tm * BM, c0 = tn * BNC;
-    const int s = p.stride, d = p.dil;
+    const int s = S1 ? 1 : p.stride, d = p.dil;
     const int shift = kw0 * d;
     const int xrows = p.xrows_lds;                 // (BT-1)*s + (KWB-1)*d + 1 rounded up to 4
 
@@ -127,6 +129,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         a_voff[i] = ((unsigned)r * (unsigned)p.Cout + (unsigned)co) * 2u;
     }
     const unsigned x_max_row = (unsigned)p.x_max_row;          // rows * Cin * 2 < 2^32 is checked by the launcher
+    // the x window likewise (stride 1, <= 20 four-row groups): per-lane offsets inside the window, computed once
+    constexpr int XG = 5;
+    const bool x_fast = S1 && (xrows >> 2) <= 4 * XG;
+    unsigned x_voff[XG];
+#pragma unroll
+    for (int i = 0; i < XG; ++i) {
+        const int r = (wave + 4 * i) * 4 + srow;
+        const int g = schunk ^ (row_key(r) << 1);
+        int ci = c0 + g * 8;
+        ci = ci < p.Cin ? ci : p.Cin - 8;
+        x_voff[i] = ((unsigned)r * (unsigned)p.Cin + (unsigned)ci) * 2u;
+    }
     auto stage = [&](char* adst, char* bdst, int n, int ts) {
         const int t0 = ts * BT;
         // dy rows t0..t0+63 (rows >= Tout are zero by contract)
@@ -137,6 +151,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         const unsigned b_lds = __builtin_amdgcn_readfirstlane(lds_addr(bdst));
         const unsigned xrow0 = (unsigned)(n * p.x_rows_per_utt) + (unsigned)(t0 * s + shift);
         const int ngrp = xrows >> 2;
+        if (x_fast && xrow0 + (unsigned)xrows - 1u <= x_max_row) {     // (wave-uniform) the whole window exists: no clamping
+            const char* xbase = reinterpret_cast<const char*>(p.x) + (uint64_t)xrow0 * (unsigned)p.Cin * 2u;
+#pragma unroll
+            for (int i = 0; i < XG; ++i)
+                if (wave + 4 * i < ngrp) glds16(xbase, x_voff[i], b_lds + (wave + 4 * i) * 1024);
+            return;
+        }
         for (int grp = wave; grp < ngrp; grp += 4) {
             const int r = grp * 4 + srow;
             const int g = schunk ^ (row_key(r) << 1);
@@ -473,11 +494,21 @@ extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const voi
     const size_t lds = 2 * BT * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
     dim3 grid(p.tiles_m * p.tiles_n * p.kgroups, splits), block(256);
     if (kwb == 2) {
-        W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<2>));
-        hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, block, lds, (hipStream_t)stream, p);
+        if (stride == 1) {
+            W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<2, true>));
+            hipLaunchKernelGGL((conv_wgrad_kernel<2, true>), grid, block, lds, (hipStream_t)stream, p);
+        } else {
+            W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<2, false>));
+            hipLaunchKernelGGL((conv_wgrad_kernel<2, false>), grid, block, lds, (hipStream_t)stream, p);
+        }
     } else {
-        W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<1>));
-        hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, block, lds, (hipStream_t)stream, p);
+        if (stride == 1) {
+            W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<1, true>));
+            hipLaunchKernelGGL((conv_wgrad_kernel<1, true>), grid, block, lds, (hipStream_t)stream, p);
+        } else {
+            W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<1, false>));
+            hipLaunchKernelGGL((conv_wgrad_kernel<1, false>), grid, block, lds, (hipStream_t)stream, p);
+        }
     }
     W2L_CHECK_LAUNCH();
     return 0;
