@@ -58,6 +58,12 @@ class GradReducer:
         self._keep = []
         backend = dist.get_backend(group) if dist.is_initialized() else None
         self._avg = dist.ReduceOp.AVG if backend == 'nccl' else None
+        # W2L_DP_SERIALIZE=1: the stream that produced a gradient (the weight-gradient side stream) also waits for that
+        # gradient's collective, so collectives and weight-gradient kernels alternate instead of running side by side: at
+        # most two kernels compete for the CUs at any time (on one GPU three concurrent heavy kernels cost 18.8 instead of
+        # 13.6 ms/step).  Off by default: RCCL's kernels are light, and the serial chain (4.6 ms of weight gradients + the
+        # collectives) must stay shorter than the backward pass to remain hidden.  To be decided on an 8-GPU node.
+        self.serialize = os.environ.get('W2L_DP_SERIALIZE', '0') == '1'
 
     def _side_stream(self, device):
         if self._stream is None:
@@ -94,6 +100,8 @@ class GradReducer:
             side.wait_event(ev)
             with torch.cuda.stream(side):
                 work, need_div = self._all_reduce(buf)
+            if self.serialize:
+                work.wait()                  # the producing stream resumes only after the collective
             # no record_stream: buf stays referenced in self._works until finish() has made the consumer stream wait
         else:
             work, need_div = self._all_reduce(buf)
