@@ -86,6 +86,8 @@ def main():
 
     rank, world = init_process_group_from_env(force=args.force_dp)
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('W2L_DIST_BACKEND') == 'gloo':      # one-GPU rehearsal of the multi-rank command line: every rank on cuda:0
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -190,13 +192,16 @@ def main():
 
     # ---- instrumented pass: HIP events around every conv kernel launch (same stream) ----
     roof = None
+    # every rank runs these steps (a data-parallel step contains collectives: a rank stepping alone would wait forever);
+    # only rank 0 records and reports the events
     if rank == 0:
         E.KERNEL_TIMER = []
-        model._overlap_wgrad = False      # serialise the side stream so per-launch durations are not shared-GPU times
-        for _ in range(3):
-            eager_step()                  # (the captured graph carries no timing events)
-        torch.cuda.synchronize()
-        model._overlap_wgrad = not args.serial_wgrad
+    model._overlap_wgrad = False      # serialise the side stream so per-launch durations are not shared-GPU times
+    for _ in range(3):
+        eager_step()                  # (the captured graph carries no timing events)
+    torch.cuda.synchronize()
+    model._overlap_wgrad = not args.serial_wgrad
+    if rank == 0:
         agg = {}
         for name, flops, s, e in E.KERNEL_TIMER:
             a = agg.setdefault(name, [0.0, 0.0, 0])

@@ -37,7 +37,9 @@ def init_process_group_from_env(backend: Optional[str] = None, force: bool = Fal
     os.environ.setdefault('MASTER_PORT', '29500')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        # W2L_DIST_BACKEND=gloo: rehearsal of a multi-rank run on a box with a single GPU (RCCL refuses two ranks on one
+        # device); production is nccl (= RCCL on ROCm)
+        backend = os.environ.get('W2L_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
     dist.init_process_group(backend=backend)
