@@ -474,3 +474,27 @@ def test_data_parallel_two_ranks_on_one_gpu(tmp_path):
         assert scale_err(z[0]['g/' + k], want) < 2e-3 or np.abs(want).max() < 1e-12, k
         np.testing.assert_array_equal(z[0]['p1/' + k], z[1]['p1/' + k])            # replicas stay identical
         assert not np.array_equal(z[0]['p1/' + k], z[0]['p0/' + k]) or 'conv1.bias' in k, k
+
+
+def test_bench_two_rank_command_line(tmp_path):
+    """the driver's multi-GPU command line (python -m torch.distributed.run ... bench.py --gpus 2) rehearsed on one GPU with
+    the gloo backend: both ranks must reach the end (every collective matched on every rank) and rank 0 prints one JSON line"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, W2L_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--mid-layers', '2', '--batch', '2', '--frames', '200', '--no-cpu-baseline']
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['value'] > 0 and d['roofline']['achieved'] > 0
