@@ -245,6 +245,15 @@ int w2l_argmax(const float* probs, int64_t rows, int C, int32_t* idx, void* stre
 /* host-side edit distance over int32 symbol arrays */
 int w2l_levenshtein_host(const int32_t* a_host, int na, const int32_t* b_host, int nb);
 
+/* Novograd step of one conv weight (novograd.py:86-112) fused with the bf16 operand pack, tap-major [Kw][Cout][Cin] fp32
+ * p / g / exp_avg like w2l_sgd_pack:  v = ||g||^2 on the first step (exp_avg_sq == 0), else beta2*v + (1-beta2)*||g||^2;
+ * amsgrad (max_exp_avg_sq != NULL): v <- running max;  g' = g/(sqrt(v)+eps) + weight_decay*p;  g' *= (1-beta1) if
+ * grad_averaging;  exp_avg = beta1*exp_avg + g';  p -= lr*exp_avg.  exp_avg_sq / max_exp_avg_sq are device scalars;
+ * scratch: >= 2 floats of device memory (1025 lets the norm use 1024 blocks).  Three launches, no host sync. */
+int w2l_novograd_pack(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, float* scratch,
+                      int scratch_floats, float lr, float beta1, float beta2, float eps, float weight_decay, int grad_averaging,
+                      int Cout, int Cin, int Kw, void* w_fwd_hi, void* w_fwd_lo, void* w_dgr_hi, void* w_dgr_lo, void* stream);
+
 /* ---- feature front-end (SpectrogramExtractor, data/data_loader.py:33-88) and augmentation masks ----------------
  * w2l_logmel: per utterance n (n_samples[n] samples of audio[n*audio_stride ...], fp32, device):
  *   x = audio + dither * noise (noise = N(0,1) draws, may be NULL: no dither)   data_loader.py:67

@@ -498,3 +498,37 @@ def test_bench_two_rank_command_line(tmp_path):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['value'] > 0 and d['roofline']['achieved'] > 0
+
+
+@pytest.mark.parametrize('amsgrad', [False, True])
+def test_fused_novograd_matches_torch_ops(amsgrad):
+    """Novograd with the fused conv-weight path (w2l_novograd_pack) == the same optimizer restricted to torch ops (itself
+    pinned to the reference's novograd.py by tests/golden/novograd_cases.npz), on real engine gradients; and the bf16
+    operands it emits are the ones the next forward uses."""
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd.novograd import Novograd
+    layers = [(128, 11, 2, 1, 0.0), (128, 13, 1, 2, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=5)
+    ma = build_w2l(layers, sd, 'bf16').train()
+    mb = build_w2l(layers, sd, 'bf16').train()
+    kw = dict(lr=0.02, betas=(0.95, 0.5), weight_decay=1e-3, grad_averaging=True, amsgrad=amsgrad)
+    oa, ob = Novograd(ma.parameters(), **kw), Novograd(mb.parameters(), **kw)
+    ob.fused = False
+    x, il, tg, tl = O.synthetic_batch(2, 160, seed=12, s_lo=5, s_hi=15)
+    for it in range(3):
+        for m, o in ((ma, oa), (mb, ob)):
+            o.zero_grad(set_to_none=True)
+            out, ol = m(x.cuda(), il)
+            m.criterion(out.transpose(0, 1), tg, ol, tl).backward()
+            o.step()
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert scale_err(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()) < 3e-5, k
+    wa = ma.conv1ds.conv1d_1.conv1.weight
+    st = oa.state[wa]
+    vb = float(ob.state[mb.conv1ds.conv1d_1.conv1.weight]['exp_avg_sq'])
+    assert abs(float(st['exp_avg_sq']) - vb) <= 1e-5 * vb
+    pk = wa._w2l_pack[False]
+    assert pk.version == wa._version
+    assert torch.equal(pk.fwd_hi, wa.detach().permute(2, 0, 1).to(torch.bfloat16))
+    assert torch.equal(pk.dgr_hi, wa.detach().flip(2).permute(2, 1, 0).to(torch.bfloat16).contiguous())
+    assert '_scratch' not in next(iter(oa.state_dict()['state'].values()))

@@ -84,6 +84,86 @@ __global__ void sgd_pack_kernel(float* p, const float* g, float* m, int first, f
     }
 }
 
+// ---- Novograd (novograd.py:86-112): per-TENSOR second moment v = EMA of ||g||^2 --------------------------------
+// Three launches per conv weight: deterministic partial sums of g^2, a one-block finalize that updates v (first-step
+// select on the device, optional running max) and leaves denom = sqrt(v) + eps in device memory, and the update fused
+// with the bf16 operand pack like sgd_pack_kernel:  g' = g/denom + wd*p;  g' *= (1-beta1) if grad_averaging;
+// m = beta1*m + g';  p -= lr*m.
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* g, int64_t n, float* partial) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = g[i];
+        s += v * v;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void novograd_finalize_kernel(const float* partial, int nblocks, float beta2, float eps,
+                                                                float* v, float* vmax, float* denom) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = red[0];
+        const float old = v[0];
+        float nv = old == 0.f ? norm : beta2 * old + (1.f - beta2) * norm;      // novograd.py:92-95
+        v[0] = nv;
+        if (vmax) {                                                             // amsgrad: novograd.py:97-102
+            nv = fmaxf(vmax[0], nv);
+            vmax[0] = nv;
+        }
+        denom[0] = sqrtf(nv) + eps;
+    }
+}
+
+__global__ void novograd_pack_kernel(float* p, const float* g, float* m, const float* denom, float lr, float beta1, float wd,
+                                     int grad_averaging, int Cout, int Cin, int Kw, bf16_raw* fwd_hi, bf16_raw* fwd_lo,
+                                     bf16_raw* dgr_hi, bf16_raw* dgr_lo) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, kw = blockIdx.z;
+    const float dn = denom[0];
+    for (int j = ty; j < 32; j += 8) {
+        const int co = co0 + j, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) {
+            const int64_t off = ((int64_t)kw * Cout + co) * Cin + ci;
+            float pv = p[off];
+            float gv = g[off] / dn;
+            if (wd != 0.f) gv += wd * pv;
+            if (grad_averaging) gv *= 1.f - beta1;
+            const float mv = beta1 * m[off] + gv;
+            m[off] = mv;
+            pv -= lr * mv;
+            p[off] = pv;
+            v = pv;
+            if (fwd_hi) put_split(fwd_hi, fwd_lo, off, pv);
+        }
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    if (dgr_hi) {
+        for (int j = ty; j < 32; j += 8) {
+            const int ci = ci0 + j, co = co0 + tx;
+            if (co < Cout && ci < Cin)
+                put_split(dgr_hi, dgr_lo, ((int64_t)(Kw - 1 - kw) * Cin + ci) * Cout + co, tile[tx][j]);
+        }
+    }
+}
+
 // padded row r of an utterance -> source frame t, or -1 for a zero row
 __device__ __forceinline__ int pad_src_row(int r, int T, int pad_l, int pad_r, int pad_mode) {
     int t = r - pad_l;
@@ -171,6 +251,33 @@ extern "C" int w2l_sgd_pack(float* p, const float* g, float* m, int first_step, 
     hipLaunchKernelGGL(sgd_pack_kernel, grid, block, 0, (hipStream_t)stream, p, g, m, first_step, lr, momentum,
                        weight_decay, nesterov, Cout, Cin, Kw, (bf16_raw*)w_fwd_hi, (bf16_raw*)w_fwd_lo,
                        (bf16_raw*)w_dgr_hi, (bf16_raw*)w_dgr_lo);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int w2l_novograd_pack(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
+                                 float* scratch, int scratch_floats, float lr, float beta1, float beta2, float eps,
+                                 float weight_decay, int grad_averaging, int Cout, int Cin, int Kw, void* w_fwd_hi,
+                                 void* w_fwd_lo, void* w_dgr_hi, void* w_dgr_lo, void* stream) {
+    W2L_CHECK_ARG(p && g && exp_avg && exp_avg_sq && scratch, "novograd_pack: null pointer");
+    W2L_CHECK_ARG(Cout > 0 && Cin > 0 && Kw > 0 && scratch_floats >= 2, "novograd_pack: bad sizes");
+    W2L_CHECK_ARG(!(w_fwd_lo && !w_fwd_hi) && !(w_dgr_lo && !w_dgr_hi), "novograd_pack: lo without hi");
+    const int64_t n = (int64_t)Cout * Cin * Kw;
+    int nblocks = (int)((n + 256 * 16 - 1) / (256 * 16));          // ~16 elements per thread
+    if (nblocks > scratch_floats - 1) nblocks = scratch_floats - 1;
+    if (nblocks > 1024) nblocks = 1024;
+    if (nblocks < 1) nblocks = 1;
+    hipStream_t st = (hipStream_t)stream;
+    float* denom = scratch;                                         // scratch = [denom | partial sums]
+    float* partial = scratch + 1;
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nblocks), dim3(256), 0, st, g, n, partial);
+    W2L_CHECK_LAUNCH();
+    hipLaunchKernelGGL(novograd_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblocks, beta2, eps, exp_avg_sq,
+                       max_exp_avg_sq, denom);
+    W2L_CHECK_LAUNCH();
+    dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, Kw), block(32, 8);
+    hipLaunchKernelGGL(novograd_pack_kernel, grid, block, 0, st, p, g, exp_avg, denom, lr, beta1, weight_decay, grad_averaging,
+                       Cout, Cin, Kw, (bf16_raw*)w_fwd_hi, (bf16_raw*)w_fwd_lo, (bf16_raw*)w_dgr_hi, (bf16_raw*)w_dgr_lo);
     W2L_CHECK_LAUNCH();
     return 0;
 }
