@@ -155,6 +155,7 @@ _dropout_calls = 0
 # the library's cost model
 AUTOTUNE = os.environ.get('W2L_AUTOTUNE', '1') != '0'
 _tuned_shapes = set()
+TUNE_REPS = int(os.environ.get('W2L_TUNE_REPS', '2'))      # timed launches per candidate configuration
 # W2L_TUNE_CACHE=<file>: measured choices are loaded at import and written back (atomically) after a step that
 # measured new shapes, so later processes (and the other DP ranks) skip the measuring launches.
 TUNE_CACHE = os.environ.get('W2L_TUNE_CACHE') or None
@@ -316,7 +317,7 @@ def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw
                 _tune_state['dirty'] = True
                 check(lib.w2l_conv1d_igemm_tune_ws(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y),
                                                    int(y.dtype == torch.float32), ptr(bias), ptr(stats), n, Cin, Cout, Tout,
-                                                   Kw, stride, dil, 2, ptr(ws), ws.numel(), st), 'w2l_conv1d_igemm_tune_ws')
+                                                   Kw, stride, dil, TUNE_REPS, ptr(ws), ws.numel(), st), 'w2l_conv1d_igemm_tune_ws')
         with _timed('conv_igemm_kernel', alg_flops):
             check(lib.w2l_conv1d_igemm_ws(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y), int(y.dtype == torch.float32),
                                           0, ptr(bias), ptr(stats), n, Cin, Cout, Tout, Kw, stride, dil, ptr(ws), ws.numel(),
@@ -869,7 +870,7 @@ class StackEngine:
                     torch.cuda.current_stream(dev).wait_stream(self._side)
                 check(lib.w2l_conv1d_wgrad_tune_ws(C.c_void_p(dy_hi.data_ptr() + halo * pk.coutp * 2), dy_bstride,
                                                    C.c_void_p(src.hi.data_ptr() + row_off * src.CP * 2), x_bstride, x_rows_total,
-                                                   ptr(scratch), N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, 2,
+                                                   ptr(scratch), N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, TUNE_REPS,
                                                    ptr(ws), ws_bytes, stream_ptr()), 'w2l_conv1d_wgrad_tune_ws')
         # with a workspace, split reductions end in plain stores by the last block of a tile: no zero fill, no atomics
         need_zero = bool(lib.w2l_wgrad_needs_zero_ws(N, pk.cinp, pk.coutp, Tout, kw, ws_bytes)) or self.precise
