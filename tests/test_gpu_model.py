@@ -532,3 +532,22 @@ def test_fused_novograd_matches_torch_ops(amsgrad):
     assert torch.equal(pk.fwd_hi, wa.detach().permute(2, 0, 1).to(torch.bfloat16))
     assert torch.equal(pk.dgr_hi, wa.detach().flip(2).permute(2, 1, 0).to(torch.bfloat16).contiguous())
     assert '_scratch' not in next(iter(oa.state_dict()['state'].values()))
+
+
+def test_random_stacks_smoke(capsys):
+    """a few cases of the randomised sweeps (tools/fuzz_model.py, tools/fuzz_jasper.py) as a regression check"""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name, argv in (('fuzz_model', ['x', '6', '7', 'fp32']), ('fuzz_jasper', ['x', '4', '7', 'fp32'])):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, 'tools', name + '.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        old = sys.argv
+        sys.argv = argv
+        try:
+            mod.main()
+        finally:
+            sys.argv = old
+        out = capsys.readouterr().out
+        assert out.count(' ok ') == int(argv[1]) and 'FAIL' not in out and 'EXCEPTION' not in out, out
