@@ -66,6 +66,10 @@ class GradReducer:
         # 13.6 ms/step).  Off by default: RCCL's kernels are light, and the serial chain (4.6 ms of weight gradients + the
         # collectives) must stay shorter than the backward pass to remain hidden.  To be decided on an 8-GPU node.
         self.serialize = os.environ.get('W2L_DP_SERIALIZE', '0') == '1'
+        # W2L_DP_BF16=1: large gradients travel as a bf16 copy (half the bytes on the xGMI ring: 306 instead of 612 MB per
+        # step for the full Wav2Letter table) and are widened back in finish(); the average is then accurate to bf16's 8
+        # bits, which is NOT what fp32 DDP computes -- an option for link-bound nodes, off by default
+        self.bf16 = os.environ.get('W2L_DP_BF16', '0') == '1'
 
     def _side_stream(self, device):
         if self._stream is None:
@@ -95,6 +99,8 @@ class GradReducer:
             self._launch(buf)
 
     def _launch(self, buf: torch.Tensor):
+        if self.bf16 and buf.dtype == torch.float32 and buf.numel() * 4 >= self.small_bytes:
+            return self._launch_bf16(buf)
         if buf.is_cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(buf.device))
@@ -109,6 +115,21 @@ class GradReducer:
             work, need_div = self._all_reduce(buf)
         self._works.append((work, buf, need_div))
 
+    def _launch_bf16(self, buf: torch.Tensor):
+        if buf.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(buf.device))
+            side = self._side_stream(buf.device)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                half = buf.to(torch.bfloat16)
+                work, need_div = self._all_reduce(half)
+        else:
+            half = buf.to(torch.bfloat16)
+            work, need_div = self._all_reduce(half)
+        self._works.append((work, (buf, half), need_div))
+        return work, True                    # "not final until finish()": the fp32 buffer is rewritten there
+
     def finish(self):
         """Flush the small gradients, then make the current stream wait for every collective."""
         if not self.active:
@@ -119,6 +140,11 @@ class GradReducer:
             self._launch(flat)
         for work, buf, need_div in self._works:
             work.wait()                      # stream-level wait for NCCL works; blocking for gloo
+            if isinstance(buf, tuple):       # bf16 transport: widen the averaged copy back into the fp32 gradient
+                buf, half = buf
+                buf.copy_(half)
+                if half.is_cuda:
+                    half.record_stream(torch.cuda.current_stream(half.device))   # allocated on the reducer's stream, read here
             if need_div and self.world > 1:
                 buf.div_(self.world)
         if flat is not None:
