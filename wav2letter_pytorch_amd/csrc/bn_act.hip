@@ -385,7 +385,19 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, 
     const int c = blockIdx.x * 32 + cx;
     double s1 = 0.0, s2 = 0.0;
     if (partial && c < C) {
-        for (int t = ly; t < ntiles; t += 8) {
+        // 16 loads in flight per lane: the loop is a chain of L2 round trips otherwise (16 of them at N*T/128 = 128 tiles)
+        int t = ly;
+        for (; t + 56 < ntiles; t += 64) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u] = partial[(int64_t)(t + 8 * u) * 2 * C + c];
+                b[u] = partial[(int64_t)(t + 8 * u) * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s1 += a[u]; s2 += b[u]; }
+        }
+        for (; t < ntiles; t += 8) {
             s1 += partial[(int64_t)t * 2 * C + c];
             s2 += partial[(int64_t)t * 2 * C + C + c];
         }
