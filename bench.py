@@ -3,7 +3,12 @@
 21-layer table of configuration/model/wav2letter.yaml (mid_layers=20, 153 M params), bf16
 operands / fp32 accumulate, synthetic 64-mel x 1000-frame spectrograms, batch 32 per GPU.
 
-  python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W]
+
+N > 1: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` each process is one rank; a plain
+`python bench.py --gpus N` (no rendezvous variables in the environment) starts the N ranks itself
+(wav2letter_pytorch_amd/launch.py: N subprocesses of this command line, before this process touches the GPU) and
+forwards rank 0's line.  One rank per GPU, gradients averaged with RCCL (torch.distributed backend "nccl").
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement).  `roofline` is the
 dominant kernel (conv_igemm_kernel: forward + data-gradient convolutions) timed with HIP events
@@ -58,6 +63,16 @@ def cpu_baseline(budget_s=20.0):
                       f'torch CPU ops on {cores} threads of {os.cpu_count()} host cores'}
 
 
+def _launcher():
+    """wav2letter_pytorch_amd/launch.py loaded by path: importing the package would load libw2l_hip.so (and the HIP
+    runtime) into the parent, which only spawns the ranks"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('w2l_launch', os.path.join(ROOT, 'wav2letter_pytorch_amd', 'launch.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -78,6 +93,15 @@ def main():
     ap.add_argument('--host-profile', action='store_true', help='cProfile of the host side of the step (stderr), then exit')
     ap.add_argument('--breakdown', action='store_true', help='print the per-kernel event timing table to stderr')
     args = ap.parse_args()
+
+    L = _launcher()
+    if args.gpus > 1 and not L.under_launcher():
+        # parent of a self-launched run: no HIP call has been made here (device_count() does not initialise the runtime)
+        if os.environ.get('W2L_DIST_BACKEND') != 'gloo' and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f'bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible')
+        sys.exit(L.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+    if L.under_launcher() and int(os.environ['WORLD_SIZE']) != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} inside a {os.environ['WORLD_SIZE']}-rank launch: the two must agree")
 
     from wav2letter_pytorch_amd import Jasper, Wav2Letter, engine as E
     from wav2letter_pytorch_amd.distributed import GradReducer, broadcast_parameters, init_process_group_from_env
@@ -183,12 +207,36 @@ def main():
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_ms = [float(v) / args.steps * 1e3 for v in every]
+        elapsed = max(float(v) for v in every)               # the job is as fast as its slowest rank
     ms = elapsed / args.steps * 1e3
     value = world * N * T / (elapsed / args.steps)
+
+    # ---- exposed communication: the same step with the gradient reducer detached (no collectives), same run ----
+    exposed_comm_ms = None
+    reducer = getattr(model, 'grad_reducer', None)
+    if reducer is not None and not args.graph:
+        model.grad_reducer = None
+        k2 = max(2, min(args.steps, 10))
+        step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k2):
+            step()
+        fence()
+        solo = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([solo], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            solo = float(t)
+        exposed_comm_ms = ms - solo / k2 * 1e3
+        model.grad_reducer = reducer
+        broadcast_parameters(model)                          # the replicas drifted apart while stepping alone
 
     # ---- instrumented pass: HIP events around every conv kernel launch (same stream) ----
     roof = None
@@ -254,6 +302,11 @@ def main():
                        'global_batch': world * N, 'frames': T, 'parallelism': f'dp{world}',
                        'value_is': 'whole-job frames/s (per-GPU = value / n_gpus)', 'loss': round(float(loss.detach()), 4)},
             'roofline': roof, 'cpu_baseline': cpu,
+            'rccl_world': dist.get_world_size() if dist.is_initialized() else 1,
+            'backend': dist.get_backend() if dist.is_initialized() else None,
+            'rank_ms_per_step': [round(v, 3) for v in rank_ms],
+            'exposed_comm_ms': None if exposed_comm_ms is None else round(exposed_comm_ms, 3),
+            'per_gpu_value': round(value / world, 1),
         }
         print(json.dumps(line))
     if dist.is_initialized():

@@ -104,7 +104,8 @@ int w2l_conv1d_igemm_tune_ws(const void* xp, int64_t x_bstride, int64_t x_rows_t
                              int dil, int reps, void* splitk_ws, int64_t splitk_ws_bytes, void* stream);
 int64_t w2l_conv_splitk_workspace_bytes(int N, int Cout, int Tout);
 
-/* tuning hook: force configuration idx (>= 0) for every later w2l_conv1d_igemm call; -1 = automatic.
+/* tuning hook: force configuration idx (>= 0) for every later w2l_conv1d_igemm call MADE BY THE CALLING THREAD (the
+ * setting is thread-local: launches from other threads are never affected); -1 = automatic.
  * idx = block shape (0..20) + 21 * K-loop structure (0: barrier at the top of a step, 1: barrier mid-step);
  * a call whose problem the forced configuration cannot run returns an error. */
 void w2l_conv_force_tile_config(int idx);
@@ -135,7 +136,8 @@ int w2l_conv1d_wgrad_tune_ws(const void* dy, int64_t dy_bstride, const void* xp,
 int w2l_wgrad_needs_zero_ws(int N, int Cin, int Cout, int Tout, int Kw, int64_t ws_bytes);
 int64_t w2l_wgrad_workspace_bytes(int Cin, int Cout, int Kw);
 
-/* Testing / profiling hook: pin the split count (0 = automatic) and the block order (0/1; -1 = automatic). */
+/* Testing / profiling hook: pin the split count (0 = automatic) and the block order (0/1; -1 = automatic) for launches
+ * made by the calling thread (thread-local, like w2l_conv_force_tile_config). */
 void w2l_wgrad_force_plan(int splits, int order);
 
 /* Autotune of the split-K factor and block order, like w2l_conv1d_igemm_tune (SYNCHRONISING, warm-up only); dw_scratch is a

@@ -7,6 +7,7 @@ import os
 import re
 import socket
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -304,3 +305,79 @@ def test_data_loader_host_side(tmp_path):
     np.testing.assert_array_equal(tl.numpy(), z['col_tl'])
     with pytest.raises(RuntimeError):                   # no CPU feature path
         DL.SpectrogramExtractor(dict(window='hamming', window_stride=0.01, window_size=0.02, sample_rate=16000), 64)
+
+
+def test_launcher_spawns_ranks_and_propagates_failure(tmp_path):
+    """launch.spawn_ranks (what `bench.py --gpus N` and `train.py trainer.gpus=N` use when no launcher set the rendezvous
+    variables): N ranks of one command line with torchrun's environment, a gloo all-reduce across them, rank 0's stdout
+    forwarded; a failing rank stops the others and gives a non-zero exit code."""
+    import subprocess
+    import sys
+    script = tmp_path / 'rank.py'
+    script.write_text(
+        'import os, sys, time\n'
+        'import torch, torch.distributed as dist\n'
+        'if sys.argv[1] == "fail":\n'
+        '    if os.environ["RANK"] == "1":\n'
+        '        sys.exit(3)\n'
+        '    time.sleep(60)\n'
+        'dist.init_process_group("gloo")\n'
+        't = torch.tensor([float(dist.get_rank() + 1)])\n'
+        'dist.all_reduce(t)\n'
+        'print("SUM", float(t), os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"])\n'
+        'dist.destroy_process_group()\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drv = tmp_path / 'drv.py'
+    drv.write_text(
+        'import importlib.util, sys\n'
+        f'spec = importlib.util.spec_from_file_location("l", {os.path.join(root, "wav2letter_pytorch_amd", "launch.py")!r})\n'
+        'm = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n'
+        f'sys.exit(m.spawn_ranks(int(sys.argv[1]), [sys.executable, {str(script)!r}, sys.argv[2]], timeout=100))\n')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    ok = subprocess.run([sys.executable, str(drv), '3', 'ok'], capture_output=True, text=True, timeout=120, env=env)
+    assert ok.returncode == 0, ok.stderr[-1000:]
+    sums = [ln.split() for ln in ok.stdout.splitlines() if ln.startswith('SUM')]      # (gloo prints a banner of its own)
+    assert sums == [['SUM', '6.0', '3', '0']]                      # only rank 0's stdout is forwarded
+    t0 = time.time()
+    bad = subprocess.run([sys.executable, str(drv), '2', 'fail'], capture_output=True, text=True, timeout=120, env=env)
+    assert bad.returncode == 3 and time.time() - t0 < 45           # rank 0 (sleeping) was stopped, not waited for
+    assert 'rank 1 exited with code 3' in bad.stderr
+
+
+def test_init_weights_xavier_and_batchnorm_reset():
+    """jasper.py:29-50: xavier_uniform(gain 1) on every Conv1d -- |w| <= sqrt(6 / (fan_in + fan_out)) with
+    fan = channels * kernel width, the bound is approached -- and BatchNorm reset to mean 0 / var 1 / gamma 1 / beta 0,
+    applied to the encoder and to the classifier (:434,:453)"""
+    import math
+    from wav2letter_pytorch_amd import Jasper
+    from wav2letter_pytorch_amd.defaults import jasper_model
+    from wav2letter_pytorch_amd.jasper import init_weights
+    torch.manual_seed(1)
+    m = Jasper(jasper_model(mid_layers=3))
+    convs = [(k, p) for k, p in m.named_parameters() if k.endswith('conv.weight') or k == 'final_layer.0.weight']
+    assert len(convs) == 3 * 2 + 2 + 1                       # 3 separable blocks (dw + pw), 2 residual convs, the head
+    for k, w in convs:
+        cout, cin_g, kw = w.shape
+        bound = math.sqrt(6.0 / (cin_g * kw + cout * kw))
+        assert float(w.abs().max()) <= bound * (1 + 1e-6), k
+        assert float(w.abs().max()) > 0.9 * bound or w.numel() < 200, k
+        assert abs(float(w.mean())) < 0.1 * bound
+    with torch.no_grad():
+        for k, t in list(m.state_dict().items()):
+            if 'running' in k or k.endswith('.weight') and t.dim() == 1 or k.endswith('.bias') and 'mconv' in k:
+                t.add_(3.0)
+        bn = m.jasper_encoder[0].mconv[2]
+        bn.num_batches_tracked.fill_(7)
+    m.jasper_encoder.apply(init_weights)
+    for k, t in m.state_dict().items():
+        if 'running_mean' in k or ('mconv' in k and k.endswith('.bias')):
+            assert float(t.abs().max()) == 0, k
+        elif 'running_var' in k or ('mconv' in k and k.endswith('.weight') and t.dim() == 1):
+            assert bool((t == 1).all()), k
+        elif 'num_batches' in k:
+            assert int(t) == 0, k
+    with pytest.raises(ValueError):
+        init_weights(m.final_layer[0], mode='kaiming')
+    x, lens = m.create_example_input_array()                 # base_asr_models.py:27-31
+    assert x.shape == (4, 64, 200) and float(x.min()) >= 0 and float(x.max()) < 1
+    assert lens.shape == (4,) and int(lens.min()) >= 100 and int(lens.max()) < 200

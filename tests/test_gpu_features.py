@@ -209,6 +209,61 @@ def test_train_cli_end_to_end_builtin_config(tmp_path):
     assert 'conv1ds.conv1d_0.conv1.weight' in sd and 'conv1ds.conv1d_1.batch_norm.running_var' in sd
 
 
+def test_data_parallel_loaders_shard_the_manifest(tmp_path):
+    """train.get_data_loaders(rank, world): the ranks of a data-parallel run read DISJOINT utterances that together cover the
+    manifest (Lightning's DDP injects a DistributedSampler into the reference's loaders, train.py:21-26,34-37), and every
+    rank takes the same number of steps"""
+    from wav2letter_pytorch_amd.defaults import root_config
+    from wav2letter_pytorch_amd.train import get_data_loaders
+    tr, va = _toy_corpus(tmp_path, n=9)                    # 4 training utterances, 5 validation utterances
+    cfg = root_config('wav2letter')
+    cfg.data.train_manifest, cfg.data.val_manifest, cfg.data.batch_size = tr, va, 1
+    labels = list(cfg.model.labels)
+    seen = []
+    for rank in range(2):
+        tl, vl = get_data_loaders(labels, cfg.data, rank, 2)
+        seen.append(([b[4][0] for b in tl], [b[4][0] for b in vl]))
+    (t0, v0), (t1, v1) = seen
+    assert len(t0) == len(t1) == 2 and not set(t0) & set(t1) and len(set(t0) | set(t1)) == 4
+    assert len(v0) == len(v1) == 3 and len(set(v0) | set(v1)) == 5      # 5 over 2 ranks: one utterance repeated as padding
+    one, _ = get_data_loaders(labels, cfg.data)
+    assert [b[4][0] for b in one] == [t for pair in zip(t0, t1) for t in pair]     # rank r reads items r, r + world, ...
+
+
+def test_train_cli_two_ranks_and_resume(tmp_path):
+    """`trainer.gpus=2` (the reference's Lightning flag): the command line starts two ranks itself (gloo rehearsal on one
+    GPU), each trains on its shard, only rank 0 writes checkpoints; the checkpoint carries optimizer and scheduler state
+    under Lightning's keys and a second run resumes from it."""
+    import subprocess
+    import sys
+    tr, va = _toy_corpus(tmp_path)
+    out = tmp_path / 'run'
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['W2L_DIST_BACKEND'] = 'gloo'
+    cmd = [sys.executable, '-m', 'wav2letter_pytorch_amd.train', f'data.train_manifest={tr}', f'data.val_manifest={va}',
+           'data.batch_size=1', 'model.mid_layers=2', 'trainer.max_epochs=2', f'trainer.default_root_dir={out}',
+           'model.optimizer.lr=0.01', 'trainer.gpus=2', 'trainer.log_every_n_steps=1']
+    run = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=280)
+    assert run.returncode == 0, run.stderr[-2000:]
+    ck = sorted(f for f in os.listdir(out) if f.endswith('.ckpt'))
+    assert ck == ['epoch=0-step=2.ckpt', 'epoch=1-step=4.ckpt']           # 4 utterances / 2 ranks / batch 1 = 2 steps an epoch
+    assert run.stdout.count('epoch 0 done') == 1                          # rank 0 alone reports
+    state = torch.load(os.path.join(out, ck[-1]))
+    assert {'state_dict', 'epoch', 'global_step', 'optimizer_states', 'lr_schedulers'} <= set(state)
+    mom = [v for v in state['optimizer_states'][0]['state'].values() if v.get('momentum_buffer') is not None]
+    assert len(mom) == len(state['optimizer_states'][0]['param_groups'][0]['params'])
+    assert abs(state['lr_schedulers'][0]['_last_lr'][0] - 0.01 * 0.999 ** 2) < 1e-9
+    # resume (single process): continues at epoch 2 with the saved momentum and learning rate
+    from wav2letter_pytorch_amd.train import main
+    trainer, model = main([f'data.train_manifest={tr}', f'data.val_manifest={va}', 'data.batch_size=2', 'model.mid_layers=2',
+                           'trainer.max_epochs=3', f'trainer.default_root_dir={out}', 'model.optimizer.lr=0.01',
+                           f'trainer.resume_from_checkpoint={os.path.join(out, ck[-1])}'])
+    assert trainer.current_epoch == 2 and trainer.global_step == 4 + 2
+    assert abs(model.optimizers().param_groups[0]['lr'] - 0.01 * 0.999 ** 3) < 1e-9
+    assert len(trainer.val_logged) == 1 and {'val_loss', 'val_cer', 'val_wer'} <= set(trainer.val_logged[0])
+
+
 def test_train_cli_yaml_tree_and_jasper(tmp_path):
     """--config-dir: a Hydra-style tree with the reference's keys (written here), model=jasper group override"""
     import yaml

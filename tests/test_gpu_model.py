@@ -72,9 +72,21 @@ def test_w2l_golden(case, precision):
         idx = argmax_indices(out).cpu().numpy()
         agree = (idx == z['argmax']).mean()
         assert agree > 0.995          # identical unless two labels are within 1e-3 of each other
-        if agree == 1.0:
-            assert model.ctc_decoder.decode(out, out_lens) == list(z['decoded'])
+        # decoded strings: every utterance whose argmax path equals the reference's must decode to the reference's string,
+        # and at least one such utterance must exist (a near-tie between two labels may flip single frames elsewhere)
+        decoded = model.ctc_decoder.decode(out, out_lens)
+        same = [bool((idx[n, :int(out_lens[n])] == z['argmax'][n, :int(out_lens[n])]).all()) for n in range(len(texts))]
+        assert any(same)
+        for n, ok in enumerate(same):
+            if ok:
+                assert decoded[n] == str(z['decoded'][n]), n
+        if all(same):
             assert abs(m['train_cer'] - float(z['cer'])) < 1e-12 and abs(m['train_wer'] - float(z['wer'])) < 1e-12
+        # the metric arithmetic itself, unconditionally: the reference's decoded strings through this package's CER / WER
+        dec = model.ctc_decoder
+        ce, cr = map(sum, zip(*(dec.cer_ratio(t, str(h)) for t, h in zip(texts, z['decoded']))))
+        we, wr = map(sum, zip(*(dec.wer_ratio(t, str(h)) for t, h in zip(texts, z['decoded']))))
+        assert abs(ce / cr - float(z['cer'])) < 1e-12 and abs(we / wr - float(z['wer'])) < 1e-12
         model.eval()                  # eval mode: running statistics
         with torch.no_grad():
             oe, _ = model(x.cuda(), il)
@@ -498,6 +510,31 @@ def test_bench_two_rank_command_line(tmp_path):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['value'] > 0 and d['roofline']['achieved'] > 0
+
+
+def test_bench_self_launch_two_ranks(tmp_path):
+    """plain `python bench.py --gpus 2` (no torchrun, no rendezvous variables): bench.py starts the two ranks itself
+    (launch.spawn_ranks) and forwards rank 0's single JSON line with the size of the process group it really ran in;
+    rehearsed on one GPU with gloo.  A mismatch between --gpus and an outer launch is refused."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['W2L_DIST_BACKEND'] = 'gloo'
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--mid-layers', '2',
+           '--batch', '2', '--frames', '200', '--no-cpu-baseline']
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['rccl_world'] == 2 and d['backend'] == 'gloo' and d['config']['global_batch'] == 4
+    assert len(d['rank_ms_per_step']) == 2 and all(v > 0 for v in d['rank_ms_per_step'])
+    assert d['exposed_comm_ms'] is not None and abs(d['per_gpu_value'] * 2 - d['value']) < 1.0
+    bad = subprocess.run(cmd, env=dict(env, RANK='0', WORLD_SIZE='3', MASTER_ADDR='127.0.0.1', MASTER_PORT='1'), cwd=root,
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and 'must agree' in bad.stderr
 
 
 @pytest.mark.parametrize('amsgrad', [False, True])

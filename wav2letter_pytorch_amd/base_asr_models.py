@@ -1,8 +1,11 @@
 """ConvCTCASR: the LightningModule surface of the reference (base_asr_models.py:16-94) over
-the HIP step engine.  Same constructor, attributes, methods, log keys and config keys."""
+the HIP step engine.  Same constructor, attributes, methods, log keys and config keys; the bodies
+are this package's own: one shared step for training and validation, batch-level metric totals."""
 from __future__ import annotations
 
 import random
+from itertools import chain
+from typing import Callable, Dict, Sequence
 
 import torch
 import torch.nn as nn
@@ -30,6 +33,9 @@ except ImportError:  # pragma: no cover - exercised in this image
             return self._optimizers
 
 
+EXAMPLE_BATCH, EXAMPLE_FRAMES = 4, (100, 200)         # base_asr_models.py:27-31
+
+
 class ConvCTCASR(_Base):
     def __init__(self, cfg):
         super().__init__()
@@ -42,10 +48,11 @@ class ConvCTCASR(_Base):
         self.example_input_array = self.create_example_input_array()
 
     def create_example_input_array(self):
-        batch_size = 4
-        min_length, max_length = 100, 200
-        lengths = torch.randint(min_length, max_length, (4,))
-        return (torch.rand(batch_size, self._cfg.input_size, max_length), lengths)
+        """(spectrograms [4, input_size, 200] ~ U[0,1), lengths [4] ~ U{100..199}) -- Lightning's model summary input;
+        the length draw comes first, as in the reference, so a seeded construction yields the same example"""
+        lo, hi = EXAMPLE_FRAMES
+        lengths = torch.randint(lo, hi, (EXAMPLE_BATCH,))
+        return torch.rand(EXAMPLE_BATCH, self._cfg.input_size, hi), lengths
 
     def compute_output_lengths(self, input_lengths):
         """floor(input_lengths / scaling_factor) (base_asr_models.py:33-39)"""
@@ -58,25 +65,41 @@ class ConvCTCASR(_Base):
     def forward(self, inputs, input_lengths):
         raise NotImplementedError()
 
-    def add_string_metrics(self, out, output_lengths, texts, prefix):
-        decoded_texts = self.ctc_decoder.decode(out, output_lengths)
+    # ------------------------------------------------------------------ engine cache
+    def _cached_engine(self, build: Callable[[], 'object']):
+        """The StackEngine of this module tree, rebuilt only when a parameter / buffer OBJECT or its device changed
+        (``module.to()`` replaces buffer tensors; load_state_dict and optimizers write in place and keep them).  The
+        per-step switches (weight-gradient overlap, graph-mode dropout counter, data-parallel reducer) are re-read on
+        every call, so attaching a ``grad_reducer`` after the first forward takes effect."""
+        key = tuple((id(t), t.device) for t in chain(self.parameters(), self.buffers())) + (getattr(self, 'precision', None),)
+        hit = self.__dict__.get('_engine_cache')
+        if hit is None or hit[0] != key:
+            hit = (key, build())
+            self.__dict__['_engine_cache'] = hit
+        eng = hit[1]
+        eng.overlap_wgrad = getattr(self, '_overlap_wgrad', True)
+        eng.dropout_counter = getattr(self, '_dropout_counter', None)               # graph.GraphedTrainStep
+        reducer = getattr(self, 'grad_reducer', None)                               # set by data-parallel drivers
+        eng.grad_ready = reducer.on_grad if reducer is not None else None
+        eng.flat_ready = getattr(reducer, 'on_flat', None)
+        eng.backward_done = reducer.finish if reducer is not None else None
+        return eng
+
+    # ------------------------------------------------------------------ metrics
+    def add_string_metrics(self, out, output_lengths, texts, prefix) -> Dict[str, float]:
+        """greedy decode, then batch-level CER / WER (edit-distance totals over reference-length totals) and the
+        decoded / reference length ratio, under the reference's keys (base_asr_models.py:53-69)"""
+        hyps: Sequence[str] = self.ctc_decoder.decode(out, output_lengths)
         if random.random() < self.print_decoded_prob:
             print(f'reference: {texts[0]}')
-            print(f'decoded  : {decoded_texts[0]}')
-        wer_sum, cer_sum, wer_denom_sum, cer_denom_sum = 0, 0, 0, 0
-        for expected, predicted in zip(texts, decoded_texts):
-            cer_value, cer_denom = self.ctc_decoder.cer_ratio(expected, predicted)
-            wer_value, wer_denom = self.ctc_decoder.wer_ratio(expected, predicted)
-            cer_sum += cer_value
-            cer_denom_sum += cer_denom
-            wer_sum += wer_value
-            wer_denom_sum += wer_denom
-        cer = cer_sum / cer_denom_sum
-        wer = wer_sum / wer_denom_sum
-        lengths_ratio = sum(map(len, decoded_texts)) / sum(map(len, texts))
-        return {prefix + '_cer': cer, prefix + '_wer': wer, prefix + '_len_ratio': lengths_ratio}
+            print(f'decoded  : {hyps[0]}')
+        dec = self.ctc_decoder
+        char_err, char_ref = map(sum, zip(*(dec.cer_ratio(ref, hyp) for ref, hyp in zip(texts, hyps))))
+        word_err, word_ref = map(sum, zip(*(dec.wer_ratio(ref, hyp) for ref, hyp in zip(texts, hyps))))
+        return {f'{prefix}_cer': char_err / char_ref, f'{prefix}_wer': word_err / word_ref,
+                f'{prefix}_len_ratio': sum(len(h) for h in hyps) / sum(len(t) for t in texts)}
 
-    # PyTorch Lightning methods
+    # ------------------------------------------------------------------ Lightning hooks
     def configure_optimizers(self):
         optimizer = instantiate(self._cfg.optimizer, params=self.parameters())
         if type(optimizer) is torch.optim.SGD and next(self.parameters()).is_cuda:
@@ -89,20 +112,17 @@ class ConvCTCASR(_Base):
         dev = next(self.parameters()).device
         return inputs.to(dev, non_blocking=True) if inputs.device != dev else inputs
 
-    def training_step(self, batch, batch_idx):
-        inputs, input_lengths, targets, target_lengths, file_paths, texts = batch
-        out, output_lengths = self.forward(self._device_batch(inputs), input_lengths)
-        loss = self.criterion(out.transpose(0, 1), targets, output_lengths, target_lengths)
-        logs = {'train_loss': loss, 'learning_rate': self.optimizers().param_groups[0]['lr']}
-        logs.update(self.add_string_metrics(out, output_lengths, texts, 'train'))
-        self.log_dict(logs)
+    def _step(self, batch, prefix: str, extra: Dict[str, float]):
+        """forward -> CTC -> string metrics -> log_dict; the body of training_step and validation_step
+        (base_asr_models.py:78-94).  batch = _collator's 6-tuple (data_loader.py:149-158)."""
+        spect, spect_lens, targets, target_lens, _paths, texts = batch
+        out, out_lens = self.forward(self._device_batch(spect), spect_lens)
+        loss = self.criterion(out.transpose(0, 1), targets, out_lens, target_lens)
+        self.log_dict({f'{prefix}_loss': loss, **extra, **self.add_string_metrics(out, out_lens, texts, prefix)})
         return loss
 
+    def training_step(self, batch, batch_idx):
+        return self._step(batch, 'train', {'learning_rate': self.optimizers().param_groups[0]['lr']})
+
     def validation_step(self, batch, batch_idx):
-        inputs, input_lengths, targets, target_lengths, file_paths, texts = batch
-        out, output_lengths = self.forward(self._device_batch(inputs), input_lengths)
-        loss = self.criterion(out.transpose(0, 1), targets, output_lengths, target_lengths)
-        logs = {'val_loss': loss}
-        logs.update(self.add_string_metrics(out, output_lengths, texts, 'val'))
-        self.log_dict(logs)
-        return loss
+        return self._step(batch, 'val', {})

@@ -441,7 +441,9 @@ constexpr int kSplits[] = {1, 2, 3, 4, 5, 6, 8};
 constexpr int kNumSplits = sizeof(kSplits) / sizeof(kSplits[0]);
 constexpr int kBaseCfgs = 2 * kNumCfgs;
 constexpr size_t kTicketBytes = 64 * 1024;              // head of the split-K workspace: one counter per output tile
-static int g_force_cfg = -1;
+// thread-local: the tuner (and the test hook below) force a configuration for launches made by the CALLING thread only --
+// a backward running on an autograd worker thread while another thread tunes never sees a forced index
+static thread_local int g_force_cfg = -1;
 extern "C" void w2l_conv_force_tile_config(int idx) { g_force_cfg = idx; }
 
 static inline int cfg_xrows(const TileCfg& c, int stride, int Kw, int dil) {

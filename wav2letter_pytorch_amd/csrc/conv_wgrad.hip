@@ -383,8 +383,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
 typedef std::tuple<int, int, int, int, int> WShapeKey;
 std::map<WShapeKey, int> g_wtuned;
 std::mutex g_wtuned_mu;
-int g_force_splits = 0;
-int g_force_order = -1;
+thread_local int g_force_splits = 0;      // per calling thread, like g_force_cfg of the implicit GEMM
+thread_local int g_force_order = -1;
 constexpr int kDefaultOrder = 1;
 
 int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out, int* order_out = nullptr) {

@@ -160,6 +160,8 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):
     """identical replicas at step 0 (DDP broadcasts rank 0's state at construction)."""
     if not dist.is_initialized() or dist.get_world_size(group) <= 1:
         return
+    from .engine import invalidate_packed
+    invalidate_packed(module)              # .data writes below do not bump Parameter._version: repack on the next forward
     for t in list(module.parameters()) + list(module.buffers()):
         if t.is_contiguous():
             dist.broadcast(t.data, src, group=group)

@@ -185,6 +185,10 @@ if TUNE_CACHE and os.path.exists(TUNE_CACHE):
     load_tune_cache(TUNE_CACHE)
 atexit.register(_flush_tune_cache)
 
+# callables run at the end of every StackEngine.forward (optim.FusedSGD releases the previous step's gradients there, once
+# the forward has waited for every update that read them)
+AFTER_FORWARD: list = []
+
 # optional kernel timer (bench.py): list of (kernel_name, flops, start_event, end_event)
 KERNEL_TIMER: Optional[list] = None
 
@@ -237,6 +241,24 @@ def pack_weights(conv: ConvSpec, precise: bool, need_dgrad: bool = True) -> _Pac
     pk = _PackedW(w._version, fwd_hi, fwd_lo, dgr_hi, dgr_lo, cinp, coutp, w.data_ptr())
     cache[precise] = pk
     return pk
+
+
+def invalidate_packed(params) -> int:
+    """Drop the cached bf16 operand packs of ``params`` (an iterable of Parameters, or a Module).
+
+    The cache is keyed on ``Parameter._version``, which in-place writes through ``.data`` / raw pointers do not bump
+    (old-style optimizers doing ``p.data.add_``, EMA, weight clipping, ``dist.broadcast(p.data)``).  Whoever updates
+    weights that way calls this afterwards; the next forward then repacks from the fp32 master weights.  Weights updated
+    through version-bumping in-place ops (torch.optim, optim.FusedSGD, novograd.Novograd) need nothing."""
+    if isinstance(params, torch.nn.Module):
+        params = params.parameters()
+    n = 0
+    for p in params:
+        cache = getattr(p, '_w2l_pack', None)
+        if cache:
+            cache.clear()
+            n += 1
+    return n
 
 
 def _padded_vec(v: Optional[torch.Tensor], cp: int, fill: float) -> Optional[torch.Tensor]:
@@ -336,7 +358,9 @@ class StackEngine:
     """Executes a list of UnitSpec.  ``precise`` selects the split-bf16 (near-fp32) mode used
     for parity against the fp32 reference; the default is bf16 operands with fp32 accumulate."""
 
-    def __init__(self, units: Sequence[UnitSpec], head: ConvSpec, n_labels: int, precise: bool = False):
+    def __init__(self, units: Sequence[UnitSpec], head: Optional[ConvSpec], n_labels: int, precise: bool = False):
+        """``head`` = the classifier conv followed by (log_)softmax; ``None`` runs an OPEN stack whose result is the last
+        unit's activation as fp32 [N, C, T'] (stand-alone Conv1dBlock / MaskedConv1d / JasperBlock modules)."""
         self.units = list(units)
         self.head = head
         self.n_labels = n_labels
@@ -366,7 +390,8 @@ class StackEngine:
             out += u.main.params()
             if u.res is not None:
                 out += u.res.params()
-        out += self.head.params()
+        if self.head is not None:
+            out += self.head.params()
         return out
 
     # ------------------------------------------------------------------ forward
@@ -380,7 +405,7 @@ class StackEngine:
                 convs.append(u.dw if u.dw is not None else u.main)
             if u.res is not None and u.res_src == act_index:
                 convs.append(u.res)
-        if act_index == len(self.units):
+        if act_index == len(self.units) and self.head is not None:
             convs.append(self.head)
         for c in convs:
             if c.pad_l > pl or c.pad_r > pr:
@@ -452,19 +477,27 @@ class StackEngine:
             acts.append(Act(out_hi, out_lo, N, Tout, conv.cout, coutp, opl, opr, omode, uc.lens_out))
             ctx['units'].append(uc)
 
-        # ---- classifier (1x1 conv, bias, no BN) + (log_)softmax
-        last = acts[-1]
-        logits, _, Th = self._conv_forward(self.head, last, need_stats=False, force_f32=True)
-        out = torch.empty(N, Th, self.n_labels, dtype=torch.float32, device=dev)
-        check(lib.w2l_log_softmax_fwd(ptr(logits), N, Th, self.n_labels, logits.shape[2], softmax_mode, ptr(out), st()),
-              'w2l_log_softmax_fwd')
         if self._nbt_pending:
             torch._foreach_add_(self._nbt_pending, 1)
             self._nbt_pending = []
         ctx['acts'] = acts
-        ctx['out'] = out
         ctx['softmax_mode'] = softmax_mode
         ctx['lens_out'] = lens_final
+        last = acts[-1]
+        if self.head is None:           # open stack: hand the last activation back in the caller's layout (cold path, torch ops)
+            a = last.hi[:, last.pad_l:last.pad_l + last.T, :last.C].float()
+            if last.lo is not None:
+                a = a + last.lo[:, last.pad_l:last.pad_l + last.T, :last.C].float()
+            ctx['out'] = a.transpose(1, 2).contiguous()
+            return ctx['out'], ctx
+        # ---- classifier (1x1 conv, bias, no BN) + (log_)softmax
+        logits, _, Th = self._conv_forward(self.head, last, need_stats=False, force_f32=True)
+        out = torch.empty(N, Th, self.n_labels, dtype=torch.float32, device=dev)
+        check(lib.w2l_log_softmax_fwd(ptr(logits), N, Th, self.n_labels, logits.shape[2], softmax_mode, ptr(out), st()),
+              'w2l_log_softmax_fwd')
+        ctx['out'] = out
+        for hook in list(AFTER_FORWARD):
+            hook()
         return out, ctx
 
     def _plan_lens(self, lens, dev):
@@ -621,13 +654,17 @@ class StackEngine:
                   'w2l_bn_finalize')
         return scale, shift, mean, invstd
 
-    def _desc(self, uc: _UnitCtx, N, T, cp, p, lens) -> BnActDesc:
+    def _desc(self, uc: _UnitCtx, N, T, cp, p, lens, constant_stats: bool = False) -> BnActDesc:
+        """``constant_stats``: leave mean / invstd out, which makes w2l_bn_act_bwd_apply treat BatchNorm as the per-channel
+        affine map it is in eval mode (dy = scale * g)"""
         d = BnActDesc()
         d.N, d.T, d.C = N, T, cp
         d.y = uc.y.data_ptr()
         d.y_f32 = int(uc.y.dtype == torch.float32)
         for name in ('scale', 'shift', 'mean', 'invstd', 'scale2', 'shift2', 'mean2', 'invstd2'):
             t = getattr(uc, name)
+            if constant_stats and name in ('mean', 'invstd', 'mean2', 'invstd2'):
+                t = None
             setattr(d, name, t.data_ptr() if t is not None else None)
         d.y2 = uc.y2.data_ptr() if uc.y2 is not None else None
         d.act = uc.unit.act
@@ -646,19 +683,56 @@ class StackEngine:
         precise = self.precise
         acts: List[Act] = ctx['acts']
         out = ctx['out']
-        N, Th, L = out.shape
+        N = out.shape[0]
         dev = out.device
         st = stream_ptr
         grads = {}
+        # eval-mode forward normalised with the RUNNING statistics: they are constants of the step, so dy = scale * g (no
+        # batch-mean terms) and the conv bias in front of BatchNorm has the ordinary gradient sum(dy)
+        batch_stats = bool(ctx['training'])
         # every per-channel gradient of the step (BatchNorm gamma / beta sums, classifier bias) lives in ONE buffer: a
         # data-parallel run averages it with one collective instead of ~80 small ones (or a gather + scatter of them)
-        pool_elems = roundup(self.head.cout, 64)
+        pool_elems = roundup(self.head.cout, 64) if self.head is not None else 0
         for uc in ctx['units']:
             if uc.unit.main.has_bn or (uc.unit.res is not None and uc.unit.res.has_bn):
                 pool_elems += 4 * acts[uc.out_index].CP
         small_pool = torch.zeros(pool_elems, dtype=torch.float32, device=dev)       # rows of absent residual branches stay 0
         pool_off = 0
-        # ---- (log_)softmax backward -> classifier gradients
+        act_grads: List[List[tuple]] = [[] for _ in acts]
+        if self.head is None:
+            # open stack: the caller's gradient wrt the fp32 [N, C, T'] result becomes the (unpadded, fp32) gradient source
+            last = acts[-1]
+            gp = torch.zeros(N, last.T, last.CP, dtype=torch.float32, device=dev)
+            gp[:, :, :last.C] = g_out.float().transpose(1, 2)
+            act_grads[len(acts) - 1].append((gp, 0, 0, PAD_ZERO, last.T))
+        else:
+            pool_off = self._head_backward(ctx, g_out, small_pool, grads, act_grads)
+        self._units_backward(ctx, act_grads, small_pool, pool_off, grads, batch_stats)
+        ctx['input_grad'] = self.input_grad(ctx, act_grads[0]) if ctx.get('want_dx') and act_grads[0] else None
+        if self.flat_ready is not None:
+            self.flat_ready(small_pool)
+        elif self.grad_ready is not None:
+            self.grad_ready(None, small_pool, small_pool)
+        if self._side_used:
+            torch.cuda.current_stream(dev).wait_stream(self._side)
+            self._side_used = False
+        self._held.clear()
+        self._zero_pool = None
+        _flush_tune_cache()
+        if self.backward_done is not None:
+            self.backward_done()
+        return [grads.get(id(p)) for p in self.parameters()]
+
+    def _head_backward(self, ctx, g_out, small_pool, grads, act_grads) -> int:
+        """(log_)softmax backward -> classifier weight / bias gradients and the gradient wrt the last activation;
+        returns the number of pool elements it used"""
+        precise = self.precise
+        acts: List[Act] = ctx['acts']
+        out = ctx['out']
+        N, Th, L = out.shape
+        dev = out.device
+        st = stream_ptr
+        pool_off = 0
         g_out = g_out.contiguous().float()
         glog = torch.empty_like(out)
         check(lib.w2l_log_softmax_bwd(ptr(g_out), ptr(out), N, Th, L, ctx['softmax_mode'], ptr(glog), st()),
@@ -676,10 +750,16 @@ class StackEngine:
         self._wgrad(head, pk, dy_hi, dy_lo, hh, Th, last, grads)
         if head.bias is not None:
             grads[id(head.bias)] = colsum[: head.cout]          # travels with the pool
-        act_grads: List[List[tuple]] = [[] for _ in acts]
         act_grads[len(acts) - 1].append(self._dgrad(head, pk, dy_hi, dy_lo, hh, Th, last))
+        return pool_off
 
-        # ---- units in reverse
+    def _units_backward(self, ctx, act_grads, small_pool, pool_off, grads, batch_stats: bool):
+        """the units in reverse: BatchNorm / activation backward -> dy -> weight gradient (side stream) -> data gradient"""
+        precise = self.precise
+        acts: List[Act] = ctx['acts']
+        N = ctx['out'].shape[0]
+        dev = ctx['out'].device
+        st = stream_ptr
         for uc in reversed(ctx['units']):
             u = uc.unit
             oi = uc.out_index
@@ -717,6 +797,8 @@ class StackEngine:
                 h2 = max((res.kernel - 1) * res.dilation, tail)
                 dy2_hi = torch.empty(h2 + N * (Tout + h2), coutp, dtype=torch.bfloat16, device=dev)
                 dy2_lo = torch.empty_like(dy2_hi) if precise else None
+            if not batch_stats:
+                d = self._desc(uc, N, Tout, coutp, p, uc.lens_out, constant_stats=True)
             check(lib.w2l_bn_act_bwd_apply(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(sums), ptr(dy_hi),
                                            ptr(dy_lo), h1, ptr(dy2_hi), ptr(dy2_lo), h2, st()),
                   'w2l_bn_act_bwd_apply')
@@ -734,11 +816,10 @@ class StackEngine:
             src = acts[u.src] if u.dw is None else uc.mid
             self._wgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, grads)
             if main.bias is not None:
-                if main.has_bn:      # sum(dy) == 0 identically under BatchNorm
+                if main.has_bn and batch_stats:      # sum(dy) == 0 identically under batch-statistics BatchNorm
                     grads[id(main.bias)] = self._zeros(main.cout, dev)      # zero on every rank: nothing to average
                 else:
-                    dyv = dy_hi[h1:].view(N, Tout + h1, coutp)[:, :Tout, : main.cout]
-                    self._set(grads, main.bias, dyv.float().sum((0, 1)))
+                    self._set(grads, main.bias, self._dy_colsum(dy_hi, dy_lo, h1, N, Tout, coutp, main.cout))
             if u.dw is not None:
                 dmid = self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src)
                 gsrc = self._dw_backward(u.dw, dmid, acts[u.src], uc.mid, need_dx_main, grads)
@@ -751,24 +832,12 @@ class StackEngine:
                 rsrc = acts[u.res_src]
                 self._wgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc, grads)
                 if res.bias is not None:
-                    grads[id(res.bias)] = self._zeros(res.cout, dev)
+                    if res.has_bn and batch_stats:
+                        grads[id(res.bias)] = self._zeros(res.cout, dev)
+                    else:
+                        self._set(grads, res.bias, self._dy_colsum(dy2_hi, dy2_lo, h2, N, Tout, coutp, res.cout))
                 if self._needs_grad(u.res_src, ctx):
                     act_grads[u.res_src].append(self._dgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc))
-        ctx['input_grad'] = self.input_grad(ctx, act_grads[0]) if ctx.get('want_dx') and act_grads[0] else None
-        if self.flat_ready is not None:
-            self.flat_ready(small_pool)
-        elif self.grad_ready is not None:
-            self.grad_ready(None, small_pool, small_pool)
-        if self._side_used:
-            torch.cuda.current_stream(dev).wait_stream(self._side)
-            self._side_used = False
-        self._held.clear()
-        self._zero_pool = None
-        _flush_tune_cache()
-        if self.backward_done is not None:
-            self.backward_done()
-        return [grads.get(id(p)) for p in self.parameters()]
-
     # ------------------------------------------------------------------ helpers
     def _needs_grad(self, act_index: int, ctx=None) -> bool:
         # the spectrogram needs no gradient in training (base_asr_models.py:78-85); computed only on request
@@ -793,6 +862,14 @@ class StackEngine:
             t = torch.arange(T0, device=total.device)[None, :, None]
             total = total * (t < a0.lens.long()[:, None, None])
         return total.transpose(1, 2).contiguous()
+
+    @staticmethod
+    def _dy_colsum(dy_hi, dy_lo, halo, N, Tout, coutp, cout) -> torch.Tensor:
+        """bias gradient sum_{n,t} dy of a conv that is not followed by batch-statistics BatchNorm (cold path, torch ops)"""
+        v = dy_hi[halo:].view(N, Tout + halo, coutp)[:, :Tout, :cout].float()
+        if dy_lo is not None:
+            v = v + dy_lo[halo:].view(N, Tout + halo, coutp)[:, :Tout, :cout].float()
+        return v.sum((0, 1))
 
     def _zeros(self, n: int, dev) -> torch.Tensor:
         """an fp32 zero vector carved from one zero-filled buffer per backward (one fill launch instead of one per layer)"""

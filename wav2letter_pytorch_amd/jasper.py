@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .base_asr_models import ConvCTCASR
 from .engine import ACT_NONE, ACT_RELU, PAD_ZERO, StackEngine, UnitSpec
-from .layers import BatchNorm1d, Conv1d, conv_spec, default_precision, run_stack
+from .layers import BatchNorm1d, Conv1d, conv_spec, default_precision, run_stack, solo_engine
 
 jasper_activations = {
     "hardtanh": nn.Hardtanh,
@@ -93,7 +93,16 @@ class MaskedConv1d(nn.Module):
                 ) / self.conv.stride[0] + 1
 
     def forward(self, x, lens):
-        raise RuntimeError('MaskedConv1d runs inside Jasper.forward on the HIP step engine')
+        """(x [N, C, T], lens [N]) -> (conv(masked x), updated float lens) -- jasper.py:114-132 -- as a one-unit open engine
+        with autograd; inside Jasper the model's engine runs the conv fused with its neighbours."""
+        if self.conv.groups != 1:
+            raise NotImplementedError('a stand-alone depthwise MaskedConv1d has no execution path: it runs in front of its '
+                                      'pointwise partner inside a separable JasperBlock')
+        pad = self.conv.padding[0]
+        eng = solo_engine(self, lambda: [UnitSpec(main=conv_spec(self.conv, None, pad, pad, PAD_ZERO, 'mconv'), src=0,
+                                                   act=ACT_NONE, update_lens=self.use_mask)])
+        out, lens_f = run_stack(eng, x, lens if self.use_mask else None, self.training)
+        return out, (lens_f if self.use_mask else lens)
 
 
 class GroupShuffle(nn.Module):
@@ -221,7 +230,14 @@ class JasperBlock(nn.Module):
         return out
 
     def forward(self, input_):
-        raise RuntimeError('JasperBlock runs inside Jasper.forward on the HIP step engine')
+        """((x [N, C, T], lens)) -> (block output [N, planes, T'], lens') -- jasper.py:379-419 -- as an open engine of the
+        block's units with autograd.  The output is not length-masked (the NEXT MaskedConv1d does that, jasper.py:116-119)."""
+        xs, lens = (input_[0], input_[1]) if len(input_) == 2 else (input_[0], None)
+        if isinstance(xs, (list, tuple)):
+            xs = xs[-1]
+        eng = solo_engine(self, lambda: self.units(0, 1, 'block', mask_last_output=False))
+        out, lens_f = run_stack(eng, xs, lens, self.training)
+        return out, lens_f
 
 
 class Jasper(ConvCTCASR):
@@ -261,7 +277,7 @@ class Jasper(ConvCTCASR):
             self._scaling_factor = int(np.prod([block.mconv[0].conv.stride[0] for block in self.jasper_encoder]))
         return self._scaling_factor
 
-    def engine(self) -> StackEngine:
+    def _build_engine(self) -> StackEngine:
         units: List[UnitSpec] = []
         a_in = 0
         blocks = list(self.jasper_encoder)
@@ -271,15 +287,10 @@ class Jasper(ConvCTCASR):
             units += us
             a_in = len(units)
         head = conv_spec(self.final_layer[0], None, 0, 0, PAD_ZERO, 'head')
-        eng = StackEngine(units, head, len(self.labels), precise=self.precision == 'fp32')
-        eng.overlap_wgrad = getattr(self, '_overlap_wgrad', True)
-        eng.dropout_counter = getattr(self, '_dropout_counter', None)               # graph.GraphedTrainStep
-        reducer = getattr(self, 'grad_reducer', None)
-        if reducer is not None:
-            eng.grad_ready = reducer.on_grad
-            eng.flat_ready = getattr(reducer, 'on_flat', None)
-            eng.backward_done = reducer.finish
-        return eng
+        return StackEngine(units, head, len(self.labels), precise=self.precision == 'fp32')
+
+    def engine(self) -> StackEngine:
+        return self._cached_engine(self._build_engine)
 
     def forward(self, xs, input_lengths):
         """[batch, channels, time], lengths -> ([batch, time', labels], lengths) (jasper.py:462-475):

@@ -4,12 +4,13 @@ from __future__ import annotations
 
 import math
 import os
-from typing import Optional
+from itertools import chain
+from typing import Callable, Optional
 
 import torch
 import torch.nn as nn
 
-from .engine import ConvSpec, StackEngine
+from .engine import ACT_NONE, PAD_ZERO, ConvSpec, StackEngine, UnitSpec
 
 
 def default_precision(cfg=None) -> str:
@@ -67,7 +68,15 @@ class Conv1d(nn.Module):
                 f'padding={self.padding}, dilation={self.dilation}, bias={self.bias is not None}')
 
     def forward(self, x):
-        raise RuntimeError('Conv1d is executed by the HIP step engine through its parent model')
+        """[N, C_in, T] -> [N, C_out, T'] fp32: the convolution alone (zero padding ``self.padding``), as a one-unit open
+        engine with autograd.  Inside a model the parent's engine runs it fused with its neighbours instead."""
+        if self.groups != 1:
+            raise NotImplementedError('a stand-alone grouped / depthwise Conv1d has no execution path: depthwise convs run '
+                                      'in front of their pointwise partner inside a separable JasperBlock')
+        pad = self.padding[0]
+        eng = solo_engine(self, lambda: [UnitSpec(main=conv_spec(self, None, pad, pad, PAD_ZERO, 'conv'), src=0, act=ACT_NONE)])
+        out, _ = run_stack(eng, x, None, self.training)
+        return out
 
 
 class BatchNorm1d(nn.Module):
@@ -88,7 +97,8 @@ class BatchNorm1d(nn.Module):
         return f'{self.num_features}, eps={self.eps}, momentum={self.momentum}'
 
     def forward(self, x):
-        raise RuntimeError('BatchNorm1d is executed by the HIP step engine through its parent model')
+        raise RuntimeError('BatchNorm1d holds parameters and running statistics only: the kernels normalise the output of '
+                           'the convolution in front of it (Conv1dBlock / JasperBlock), there is no conv-less BatchNorm pass')
 
 
 def conv_spec(conv: Conv1d, bn: Optional[BatchNorm1d], pad_l: int, pad_r: int, pad_mode: int, name: str = '',
@@ -136,3 +146,15 @@ def run_stack(engine: StackEngine, x, lens, training: bool, softmax_mode: int = 
     if keep_ctx:
         return out, holder.get('lens_out'), holder.get('ctx')
     return out, holder.get('lens_out')
+
+
+def solo_engine(owner: nn.Module, units_fn: Callable[[], list]) -> StackEngine:
+    """Open (head-less) engine for a module called on its own -- Conv1dBlock, MaskedConv1d, JasperBlock, Conv1d --
+    cached on the module and rebuilt when a parameter / buffer object, its device or the precision changes."""
+    prec = getattr(owner, 'precision', None) or default_precision()
+    key = tuple((id(t), t.device) for t in chain(owner.parameters(), owner.buffers())) + (prec,)
+    hit = owner.__dict__.get('_solo_engine')
+    if hit is None or hit[0] != key:
+        hit = (key, StackEngine(units_fn(), None, 0, precise=prec == 'fp32'))
+        owner.__dict__['_solo_engine'] = hit
+    return hit[1]

@@ -6,30 +6,39 @@ Hydra / Lightning:
 
 Same override syntax and config keys as ``python train.py ...``; without ``--config-dir`` the built-in copy of the
 hyper-parameters (defaults.py) is used.  Manifests, labels, feature extraction and batching are data/data_loader.py's;
-the fit loop is trainer.Trainer.  Under ``python -m torch.distributed.run --nproc-per-node N`` every rank trains on its
-own GPU and gradients are averaged with RCCL (distributed.GradReducer)."""
+the fit loop is trainer.Trainer.  ``trainer.gpus=N`` (the reference's Lightning flag, README.md:40) starts N ranks of this
+command line (launch.py), one per GPU; ``python -m torch.distributed.run --nproc-per-node N`` works too.  Every rank trains
+on its own shard of the manifest and gradients are averaged with RCCL (distributed.GradReducer)."""
 from __future__ import annotations
 
 import os
 import sys
 
 import torch
+from torch.utils.data.distributed import DistributedSampler
 
 from . import Jasper, Wav2Letter
-from .config import _yaml_load, load_config, to_cfg
 from .data import label_sets
 from .data.data_loader import BatchAudioDataLoader, SpectrogramDataset
-from .defaults import root_config
+from .launch import spawn_ranks, under_launcher
 from .trainer import Trainer
 
 name_to_model = {'jasper': Jasper, 'wav2letter': Wav2Letter}
 
 
-def get_data_loaders(labels, cfg):
-    """train.py:21-26"""
-    train = SpectrogramDataset(cfg.train_manifest, cfg.audio_conf, labels, mel_spec=cfg.mel_spec)
-    val = SpectrogramDataset(cfg.val_manifest, cfg.audio_conf, labels, mel_spec=cfg.mel_spec)
-    return BatchAudioDataLoader(train, batch_size=cfg.batch_size), BatchAudioDataLoader(val, batch_size=cfg.batch_size)
+def get_data_loaders(labels, cfg, rank: int = 0, world: int = 1):
+    """train.py:21-26.  With more than one rank each loader walks its own shard of the manifest: a DistributedSampler
+    over the raw items (indices rank, rank + world, ...; the tail padded so every rank takes the same number of steps --
+    a rank that ran out of batches early would leave the others waiting in a collective), which is what Lightning's DDP
+    injects into the reference's loaders."""
+    loaders = []
+    for manifest in (cfg.train_manifest, cfg.val_manifest):
+        ds = SpectrogramDataset(manifest, cfg.audio_conf, labels, mel_spec=cfg.mel_spec)
+        kw = {}
+        if world > 1:
+            kw['sampler'] = DistributedSampler(range(len(ds)), num_replicas=world, rank=rank, shuffle=False)
+        loaders.append(BatchAudioDataLoader(ds, batch_size=cfg.batch_size, **kw))
+    return loaders[0], loaders[1]
 
 
 def build_config(argv):
@@ -64,18 +73,40 @@ def build_config(argv):
     return cfg
 
 
+def _requested_gpus(cfg) -> int:
+    """trainer.gpus of the reference's config tree (configuration/config.yaml: passed to pytorch_lightning.Trainer):
+    an int is a device count, a list names devices"""
+    g = cfg.trainer.get('gpus', 0)
+    if isinstance(g, (list, tuple)):
+        return len(g)
+    try:
+        return int(g or 0)
+    except (TypeError, ValueError):
+        return 0
+
+
 def main(argv=None):
-    cfg = build_config(sys.argv[1:] if argv is None else argv)
+    argv = sys.argv[1:] if argv is None else list(argv)
+    cfg = build_config(argv)
     for key in ('train_manifest', 'val_manifest'):
         if cfg.data.get(key) in (None, '???'):
             raise SystemExit(f'data.{key} is required (e.g. data.{key}=/path/to/manifest.csv)')
+    n_gpus = _requested_gpus(cfg)
+    if n_gpus > 1 and not under_launcher():
+        # Trainer(gpus=N) of the reference = N DDP processes.  This parent has not touched the GPU: it only starts the ranks.
+        rc = spawn_ranks(n_gpus, [sys.executable, '-m', 'wav2letter_pytorch_amd.train'] + argv)
+        if rc:
+            raise SystemExit(rc)
+        return None, None
     if type(cfg.model.labels) is str:
         cfg.model.labels = list(label_sets.labels_map[cfg.model.labels])
     if isinstance(cfg.model.get('decoder'), dict):
         cfg.model.decoder.labels = cfg.model.labels
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-    train_loader, val_loader = get_data_loaders(cfg.model.labels, cfg.data)
+    rank = int(os.environ.get('RANK', '0'))
+    local = 0 if os.environ.get('W2L_DIST_BACKEND') == 'gloo' else int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    train_loader, val_loader = get_data_loaders(cfg.model.labels, cfg.data, rank, world)
     model = name_to_model[cfg.model.name](cfg.model)
     if world > 1:
         from .distributed import GradReducer, broadcast_parameters, init_process_group_from_env

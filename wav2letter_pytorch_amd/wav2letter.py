@@ -1,21 +1,30 @@
 """Wav2Letter on the HIP step engine (reference: wav2letter.py:12-92)."""
 from __future__ import annotations
 
+import math
 from collections import OrderedDict
+from typing import Tuple
 
-import numpy as np
-import torch
 import torch.nn as nn
 
 from .base_asr_models import ConvCTCASR
 from .engine import ACT_CLAMP20, ACT_NONE, PAD_REFLECT, StackEngine, UnitSpec
-from .layers import BatchNorm1d, Conv1d, conv_spec, default_precision, run_stack
+from .layers import BatchNorm1d, Conv1d, conv_spec, default_precision, run_stack, solo_engine
+
+
+def same_pad_amounts(rows: int, kernel: int, stride: int, dilation: int) -> Tuple[int, int, int]:
+    """TF-style SAME padding of an axis of ``rows`` samples: (total, left, right), the odd sample on the right.
+    The reference feeds this rule the number of input CHANNELS, not the sequence length (wav2letter.py:24-27); for
+    stride 1 the result is length-independent ((k-1)*d), and the 64-mel stride-2 first layer gets 9 = (4, 5)."""
+    covered = (math.ceil(rows / stride) - 1) * stride + (kernel - 1) * dilation + 1
+    total = max(0, covered - rows)
+    return total, total // 2, total - total // 2
 
 
 class Conv1dBlock(nn.Module):
     """reflect-pad -> Conv1d -> BatchNorm1d(momentum=.9, eps=1e-3) -> Dropout -> clamp(0, 20)
-    (wav2letter.py:12-47).  Note the reference's pad rule derives the SAME-padding amount from
-    ``input_channels`` (wav2letter.py:24-27); reproduced as is."""
+    (wav2letter.py:12-47).  Inside Wav2Letter the block is one unit of the model's step engine; called on its own
+    (``block(x)`` with x [N, C_in, T] on the device) it runs as a one-unit engine with autograd."""
 
     def __init__(self, input_channels, output_channels, kernel_size, stride, drop_out_prob=-1.0, dilation=1, bn=True,
                  activation_use=True):
@@ -27,16 +36,12 @@ class Conv1dBlock(nn.Module):
         self.drop_out_prob = drop_out_prob
         self.dilation = dilation
         self.activation_use = activation_use
-        self.padding = kernel_size[0]
-        input_rows = input_channels
-        filter_rows = kernel_size[0]
-        out_rows = (input_rows + stride - 1) // stride
-        self.padding_rows = max(0, (out_rows - 1) * stride + (filter_rows - 1) * dilation + 1 - input_rows)
-        self.pad_l = self.padding_rows // 2
-        self.pad_r = (self.padding_rows + 1) // 2 if self.padding_rows % 2 else self.padding_rows // 2
+        self.padding = kernel_size[0]                      # kept (and unused) as in the reference, wav2letter.py:22
+        self.padding_rows, self.pad_l, self.pad_r = same_pad_amounts(input_channels, kernel_size[0], stride, dilation)
         self.conv1 = Conv1d(input_channels, output_channels, kernel_size, stride=stride, padding=0, dilation=dilation)
         self.batch_norm = BatchNorm1d(output_channels, momentum=0.9, eps=0.001) if bn else None
         self.has_dropout = self.drop_out_prob != -1
+        self.precision = default_precision()
 
     def unit(self, src: int, name: str = '') -> UnitSpec:
         spec = conv_spec(self.conv1, self.batch_norm, self.pad_l, self.pad_r, PAD_REFLECT, name)
@@ -44,75 +49,53 @@ class Conv1dBlock(nn.Module):
         return UnitSpec(main=spec, src=src, act=ACT_CLAMP20 if self.activation_use else ACT_NONE, drop_p=max(p, 0.0))
 
     def forward(self, xs):
-        raise RuntimeError('Conv1dBlock runs inside Wav2Letter.forward on the HIP step engine; '
-                           'a stand-alone block has no execution path of its own')
+        """[N, C_in, T] -> [N, C_out, T'] fp32 (wav2letter.py:40-47)"""
+        eng = solo_engine(self, lambda: [self.unit(0, 'conv1d')])
+        out, _ = run_stack(eng, xs, None, self.training)
+        return out
 
 
 class Wav2Letter(ConvCTCASR):
     def __init__(self, cfg):
         super(Wav2Letter, self).__init__(cfg)
         self.mid_layers = cfg.mid_layers
-        if not cfg.input_size:
-            nfft = (self.audio_conf['sample_rate'] * self.audio_conf['window_size'])
-            self.input_size = int(1 + (nfft / 2))
-        else:
-            self.input_size = cfg.input_size
+        # spectrogram bins when the config gives no feature size (wav2letter.py:53-57): 1 + n_fft / 2
+        self.input_size = cfg.input_size or int(1 + self.audio_conf['sample_rate'] * self.audio_conf['window_size'] / 2)
         self.precision = default_precision(cfg)
-
-        layers = cfg.layers[: self.mid_layers]
-        layer_size = self.input_size
-        conv_blocks = []
-        for idx in range(len(layers)):
-            layer_params = layers[idx]
-            layer = Conv1dBlock(input_channels=layer_size, output_channels=layer_params.output_size,
-                                kernel_size=(layer_params.kernel_size,), stride=layer_params.stride,
-                                dilation=layer_params.dilation, drop_out_prob=layer_params.dropout)
-            layer_size = layer_params.output_size
-            conv_blocks.append(('conv1d_{}'.format(idx), layer))
-        last_layer = Conv1dBlock(input_channels=layer_size, output_channels=len(self.labels), kernel_size=(1,),
-                                 stride=1, bn=False, activation_use=False)
-        conv_blocks.append(('conv1d_{}'.format(len(layers)), last_layer))
-        self.conv1ds = nn.Sequential(OrderedDict(conv_blocks))
-        self._engine = None
+        rows = list(cfg.layers[: self.mid_layers])
+        widths = [self.input_size] + [r.output_size for r in rows]
+        blocks = [Conv1dBlock(input_channels=c_in, output_channels=r.output_size, kernel_size=(r.kernel_size,),
+                              stride=r.stride, dilation=r.dilation, drop_out_prob=r.dropout)
+                  for c_in, r in zip(widths, rows)]
+        # classifier: 1x1 conv to the label set, no BatchNorm / activation / dropout (wav2letter.py:69-70)
+        blocks.append(Conv1dBlock(input_channels=widths[-1], output_channels=len(self.labels), kernel_size=(1,), stride=1,
+                                  bn=False, activation_use=False))
+        self.conv1ds = nn.Sequential(OrderedDict((f'conv1d_{i}', b) for i, b in enumerate(blocks)))
 
     @property
     def scaling_factor(self):
-        if not hasattr(self, '_scaling_factor'):
-            strides = []
-            for module in self.conv1ds.children():
-                strides.append(module.conv1.stride[0])
-            self._scaling_factor = int(np.prod(strides))
-        return self._scaling_factor
+        """input frames per output frame = product of the conv strides (wav2letter.py:74-81), computed once"""
+        cached = self.__dict__.get('_scaling_factor')
+        if cached is None:
+            cached = self.__dict__['_scaling_factor'] = math.prod(b.conv1.stride[0] for b in self.conv1ds.children())
+        return cached
+
+    def _build_engine(self) -> StackEngine:
+        *body, head_blk = self.conv1ds.children()
+        if head_blk.batch_norm is not None or head_blk.activation_use or head_blk.padding_rows:
+            raise NotImplementedError('the classifier block must be a plain 1x1 convolution (wav2letter.py:69)')
+        units = [b.unit(i, f'conv1d_{i}') for i, b in enumerate(body)]
+        head = conv_spec(head_blk.conv1, None, 0, 0, PAD_REFLECT, 'head')
+        return StackEngine(units, head, len(self.labels), precise=self.precision == 'fp32')
 
     def engine(self) -> StackEngine:
-        # rebuilt per call: module.to()/cuda() replaces buffer tensors, so specs must not go stale
-        precise = self.precision == 'fp32'
-        if True:
-            blocks = list(self.conv1ds.children())
-            units = [b.unit(i, f'conv1d_{i}') for i, b in enumerate(blocks[:-1])]
-            head_blk = blocks[-1]
-            if head_blk.batch_norm is not None or head_blk.activation_use or head_blk.padding_rows:
-                raise NotImplementedError('the classifier block must be a plain 1x1 convolution (wav2letter.py:69)')
-            head = conv_spec(head_blk.conv1, None, 0, 0, PAD_REFLECT, 'head')
-            self._engine = StackEngine(units, head, len(self.labels), precise=precise)
-            self._engine.overlap_wgrad = getattr(self, '_overlap_wgrad', True)
-            self._engine.dropout_counter = getattr(self, '_dropout_counter', None)      # graph.GraphedTrainStep
-            reducer = getattr(self, 'grad_reducer', None)      # set by distributed training drivers
-            if reducer is not None:
-                self._engine.grad_ready = reducer.on_grad
-                self._engine.flat_ready = getattr(reducer, 'on_flat', None)
-                self._engine.backward_done = reducer.finish
-        return self._engine
+        return self._cached_engine(self._build_engine)
 
     def forward(self, x, input_lengths=None):
         """x [N, input_size, T] float -> (log_probs [N, T', n_labels], output_lengths or None)
         (wav2letter.py:84-92).  Lengths are not used inside the network (no masking)."""
-        if getattr(self, '_debug_keep_ctx', False):      # test hook: expose the engine's saved activations
-            x, _, self._last_ctx = run_stack(self.engine(), x, None, self.training, softmax_mode=0, keep_ctx=True)
-        else:
-            x, _ = run_stack(self.engine(), x, None, self.training, softmax_mode=0)
-        if input_lengths is not None:
-            output_lengths = self.compute_output_lengths(input_lengths)
-        else:
-            output_lengths = None
-        return x, output_lengths
+        keep = getattr(self, '_debug_keep_ctx', False)        # test hook: expose the engine's saved activations
+        res = run_stack(self.engine(), x, None, self.training, softmax_mode=0, keep_ctx=keep)
+        if keep:
+            self._last_ctx = res[2]
+        return res[0], (None if input_lengths is None else self.compute_output_lengths(input_lengths))
