@@ -42,9 +42,11 @@ int w2l_pack_weights(const float* w, int64_t s_co, int64_t s_ci, int64_t s_kw, i
 /* torch.optim.SGD(momentum, nesterov, weight_decay; dampening 0) -- configuration/optimizer/exp_lr_optimizer.yaml:2-7
  * -- fused with w2l_pack_weights for a tap-major conv weight: p, g, m are dense fp32 [Kw][Cout][Cin];
  * first_step != 0 initialises the momentum buffer with the (decayed) gradient as torch does.  The bf16
- * outputs are the operands of the next step (no channel padding: Cout, Cin multiples of 64). */
-int w2l_sgd_pack(float* p, const float* g, float* m, int first_step, float lr, float momentum, float weight_decay,
-                 int nesterov, int Cout, int Cin, int Kw, void* w_fwd_hi, void* w_fwd_lo, void* w_dgr_hi,
+ * outputs are the operands of the next step (no channel padding: Cout, Cin multiples of 64).  zero_grad != 0 writes
+ * zeros back into g once it has been read: the buffer can then serve as the next step's dw without a fill launch
+ * (split-K weight gradients accumulate with atomics into a zeroed buffer, see w2l_wgrad_needs_zero). */
+int w2l_sgd_pack(float* p, float* g, float* m, int first_step, float lr, float momentum, float weight_decay,
+                 int nesterov, int zero_grad, int Cout, int Cin, int Kw, void* w_fwd_hi, void* w_fwd_lo, void* w_dgr_hi,
                  void* w_dgr_lo, void* stream);
 
 /* input spectrogram fp32 [N][C][T] -> padded NTC bf16 [N][pad_l+T+pad_r][CP];

@@ -219,61 +219,73 @@ __device__ __forceinline__ void bwd_row(const w2l_bnact_t& d, const Chan& c1, co
     }
 }
 
-constexpr int BWD_ROWS_PER_BLOCK = 16;   // 1000 blocks at N*T = 16000
+// ---- backward reduction: partial[chunk][ncomp][C] = sum over the chunk's rows of g, g*xh1 [, g, g*xh2 with a residual
+// branch].  One WAVE owns a 64-channel slab (8 lanes x 16 bytes = one 128-byte line per row) of one row chunk and walks it
+// 8 rows at a time; the eight row-lanes are combined with lane shuffles and lanes 0..7 store the slab's sums.  No LDS and
+// no block barrier: the kernel's occupancy is bounded by registers only, so its blocks fit next to whatever else is
+// resident (the LDS version -- 24 KB per block -- ran at one block per CU beside the weight-gradient kernel, which takes
+// 132 of a CU's 160 KB).  The four waves of a block take four adjacent slabs of the same rows.  Deterministic.
+constexpr int BWD_SLAB = 64;             // channels per wave
+__host__ __device__ inline int bwd_rows_per_wave(int64_t rows, int C) {
+    // ~4096 wave tasks per launch: 16 rows for the narrow layers, up to 64 for the wide ones
+    int64_t rw = rows * (C / BWD_SLAB) / 4096;
+    rw = rw / 8 * 8;
+    return (int)(rw < 16 ? 16 : (rw > 64 ? 64 : rw));
+}
 
-// partial[blk][ncomp][C]: sum g, sum g*xh1 [, sum g, sum g*xh2 when there is a residual branch].
-// A thread owns one channel group for the whole block: per-channel constants live in registers.
 template <bool F32, bool GF32, bool HAS2>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(w2l_bnact_t d, w2l_gradsrc_t g1, w2l_gradsrc_t g2,
-                                                                 int has_g2, float* partial, float inv_keep) {
-    extern __shared__ float red[];               // [RPB][3][C]
+                                                                 int has_g2, float* partial, float inv_keep, int rw,
+                                                                 int nchunks) {
     const int G = d.C >> 3;
-    const int RPB = 256 / G;
-    const int tid = threadIdx.x;
-    const int rr = tid / G, cg = tid - rr * G;
+    const int nslabs = d.C / BWD_SLAB;
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= nslabs * nchunks) return;                     // (whole waves leave: no barrier below)
+    const int chunk = task / nslabs, slab = task - chunk * nslabs;
+    const int cg = slab * (BWD_SLAB / 8) + (lane & 7);        // 8-channel group of this lane
+    const int rr = lane >> 3;                                 // row lane 0..7
     constexpr int ncomp = HAS2 ? 4 : 2;
     const int64_t rows = (int64_t)d.N * d.T;
-    const int64_t row0 = (int64_t)blockIdx.x * BWD_ROWS_PER_BLOCK;
+    const int64_t row0 = (int64_t)chunk * rw;
+    int64_t rend = row0 + rw;
+    if (rend > rows) rend = rows;
     float s0[8], s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
-    if (rr < RPB) {
-        Chan c1, c2;
-        load_chan(c1, d.scale, d.shift, d.mean, d.invstd, cg * 8);
-        if (HAS2) load_chan(c2, d.scale2, d.shift2, d.mean2, d.invstd2, cg * 8);
-        int64_t rend = row0 + BWD_ROWS_PER_BLOCK;
-        if (rend > rows) rend = rows;
-        int n = (int)((row0 + rr) / d.T), t = (int)((row0 + rr) - (int64_t)n * d.T);
+    Chan c1, c2;
+    load_chan(c1, d.scale, d.shift, d.mean, d.invstd, cg * 8);
+    if (HAS2) load_chan(c2, d.scale2, d.shift2, d.mean2, d.invstd2, cg * 8);
+    int n = (int)((row0 + rr) / d.T), t = (int)((row0 + rr) - (int64_t)n * d.T);
 #pragma unroll 2
-        for (int64_t row = row0 + rr; row < rend; row += RPB, t += RPB) {
-            while (t >= d.T) { t -= d.T; ++n; }
-            BwdRow o;
-            bwd_row<F32, GF32, HAS2>(d, c1, c2, g1, g2, has_g2, n, t, cg, G, inv_keep, o);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                s0[j] += o.g[j];
-                s1[j] += o.g[j] * o.xh1[j];
-                if (HAS2) s2[j] += o.g[j] * o.xh2[j];
-            }
-        }
+    for (int64_t row = row0 + rr; row < rend; row += 8, t += 8) {
+        while (t >= d.T) { t -= d.T; ++n; }
+        BwdRow o;
+        bwd_row<F32, GF32, HAS2>(d, c1, c2, g1, g2, has_g2, n, t, cg, G, inv_keep, o);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            red[(rr * 3 + 0) * d.C + cg * 8 + j] = s0[j];
-            red[(rr * 3 + 1) * d.C + cg * 8 + j] = s1[j];
-            red[(rr * 3 + 2) * d.C + cg * 8 + j] = s2[j];
+            s0[j] += o.g[j];
+            s1[j] += o.g[j] * o.xh1[j];
+            if (HAS2) s2[j] += o.g[j] * o.xh2[j];
         }
     }
-    __syncthreads();
-    for (int c = tid; c < d.C; c += 256) {
-        float a = 0.f, b = 0.f, e = 0.f;
-        for (int k = 0; k < RPB; ++k) {
-            a += red[(k * 3 + 0) * d.C + c];
-            b += red[(k * 3 + 1) * d.C + c];
-            e += red[(k * 3 + 2) * d.C + c];
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s0[j] += __shfl_xor(s0[j], m, 64);
+            s1[j] += __shfl_xor(s1[j], m, 64);
+            if (HAS2) s2[j] += __shfl_xor(s2[j], m, 64);
         }
-        float* dst = partial + (int64_t)blockIdx.x * ncomp * d.C;
-        dst[c] = a; dst[d.C + c] = b;
-        if (ncomp == 4) { dst[2 * d.C + c] = a; dst[3 * d.C + c] = e; }
+    if (rr == 0) {
+        float* dst = partial + (int64_t)chunk * ncomp * d.C + cg * 8;
+        auto put = [&](float* q, const float* v) {
+            *reinterpret_cast<f32x4*>(q) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(q + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        };
+        put(dst, s0);
+        put(dst + d.C, s1);
+        if (ncomp == 4) { put(dst + 2 * d.C, s0); put(dst + 3 * d.C, s2); }
     }
 }
 
@@ -481,8 +493,10 @@ extern "C" int w2l_bn_act_fwd(const w2l_bnact_t* d, void* out_hi, void* out_lo, 
 }
 
 extern "C" int w2l_bn_bwd_blocks(int N, int T, int C) {
-    (void)C;
-    return (int)(((int64_t)N * T + BWD_ROWS_PER_BLOCK - 1) / BWD_ROWS_PER_BLOCK);
+    if (N <= 0 || T <= 0 || C < BWD_SLAB) return 0;
+    const int64_t rows = (int64_t)N * T;
+    const int rw = bwd_rows_per_wave(rows, C);
+    return (int)((rows + rw - 1) / rw);
 }
 
 #define W2L_DISPATCH_BWD2(KERNEL, H2, ...)                                                                 \
@@ -505,15 +519,15 @@ extern "C" int w2l_bn_act_bwd_reduce(const w2l_bnact_t* d, const w2l_gradsrc_t* 
     W2L_CHECK_ARG(!g2 || g2->f32 == g1->f32, "bn_act_bwd_reduce: gradient sources must share a dtype");
     W2L_CHECK_ARG(g1->rows >= g1->pad_l + d->T + g1->pad_r && (!g2 || g2->rows >= g2->pad_l + d->T + g2->pad_r),
                   "bn_act_bwd_reduce: gradient source has too few rows per utterance");
-    const int G = d->C / 8;
-    W2L_CHECK_ARG(G <= 256, "bn_act_bwd_reduce: C too large");
-    const int RPB = 256 / G;
-    const size_t lds = (size_t)RPB * 3 * d->C * sizeof(float);
-    const int blocks = w2l_bn_bwd_blocks(d->N, d->T, d->C);
+    W2L_CHECK_ARG(d->C % BWD_SLAB == 0, "bn_act_bwd_reduce: C=%d must be a multiple of %d", d->C, BWD_SLAB);
+    const int64_t rows = (int64_t)d->N * d->T;
+    const int rw = bwd_rows_per_wave(rows, d->C);
+    const int nchunks = w2l_bn_bwd_blocks(d->N, d->T, d->C);       // rows of `partial`
+    const int tasks = nchunks * (d->C / BWD_SLAB);
     const float inv_keep = 1.f / (1.f - d->drop_p);
     w2l_gradsrc_t g2v = g2 ? *g2 : *g1;
-    W2L_DISPATCH_BWD(bn_act_bwd_reduce_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, *d, *g1, g2v,
-                     g2 ? 1 : 0, partial, inv_keep);
+    W2L_DISPATCH_BWD(bn_act_bwd_reduce_kernel, dim3((tasks + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d, *g1, g2v,
+                     g2 ? 1 : 0, partial, inv_keep, rw, nchunks);
     W2L_CHECK_LAUNCH();
     return 0;
 }

@@ -51,8 +51,8 @@ __global__ void pack_weights_kernel(const float* w, int64_t s_co, int64_t s_ci, 
 // read p, g, m; write p, m, 2 x bf16 -- instead of torch's multi-pass foreach update plus a separate pack.
 // Update rule = torch.optim.SGD (dampening 0): g += wd*p; m = first ? g : mu*m + g; g = nesterov ? g + mu*m : m;
 // p -= lr*g.
-__global__ void sgd_pack_kernel(float* p, const float* g, float* m, int first, float lr, float mu, float wd,
-                                int nesterov, int Cout, int Cin, int Kw, bf16_raw* fwd_hi, bf16_raw* fwd_lo,
+__global__ void sgd_pack_kernel(float* p, float* g, float* m, int first, float lr, float mu, float wd,
+                                int nesterov, int zero_grad, int Cout, int Cin, int Kw, bf16_raw* fwd_hi, bf16_raw* fwd_lo,
                                 bf16_raw* dgr_hi, bf16_raw* dgr_lo) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -64,6 +64,7 @@ __global__ void sgd_pack_kernel(float* p, const float* g, float* m, int first, f
             const int64_t off = ((int64_t)kw * Cout + co) * Cin + ci;
             float pv = p[off];
             float gv = g[off] + wd * pv;
+            if (zero_grad) g[off] = 0.f;       // the buffer comes back as the next step's (split-K, atomically accumulated) dW
             float mv = first ? gv : mu * m[off] + gv;
             m[off] = mv;
             gv = nesterov ? gv + mu * mv : mv;
@@ -241,15 +242,15 @@ extern "C" int w2l_pack_weights(const float* w, int64_t s_co, int64_t s_ci, int6
     return 0;
 }
 
-extern "C" int w2l_sgd_pack(float* p, const float* g, float* m, int first_step, float lr, float momentum,
-                            float weight_decay, int nesterov, int Cout, int Cin, int Kw, void* w_fwd_hi, void* w_fwd_lo,
-                            void* w_dgr_hi, void* w_dgr_lo, void* stream) {
+extern "C" int w2l_sgd_pack(float* p, float* g, float* m, int first_step, float lr, float momentum,
+                            float weight_decay, int nesterov, int zero_grad, int Cout, int Cin, int Kw, void* w_fwd_hi,
+                            void* w_fwd_lo, void* w_dgr_hi, void* w_dgr_lo, void* stream) {
     W2L_CHECK_ARG(p && g && m, "sgd_pack: null pointer");
     W2L_CHECK_ARG(Cout > 0 && Cin > 0 && Kw > 0, "sgd_pack: bad sizes");
     W2L_CHECK_ARG(!(w_fwd_lo && !w_fwd_hi) && !(w_dgr_lo && !w_dgr_hi), "sgd_pack: lo without hi");
     dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, Kw), block(32, 8);
     hipLaunchKernelGGL(sgd_pack_kernel, grid, block, 0, (hipStream_t)stream, p, g, m, first_step, lr, momentum,
-                       weight_decay, nesterov, Cout, Cin, Kw, (bf16_raw*)w_fwd_hi, (bf16_raw*)w_fwd_lo,
+                       weight_decay, nesterov, zero_grad, Cout, Cin, Kw, (bf16_raw*)w_fwd_hi, (bf16_raw*)w_fwd_lo,
                        (bf16_raw*)w_dgr_hi, (bf16_raw*)w_dgr_lo);
     W2L_CHECK_LAUNCH();
     return 0;

@@ -294,6 +294,9 @@ _side_streams = {}                 # device index -> the stream weight gradients
 
 
 def _side_stream(dev) -> 'torch.cuda.Stream':
+    # a plain default-priority stream.  Measured and rejected: hipStreamCreateWithPriority (lowest or highest: 18.8 / 20.1
+    # instead of 14.3 ms per step) and hipExtStreamCreateWithCUMask with 7/8, 6/8 or 5/8 of the CUs (16.6-16.7 instead of
+    # 13.7 ms per step, round 2): any special queue makes the weight gradients crawl.
     st = _side_streams.get(dev.index)
     if st is None:
         st = torch.cuda.Stream(device=dev)
@@ -951,6 +954,21 @@ class StackEngine:
                                                    ptr(ws), ws_bytes, stream_ptr()), 'w2l_conv1d_wgrad_tune_ws')
         # with a workspace, split reductions end in plain stores by the last block of a tile: no zero fill, no atomics
         need_zero = bool(lib.w2l_wgrad_needs_zero_ws(N, pk.cinp, pk.coutp, Tout, kw, ws_bytes)) or self.precise
+        # optim.FusedSGD leaves last step's gradient buffer zero-filled on the parameter: take it as this step's dW (only
+        # when zero_grad(set_to_none=True) dropped p.grad -- otherwise autograd is about to ADD into that very tensor)
+        recycled = w.__dict__.pop('_w2l_dw_zeroed', None)
+        if (recycled is not None and need_zero and w.grad is None and recycled.device == dev and recycled.is_contiguous()
+                and tuple(recycled.shape) == (kw, pk.coutp, pk.cinp)):
+            if fork is not None:
+                ev = torch.cuda.Event()
+                ev.record(fork[0])
+                fork[1].wait_event(ev)
+                self._held.append(recycled)
+                with torch.cuda.stream(fork[1]):
+                    return self._wgrad_launch(conv, pk, recycled, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride,
+                                              x_rows_total, dy_bstride, row_off, direct, ws)
+            return self._wgrad_launch(conv, pk, recycled, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total,
+                                      dy_bstride, row_off, direct, ws)
         if fork is not None:
             # allocated on the main stream (the caching allocator then owns it there), zero-filled on the side stream:
             # the fill of a split-K gradient is as far off the critical path as the kernel that accumulates into it

@@ -27,6 +27,7 @@ def _is_tap_major(t: torch.Tensor) -> bool:
 
 
 class FusedSGD(torch.optim.SGD):
+    recycle_grads = True      # zero the consumed conv-weight gradients in the update kernel and hand them back as the next dW
     overlap = False           # opt-in (trainer.Trainer and bench.py set it): whoever enables it must join() before
                               # reading parameters outside the step engine (checkpoints, .cpu() copies, ...)
 
@@ -137,9 +138,14 @@ class FusedSGD(torch.optim.SGD):
             dgr_hi = torch.empty(kw, cin, cout, dtype=torch.bfloat16, device=dev)
             fwd_lo = torch.empty_like(fwd_hi) if precise else None
             dgr_lo = torch.empty_like(dgr_hi) if precise else None
+        # the gradient buffer is handed back to the step engine zero-filled (engine._wgrad_now takes it as the next dW when
+        # zero_grad(set_to_none=True) has dropped p.grad): no fill launch for the split-K weight gradients of the next step
+        recycle = self.recycle_grads and not precise
         check(lib.w2l_sgd_pack(ptr(p), ptr(g), ptr(buf), int(first), float(lr), float(mu), float(wd), int(nesterov),
-                               cout, cin, kw, ptr(fwd_hi), ptr(fwd_lo), ptr(dgr_hi), ptr(dgr_lo), stream_ptr()),
+                               int(recycle), cout, cin, kw, ptr(fwd_hi), ptr(fwd_lo), ptr(dgr_hi), ptr(dgr_lo), stream_ptr()),
               'w2l_sgd_pack')
+        if recycle:
+            p._w2l_dw_zeroed = g.permute(2, 0, 1)                    # the dense [Kw, Cout, Cin] storage of g
         torch.autograd.graph.increment_version(p)                    # p changed through its raw pointer
         cache.clear()
         pk = E._PackedW(p._version, fwd_hi, fwd_lo, dgr_hi, dgr_lo, cin, cout, p.data_ptr())

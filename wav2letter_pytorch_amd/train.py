@@ -18,8 +18,10 @@ import torch
 from torch.utils.data.distributed import DistributedSampler
 
 from . import Jasper, Wav2Letter
+from .config import _yaml_load, load_config, to_cfg
 from .data import label_sets
 from .data.data_loader import BatchAudioDataLoader, SpectrogramDataset
+from .defaults import root_config
 from .launch import spawn_ranks, under_launcher
 from .trainer import Trainer
 
