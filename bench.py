@@ -26,16 +26,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
+FP8_DENSE_PEAK_TFLOPS = 5000.0       # ~5 PFLOP/s dense fp8 (block-scaled MFMA, K = 128)
 
 
-def w2l_cfg(mid_layers, dropout=True):
+def w2l_cfg(mid_layers, dropout=True, precision='bf16'):
     from wav2letter_pytorch_amd.defaults import wav2letter_model
-    return wav2letter_model(mid_layers, dropout=dropout)
+    return wav2letter_model(mid_layers, dropout=dropout, precision=precision)
 
 
-def jasper10x5_cfg():
+def jasper10x5_cfg(precision='bf16'):
     from wav2letter_pytorch_amd.defaults import jasper10x5_model
-    return jasper10x5_model()
+    return jasper10x5_model(precision=precision)
 
 
 def cpu_baseline(budget_s=20.0):
@@ -83,6 +84,8 @@ def main():
     ap.add_argument('--mid-layers', type=int, default=20)
     ap.add_argument('--model', default='wav2letter', choices=['wav2letter', 'jasper10x5'],
                     help='wav2letter = the headline workload; jasper10x5 = BASELINE config 4 (secondary)')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp8'],
+                    help='fp8 = forward convolutions on e4m3 operands (BASELINE config 5); gradients stay bf16')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the step as a captured hipGraph (graph.GraphedTrainStep; Wav2Letter)')
@@ -117,10 +120,10 @@ def main():
 
     torch.manual_seed(0)
     if args.model == 'jasper10x5':
-        model = Jasper(jasper10x5_cfg()).to(dev).train()
+        model = Jasper(jasper10x5_cfg(args.dtype)).to(dev).train()
         model.check_nan = False              # the reference's per-step NaN assert is a host sync
     else:
-        model = Wav2Letter(w2l_cfg(args.mid_layers)).to(dev).train()
+        model = Wav2Letter(w2l_cfg(args.mid_layers, precision=args.dtype)).to(dev).train()
     broadcast_parameters(model)
     if world > 1 or args.force_dp:
         model.grad_reducer = GradReducer(force=args.force_dp)
@@ -272,6 +275,14 @@ def main():
             if 'traffic_bytes_per_launch' in k:
                 roof['traffic'] = round(k['traffic_bytes_per_launch'])
                 roof['traffic_source'] = 'profiles/r01_pmc_bench.json (rocprofv3 --pmc, mean over the step\'s launches)'
+        if 'conv_igemm_fp8_kernel' in agg:
+            # fp8 mode: the forward convolutions of the units ran on e4m3 operands; they are priced against the fp8 peak, the
+            # bf16 launches left in `roof` (first layer, classifier, data gradients) against the bf16 peak
+            fl8, tt8, cnt8 = agg['conv_igemm_fp8_kernel']
+            roof['fp8_kernel'] = {'kernel': 'conv_igemm_kernel<..., F8>', 'achieved': round(fl8 / tt8 / 1e12, 1),
+                                  'peak': FP8_DENSE_PEAK_TFLOPS, 'frac': round(fl8 / tt8 / 1e12 / FP8_DENSE_PEAK_TFLOPS, 4),
+                                  'avg_launch_ms': round(tt8 / cnt8 * 1e3, 4), 'launches_per_step': cnt8 // 3,
+                                  'alg_gflop_per_launch': round(fl8 / cnt8 / 1e9, 2)}
         if 'conv_wgrad_kernel' in agg:
             fl2, tt2, cnt2 = agg['conv_wgrad_kernel']
             roof['wgrad_kernel'] = {'achieved': round(fl2 / tt2 / 1e12, 1), 'frac': round(fl2 / tt2 / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4),
@@ -288,11 +299,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.model == 'wav2letter':
             cpu = cpu_baseline()
         line = {
-            'metric': ('audio-frames/sec/GPU (fwd+bwd+CTC), Wav2Letter 64-mel x 1000-frame bf16' if args.model == 'wav2letter'
-                       else 'audio-frames/sec/GPU (fwd+bwd+CTC), Jasper 10x5 bf16 (secondary workload)'),
+            'metric': (f'audio-frames/sec/GPU (fwd+bwd+CTC), Wav2Letter 64-mel x 1000-frame {args.dtype}' if args.model == 'wav2letter'
+                       else f'audio-frames/sec/GPU (fwd+bwd+CTC), Jasper 10x5 {args.dtype} (secondary workload)'),
             'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16', 'data': 'synthetic',
+            'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': ('Jasper 10x5 (13 dense blocks, repeat 5, 322 M params), ' if args.model == 'jasper10x5' else '')
                                    + f'Wav2Letter mid_layers={args.mid_layers} (configuration/model/wav2letter.yaml table), ' * (args.model == 'wav2letter')
                                    +

@@ -106,6 +106,20 @@ int w2l_conv1d_igemm_tune_ws(const void* xp, int64_t x_bstride, int64_t x_rows_t
                              int dil, int reps, void* splitk_ws, int64_t splitk_ws_bytes, void* stream);
 int64_t w2l_conv_splitk_workspace_bytes(int N, int Cout, int Tout);
 
+/* nn.Conv1d forward (wav2letter.py:35-36,42 / jasper.py:96-105) on OCP e4m3 operands -- BASELINE config 5 "fp8 MFMA":
+ *   y[n][t][co] = descale * sum_{kw,ci} wq[kw][co][ci] * xq[n][t + kw*dil][ci] (+ bias[co]),
+ * xq / wq one byte per element, same layouts as the bf16 entry point (x_bstride in elements), Cin a multiple of 128,
+ * stride 1; the products run on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the bf16 MFMA rate), fp32
+ * accumulate; descale = 1 / (activation scale * weight scale) undoes the producers' per-tensor scaling.  Output bf16 or
+ * fp32, optional BatchNorm partial statistics as w2l_conv1d_igemm.  The _tune form measures the block shapes once per
+ * shape (synchronising; warm-up only). */
+int w2l_conv1d_igemm_fp8(const void* xq, int64_t x_bstride, int64_t x_rows_total, const void* wq, void* y, int y_f32,
+                         float descale, const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout, int Kw,
+                         int dil, void* stream);
+int w2l_conv1d_igemm_fp8_tune(const void* xq, int64_t x_bstride, int64_t x_rows_total, const void* wq, void* y, int y_f32,
+                              const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout, int Kw, int dil,
+                              int reps, void* stream);
+
 /* tuning hook: force configuration idx (>= 0) for every later w2l_conv1d_igemm call MADE BY THE CALLING THREAD (the
  * setting is thread-local: launches from other threads are never affected); -1 = automatic.
  * idx = block shape (0..20) + 21 * K-loop structure (0: barrier at the top of a step, 1: barrier mid-step);
@@ -204,6 +218,13 @@ typedef struct {
  * [N][pad_l+T+pad_r+tail][C] for the NEXT conv: halo rows are reflected copies (pad_mode 1) or zeros. */
 int w2l_bn_act_fwd(const w2l_bnact_t* d, void* out_hi, void* out_lo, int out_rows, int pad_l, int pad_r,
                    int pad_mode, void* stream);
+/* the same with a second copy of the padded activation as OCP e4m3 bytes, a * q_scale (saturating at +-448): the
+ * forward operand of the next nn.Conv1d in fp8 mode (BASELINE config 5).  out_q == NULL: plain w2l_bn_act_fwd. */
+int w2l_bn_act_fwd_q(const w2l_bnact_t* d, void* out_hi, void* out_lo, void* out_q, float q_scale, int out_rows,
+                     int pad_l, int pad_r, int pad_mode, void* stream);
+/* dst[i] = e4m3(src[i] * scale), src bf16 (src_f32 = 0) or fp32, n a multiple of 8: per-tensor quantisation of the conv
+ * weights (and of the spectrogram) for w2l_conv1d_igemm_fp8. */
+int w2l_quantize_e4m3(const void* src, int src_f32, int64_t n, float scale, void* dst, void* stream);
 
 typedef struct {
     const void* dxp;        /* gradient wrt the padded activation buffer [N][rows][C], bf16 or fp32; the first

@@ -1,0 +1,128 @@
+"""fp8 mode (BASELINE config 5, "fp8 MFMA"): the forward convolutions on OCP e4m3 operands through
+v_mfma_scale_f32_16x16x128_f8f6f4 (csrc/conv_igemm.hip, F8 kernels), per-tensor scaling.
+
+Kernel level: the device's quantisation is bit-identical to torch's float8_e4m3fn cast, and the convolution of the
+quantised operands equals the fp32 convolution of the SAME (dequantised) values -- the MFMA path itself is exact up to
+fp32 accumulation order.  Model level: the step in fp8 mode against the fp32 oracle at the documented fp8 bounds (e4m3
+keeps 4 significant bits: a forward layer is good to a few percent, where bf16 mode is good to a few tenths of one)."""
+import ctypes as C_
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_helpers import build_w2l, scale_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def L():
+    from wav2letter_pytorch_amd import _lib
+    return _lib
+
+
+def _quant(L, t, scale):
+    q = torch.empty(t.shape, dtype=torch.uint8, device='cuda')
+    L.check(L.lib.w2l_quantize_e4m3(L.ptr(t), int(t.dtype == torch.float32), t.numel(), scale, L.ptr(q), L.stream_ptr()))
+    return q
+
+
+def test_quantize_e4m3_is_torch_float8_e4m3fn(L):
+    """round-to-nearest-even onto the OCP e4m3 grid (not MI300's fnuz), saturating at +-448, from fp32 and from bf16"""
+    g = torch.Generator().manual_seed(1)
+    v = torch.cat([torch.randn(4096, generator=g) * s for s in (1e-3, 0.05, 1.0, 30.0, 400.0)]
+                  + [torch.tensor([0.0, -0.0, 448.0, -448.0, 460.0, 1e4, -1e4, 2.0 ** -9, 2.0 ** -10, 0.017, 239.9, 240.1])])
+    v = v[: v.numel() // 8 * 8].contiguous()
+    for src in (v, v.to(torch.bfloat16)):
+        for scale in (1.0, 16.0):
+            got = _quant(L, src.cuda(), scale).cpu()
+            want = (src.float() * scale).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+            same = got == want
+            # +0 / -0 of a product that underflowed may differ in sign only
+            assert bool((same | ((got & 0x7F) == 0) & ((want & 0x7F) == 0)).all()), (got[~same][:8], want[~same][:8])
+
+
+@pytest.mark.parametrize('N,T,cin,cout,kw,dil,stats', [(2, 300, 128, 128, 11, 1, True), (3, 200, 256, 192, 13, 1, True),
+                                                        (2, 260, 384, 256, 29, 2, False), (1, 129, 128, 64, 1, 1, True),
+                                                        (4, 500, 896, 896, 29, 2, True)])
+def test_conv1d_igemm_fp8_matches_dequantised_fp32_conv(L, N, T, cin, cout, kw, dil, stats):
+    g = torch.Generator().manual_seed(N * 7 + kw)
+    halo = (kw - 1) * dil
+    rows = T + halo
+    x = (torch.randn(N, rows, cin, generator=g).clamp(min=0) * 3).to(torch.bfloat16)         # post-clamp-like activations
+    w = (torch.randn(kw, cout, cin, generator=g) * 0.02)
+    sx, sw = 16.0, 2.0 ** int(np.floor(np.log2(448.0 / float(w.abs().max()))))
+    xq = _quant(L, x.cuda(), sx)
+    wq = _quant(L, w.cuda(), sw)
+    bias = torch.randn(cout, generator=g)
+    y = torch.empty(N, T, cout, dtype=torch.float32, device='cuda')
+    st = torch.zeros(L.lib.w2l_conv_stat_tiles(N, T), 2, cout, device='cuda') if stats else None
+    b_d = bias.cuda()
+    L.check(L.lib.w2l_conv1d_igemm_fp8_tune(L.ptr(xq), rows * cin, N * rows, L.ptr(wq), L.ptr(y), 1, L.ptr(b_d), L.ptr(st), N, cin,
+                                            cout, T, kw, dil, 1, L.stream_ptr()))
+    L.check(L.lib.w2l_conv1d_igemm_fp8(L.ptr(xq), rows * cin, N * rows, L.ptr(wq), L.ptr(y), 1, 1.0 / (sx * sw), L.ptr(b_d),
+                                       L.ptr(st), N, cin, cout, T, kw, dil, L.stream_ptr()))
+    xd = xq.cpu().view(torch.float8_e4m3fn).float() / sx                                       # what the kernel multiplied
+    wd = wq.cpu().view(torch.float8_e4m3fn).float() / sw
+    ref = F.conv1d(xd.transpose(1, 2).double(), wd.permute(1, 2, 0).double(), bias.double(), dilation=dil).transpose(1, 2)
+    got = y.cpu().double()
+    assert got.shape == ref.shape
+    assert scale_err(got.numpy(), ref.numpy()) < 2e-5
+    if stats:
+        s = st.cpu().double().sum(0)
+        assert scale_err(s[0].numpy(), ref.sum((0, 1)).numpy()) < 1e-4
+        assert scale_err(s[1].numpy(), (ref ** 2).sum((0, 1)).numpy()) < 1e-4
+    # and the quantisation error itself against the unquantised operands: a few percent of the output scale
+    full = F.conv1d(x.float().transpose(1, 2), w.permute(1, 2, 0), bias, dilation=dil).transpose(1, 2)
+    assert scale_err(got.float().numpy(), full.numpy()) < 6e-2
+
+
+def test_fp8_rejects_unsupported_shapes(L):
+    x = torch.zeros(1, 64, 192, dtype=torch.uint8, device='cuda')
+    w = torch.zeros(1, 64, 192, dtype=torch.uint8, device='cuda')
+    y = torch.empty(1, 64, 64, device='cuda')
+    rc = L.lib.w2l_conv1d_igemm_fp8(L.ptr(x), 64 * 192, 64, L.ptr(w), L.ptr(y), 1, 1.0, None, None, 1, 192, 64, 64, 1, 1, L.stream_ptr())
+    assert rc != 0 and b'multiple of 128' in L.lib.w2l_last_error()
+
+
+def _fp8_step(layers, N, T, seed, dropout=False):
+    from oracle import w2l_oracle as O
+    from gpu_helpers import compare_step
+    sd = O.init_wav2letter_state(layers, seed=seed)
+    model = build_w2l(layers, sd, 'fp8', dropout=dropout).train()
+    x, il, tg, tl = O.synthetic_batch(N, T, seed=seed + 1, s_lo=max(2, T // 12), s_hi=max(3, T // 6))
+    errs, stats, out, out_lens, ref = compare_step(model, layers, sd, x, il, tg, tl, 'bf16', drop=dropout, tie=2.0, max_frac=0.3)
+    return model, errs, stats
+
+
+def test_w2l_small_stack_fp8_vs_oracle():
+    """4 layers (stride-2 first layer in bf16: 64 input channels; the others 128/256/384 wide, k11-k29, dilation 2) in
+    fp8 mode vs the fp32 oracle: e4m3 operands carry 3 mantissa bits, so one forward layer is good to ~3 % of scale"""
+    layers = [(128, 11, 2, 1, 0.0), (256, 13, 1, 1, 0.0), (384, 29, 1, 2, 0.0), (128, 1, 1, 1, 0.0)]
+    model, errs, stats = _fp8_step(layers, N=3, T=300, seed=3)
+    eng = model.engine()
+    assert eng.fp8 and not eng.precise
+    worst = max((v, k) for k, v in errs.items() if k not in ('log_probs', 'loss'))
+    print(f'fp8 small stack: log-probs {errs["log_probs"]:.3f} loss {errs["loss"]:.4f} worst grad {worst[0]:.3f} ({worst[1]}) '
+          f'stats {max(stats.values()):.3f}')
+    assert errs['log_probs'] < 1.5e-1 and errs['loss'] < 5e-2
+    assert worst[0] < 3e-1
+    assert max(stats.values()) < 1e-1
+    w = model.conv1ds.conv1d_1.conv1.weight
+    st = w._w2l_fp8
+    assert st['q'].dtype == torch.uint8 and st['scale'] >= 1 and float(w.detach().abs().max()) * st['scale'] <= 448
+
+
+def test_w2l_full_table_fp8_properties_and_loss():
+    """the 21-layer table in fp8 mode at N=4 x T=1000, dropout on: finite / normalised outputs, every gradient finite and
+    non-zero, and the loss close to the oracle's with the device's masks and gates replayed"""
+    from oracle import w2l_oracle as O
+    layers = list(O.W2L_LAYERS)
+    model, errs, stats = _fp8_step(layers, N=4, T=1000, seed=0, dropout=True)
+    print(f'fp8 full table: log-probs {errs["log_probs"]:.3f} loss {errs["loss"]:.4f}')
+    assert errs['loss'] < 1e-1
+    assert errs['log_probs'] < 5e-1
+    for k, p in model.named_parameters():
+        assert torch.isfinite(p.grad).all(), k

@@ -133,11 +133,25 @@ __device__ __forceinline__ bool act_pass(float z, int act) {
     return true;
 }
 
+// 8 floats -> 8 OCP e4m3 bytes (round to nearest even, saturating at +-448), v * scale
+__device__ __forceinline__ uint2 quant8_e4m3(const float v[8], float scale) {
+    float q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = fminf(fmaxf(v[j] * scale, -448.f), 448.f);
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], hi, true);
+    return make_uint2((unsigned)lo, (unsigned)hi);
+}
+
 // ---------------------------------------------------------------- forward
+// out_q (optional): the same padded activation once more as e4m3 bytes, a * q_scale -- the operand of the next
+// convolution's forward pass in fp8 mode (w2l_conv1d_igemm_fp8); the bf16 copy stays the weight gradient's operand
 template <bool F32, bool HAS2>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(w2l_bnact_t d, bf16_raw* out_hi, bf16_raw* out_lo, int R,
                                                           int pad_l, int pad_r, int pad_mode, uint32_t thresh,
-                                                          float inv_keep) {
+                                                          float inv_keep, uint8_t* out_q, float q_scale) {
     const int G = d.C >> 3;
     const unsigned total = (unsigned)d.N * R * G;            // < 2^31 (checked by the launcher): 32-bit index math
     for (unsigned it = blockIdx.x * 256u + threadIdx.x; it < total; it += gridDim.x * 256u) {
@@ -160,6 +174,17 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(w2l_bnact_t d, bf16_raw
             for (int j = 0; j < 8; ++j) a[j] = activate(z[j], d.act);
         }
         store8_split(out_hi, out_lo, (int64_t)orow * d.C + cg * 8, a);
+        if (out_q) *reinterpret_cast<uint2*>(out_q + (int64_t)orow * d.C + cg * 8) = quant8_e4m3(a, q_scale);
+    }
+}
+
+__global__ __launch_bounds__(256) void quantize_e4m3_kernel(const void* src, int src_f32, int64_t ngroups, float scale,
+                                                             uint8_t* dst) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ngroups; i += (int64_t)gridDim.x * 256) {
+        float v[8];
+        if (src_f32) load8<true>(src, i * 8, v);
+        else load8<false>(src, i * 8, v);
+        *reinterpret_cast<uint2*>(dst + i * 8) = quant8_e4m3(v, scale);
     }
 }
 
@@ -474,7 +499,21 @@ extern "C" int w2l_bn_finalize(const float* partial, int ntiles, int C, int64_t 
 
 extern "C" int w2l_bn_act_fwd(const w2l_bnact_t* d, void* out_hi, void* out_lo, int out_rows, int pad_l, int pad_r,
                               int pad_mode, void* stream) {
+    return w2l_bn_act_fwd_q(d, out_hi, out_lo, nullptr, 1.f, out_rows, pad_l, pad_r, pad_mode, stream);
+}
+
+extern "C" int w2l_quantize_e4m3(const void* src, int src_f32, int64_t n, float scale, void* dst, void* stream) {
+    W2L_CHECK_ARG(src && dst && n > 0 && n % 8 == 0 && scale > 0.f, "quantize_e4m3: bad arguments (n must be a multiple of 8)");
+    hipLaunchKernelGGL(quantize_e4m3_kernel, dim3(elementwise_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream, src, src_f32,
+                       n / 8, scale, (uint8_t*)dst);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int w2l_bn_act_fwd_q(const w2l_bnact_t* d, void* out_hi, void* out_lo, void* out_q, float q_scale, int out_rows,
+                                int pad_l, int pad_r, int pad_mode, void* stream) {
     if (int e = check_desc(d, "bn_act_fwd")) return e;
+    W2L_CHECK_ARG(!out_q || q_scale > 0.f, "bn_act_fwd: the e4m3 copy needs a positive scale");
     W2L_CHECK_ARG(out_hi && out_rows >= pad_l + d->T + pad_r && pad_l >= 0 && pad_r >= 0, "bn_act_fwd: bad output geometry");
     W2L_CHECK_ARG(pad_mode != 1 || (pad_l < d->T && pad_r < d->T), "bn_act_fwd: reflect pad (%d,%d) needs pad < T=%d",
                   pad_l, pad_r, d->T);
@@ -484,7 +523,8 @@ extern "C" int w2l_bn_act_fwd(const w2l_bnact_t* d, void* out_hi, void* out_lo, 
     const int blocks = elementwise_blocks((int64_t)d->N * out_rows * (d->C / 8));
 #define W2L_FWD(F, H)                                                                                        \
     hipLaunchKernelGGL((bn_act_fwd_kernel<F, H>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d,          \
-                       (bf16_raw*)out_hi, (bf16_raw*)out_lo, out_rows, pad_l, pad_r, pad_mode, thresh, inv_keep)
+                       (bf16_raw*)out_hi, (bf16_raw*)out_lo, out_rows, pad_l, pad_r, pad_mode, thresh, inv_keep,    \
+                       (uint8_t*)out_q, q_scale)
     if (d->y_f32) { if (d->y2) W2L_FWD(true, true); else W2L_FWD(true, false); }
     else { if (d->y2) W2L_FWD(false, true); else W2L_FWD(false, false); }
 #undef W2L_FWD

@@ -41,7 +41,22 @@ struct IgemmParams {
     int splits;
     float* slabs;             // [tiles][splits][BM*BN]
     unsigned* tickets;        // [tiles], zero between launches
+    float descale;            // F8 kernels: y = acc * descale (+ bias), descale = 1 / (activation scale * weight scale)
 };
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+// one 16x16x128 MFMA on OCP e4m3 operands (cbsz = blgp = 0) with unit E8M0 block scales (127 = 2^0): per-tensor scaling
+// is applied by the producer kernels and undone in the epilogue.  The 32 operand bytes of a lane are two ds_read_b128
+// chunks; A and B take the same 32 channels of a row per lane group, so the products pair up whatever order the
+// instruction walks its k range in.
+__device__ __forceinline__ f32x4 mfma_e4m3_k128(bf16x8 a_lo, bf16x8 a_hi, bf16x8 b_lo, bf16x8 b_hi, f32x4 c) {
+    const v4i al = __builtin_bit_cast(v4i, a_lo), ah = __builtin_bit_cast(v4i, a_hi);
+    const v4i bl = __builtin_bit_cast(v4i, b_lo), bh = __builtin_bit_cast(v4i, b_hi);
+    const v8i av = __builtin_shufflevector(al, ah, 0, 1, 2, 3, 4, 5, 6, 7);
+    const v8i bv = __builtin_shufflevector(bl, bh, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -50,8 +65,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base
 
 // MW x NW waves, each owning MS x NS MFMA tiles of 16x16: block tile BM = 16*MW*MS (co) x BN = 16*NW*NS (t)
 // S = conv stride (compile time: the fragment reads then use immediate LDS offsets)
-template <int MW, int NW, int MS, int NS, int S, int PIPE>
+// F8: operands are OCP e4m3 bytes (x [.][rows][Cin], w [Kw][Cout][Cin], one byte per element): a 128-byte LDS row is 128
+// channels, a K step is one tap of a 128-channel chunk, and its MS x NS MFMAs are v_mfma_scale_f32_16x16x128_f8f6f4 (twice
+// the bf16 rate); LDS-DMA, swizzle, window reuse, split-K and the epilogue are the bf16 kernel's.  PIPE = 0 only.
+template <int MW, int NW, int MS, int NS, int S, int PIPE, bool F8 = false>
 __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams p) {
+    static_assert(!(F8 && PIPE != 0), "the e4m3 kernel is built for K-loop structure 0 only");
+    constexpr int ESZ = F8 ? 1 : 2;                // bytes per operand element
+    constexpr int BKE = ROWB / ESZ;                // channels per K chunk (one 128-byte LDS row)
     constexpr int BM = 16 * MW * MS, BN = 16 * NW * NS, NWAVES = MW * NW, NT = 64 * NWAVES;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
@@ -95,9 +116,9 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
     for (int i = 0; i < W_PER_WAVE; ++i) {
         int co = m0 + (wave + i * NWAVES) * 8 + srow;
         co = co < p.Cout ? co : p.Cout - 1;
-        w_voff[i] = ((unsigned)co * (unsigned)Cin + (unsigned)gchunk * 8u) * 2u;
+        w_voff[i] = (unsigned)co * (unsigned)Cin * (unsigned)ESZ + (unsigned)gchunk * 16u;
     }
-    const int64_t w_tap_bytes = (int64_t)p.Cout * Cin * 2;
+    const int64_t w_tap_bytes = (int64_t)p.Cout * Cin * ESZ;
     auto stage_w = [&](char* dst, int kw, int c) {
         const char* slab = reinterpret_cast<const char*>(p.w) + kw * w_tap_bytes + c * (BK * 2);   // wave-uniform
 #pragma unroll
@@ -111,7 +132,7 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
         for (int grp = wave; grp < ngrp; grp += NWAVES) {
             int64_t r = xrow0 + grp * 8 + srow;
             r = r < p.x_max_row ? r : p.x_max_row;
-            const bf16_raw* src = p.x + r * Cin + c * BK + gchunk * 8;
+            const char* src = reinterpret_cast<const char*>(p.x) + (r * Cin + (int64_t)c * BKE) * ESZ + gchunk * 16;
             glds16(src, dst + grp * 1024);
         }
     };
@@ -122,7 +143,7 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
 #pragma unroll
         for (int j = 0; j < NS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nchunks = Cin / BK;
+    const int nchunks = Cin / BKE;
     // this block's share of the nchunks * Kw (chunk-major) steps; a range may start in the middle of a chunk
     const int total_steps = nchunks * Kw;
     const int s_begin = p.splits > 1 ? (int)(((int64_t)total_steps * split) / p.splits) : 0;
@@ -132,8 +153,12 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
 
     // per-lane fragment offsets (constant over the whole K loop)
     const int fr = lane & 15, fq = lane >> 4;
-    const int a_lane0 = (wm * MS * 16 + fr) * ROWB + (((fq) ^ (fr & 7)) << 4);        // k-substep 0: chunk fq
-    const int a_lane1 = (wm * MS * 16 + fr) * ROWB + (((4 + fq) ^ (fr & 7)) << 4);    // k-substep 1: chunk 4+fq
+    // bf16: k-substep 0 reads 16-byte chunk fq of the row, k-substep 1 chunk 4+fq.  e4m3: the lane group's 32 channels
+    // are chunks 2fq and 2fq+1, both operands of the one MFMA of the step.
+    constexpr int CH1_XOR = F8 ? 16 : 64;          // byte distance (under the XOR swizzle) between the two chunks of a lane
+    const int ch0 = F8 ? 2 * fq : fq;
+    const int a_lane0 = (wm * MS * 16 + fr) * ROWB + ((ch0 ^ (fr & 7)) << 4);
+    const int a_lane1 = a_lane0 ^ CH1_XOR;
     const int b_row0 = (wn * NS * 16 + fr) * s;      // tile rows ni*16*s further down share (row & 7): NS reads per base
 
     // Two K-loop structures are built for every block shape; which one is faster depends on the shape and the
@@ -159,10 +184,10 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
             const char* A0 = wb + a_lane0;
             const char* A1 = wb + a_lane1;
             const int tsh = b_row0 + kw * d;             // LDS row of this lane's first B tile for this tap
-            const int sw0 = ((fq ^ (tsh & 7)) << 4);
+            const int sw0 = ((ch0 ^ (tsh & 7)) << 4);
             const char* Bb = xb + (tsh << 7);
             const char* B0 = Bb + sw0;
-            const char* B1 = Bb + (sw0 ^ 64);            // chunk 4+fq == (chunk fq) ^ 4
+            const char* B1 = Bb + (sw0 ^ CH1_XOR);       // bf16: chunk 4+fq == (chunk fq) ^ 4; e4m3: chunk 2fq+1
             // both k-substeps' fragments are requested up front (16 ds_read_b128 in flight); the second half lands
             // while the first half's MFMAs run.  sched_barrier pins that order against the register-pressure scheduler.
             bf16x8 a0[MS], b0[NS], a1[MS], b1[NS];
@@ -174,24 +199,32 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
             for (int mi = 0; mi < MS; ++mi) a1[mi] = *reinterpret_cast<const bf16x8*>(A1 + mi * 16 * ROWB);
     #pragma unroll
             for (int ni = 0; ni < NS; ++ni) b1[ni] = *reinterpret_cast<const bf16x8*>(B1 + ni * 16 * S * ROWB);
+            if constexpr (F8) {
     #pragma unroll
-            for (int mi = 0; mi < MS; ++mi)
+                for (int mi = 0; mi < MS; ++mi)
     #pragma unroll
-                for (int ni = 0; ni < NS; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < NS; ++ni)
+                        acc[mi][ni] = mfma_e4m3_k128(a0[mi], a1[mi], b0[ni], b1[ni], acc[mi][ni]);
+            } else {
     #pragma unroll
-            for (int mi = 0; mi < MS; ++mi)
+                for (int mi = 0; mi < MS; ++mi)
     #pragma unroll
-                for (int ni = 0; ni < NS; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
-            // schedule: ks0 fragment reads, then ks1 reads slotted one per MFMA into the ks0 MFMAs, then the rest
-            __builtin_amdgcn_sched_group_barrier(0x100, MS + NS, 0);
+                    for (int ni = 0; ni < NS; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
     #pragma unroll
-            for (int i = 0; i < MS + NS; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                for (int mi = 0; mi < MS; ++mi)
+    #pragma unroll
+                    for (int ni = 0; ni < NS; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
+                // schedule: ks0 fragment reads, then ks1 reads slotted one per MFMA into the ks0 MFMAs, then the rest
+                __builtin_amdgcn_sched_group_barrier(0x100, MS + NS, 0);
+    #pragma unroll
+                for (int i = 0; i < MS + NS; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * MS * NS - (MS + NS), 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MS * NS - (MS + NS), 0);
             kw = kw_n;
             c = c_n;
         }
@@ -203,8 +236,8 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
             const char* xb = (cc & 1) ? xbuf1 : xbuf0;
             const char* A = wb + (ks ? a_lane1 : a_lane0);
             const int tsh = b_row0 + kk * d;             // LDS row of this lane's first B tile for this tap
-            const int sw0 = ((fq ^ (tsh & 7)) << 4);
-            const char* B = xb + (tsh << 7) + (ks ? (sw0 ^ 64) : sw0);      // chunk 4+fq == (chunk fq) ^ 4
+            const int sw0 = ((ch0 ^ (tsh & 7)) << 4);
+            const char* B = xb + (tsh << 7) + (ks ? (sw0 ^ CH1_XOR) : sw0);      // chunk 4+fq == (chunk fq) ^ 4
     #pragma unroll
             for (int mi = 0; mi < MS; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(A + mi * 16 * ROWB);
     #pragma unroll
@@ -334,7 +367,7 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
         for (int ni = 0; ni < NS; ++ni) {
             const int t = t0 + (wn * NS + ni) * 16 + fr;
             const bool ok = co_ok && t < Tout;
-            f32x4 v = acc[mi][ni] + bias4;
+            f32x4 v = F8 ? acc[mi][ni] * p.descale + bias4 : acc[mi][ni] + bias4;
             const int64_t off = ((int64_t)n * Tout + t) * Cout + co;
             if (ok) {
                 if (p.y_f32) {
@@ -432,6 +465,19 @@ int launch_cfg1(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t strea
 template <int MW, int NW, int MS, int NS>
 int launch_cfg(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream, int pipe) {
     return pipe ? launch_cfg1<MW, NW, MS, NS, 1>(p, tiles_m, lds, stream) : launch_cfg1<MW, NW, MS, NS, 0>(p, tiles_m, lds, stream);
+}
+
+// e4m3 launches: K-loop structure 0, stride 1, a subset of the block shapes (indices into kCfgs)
+constexpr int kF8Cfgs[] = {2, 5, 12, 14, 16};
+constexpr int kNumF8Cfgs = sizeof(kF8Cfgs) / sizeof(kF8Cfgs[0]);
+
+template <int MW, int NW, int MS, int NS>
+int launch_f8(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream) {
+    auto kern = conv_igemm_kernel<MW, NW, MS, NS, 1, 0, true>;
+    W2L_CHECK_HIP(w2l_allow_big_lds((const void*)kern));
+    hipLaunchKernelGGL(kern, dim3(tiles_m * p.ncols), dim3(64 * MW * NW), lds, stream, p);
+    W2L_CHECK_LAUNCH();
+    return 0;
 }
 
 }  // namespace
@@ -544,6 +590,7 @@ extern "C" int w2l_conv1d_igemm_ws(const void* xp, int64_t x_bstride, int64_t x_
     p.x_max_row = x_rows_total - 1;
     p.N = N; p.Cin = Cin; p.Cout = Cout; p.Tout = Tout; p.Kw = Kw; p.stride = stride; p.dil = dil;
     p.y_f32 = y_f32; p.accumulate = accumulate;
+    p.descale = 1.f;
     // the last valid output row must only need rows that exist in the padded buffer
     const int64_t need = (int64_t)(N - 1) * p.x_rows_per_utt + (int64_t)(Tout - 1) * stride + (int64_t)(Kw - 1) * dil;
     W2L_CHECK_ARG(need <= p.x_max_row, "conv1d_igemm: padded input too small (need row %lld, have %lld)",
@@ -674,6 +721,130 @@ extern "C" int w2l_conv1d_igemm_tune(const void* xp, int64_t x_bstride, int64_t 
                                      int Kw, int stride, int dil, int reps, void* stream) {
     return w2l_conv1d_igemm_tune_ws(xp, x_bstride, x_rows_total, w, y, y_f32, bias, stats_partial, N, Cin, Cout, Tout, Kw,
                                     stride, dil, reps, nullptr, 0, stream);
+}
+
+// ---- e4m3 operands (BASELINE config 5: fp8 MFMA) -------------------------------------------------------------------
+// measured choices of the e4m3 kernel: shape -> index into kF8Cfgs
+static std::map<ShapeKey, int> g_tuned_f8;
+static thread_local int g_force_f8 = -1;
+
+static bool f8_feasible(int k, int Kw, int dil, bool need_bn128) {
+    if (k < 0 || k >= kNumF8Cfgs) return false;
+    const TileCfg& c = kCfgs[kF8Cfgs[k]];
+    if (need_bn128 && (16 * c.nw * c.ns) % 128 != 0) return false;
+    const size_t lds = 2 * (size_t)(16 * c.mw * c.ms) * ROWB + 2 * (size_t)cfg_xrows(c, 1, Kw, dil) * ROWB;
+    return lds <= 160 * 1024;
+}
+
+static int choose_f8(int N, int Cin, int Cout, int Tout, int Kw, int dil, bool need_bn128) {
+    if (g_force_f8 >= 0) return f8_feasible(g_force_f8, Kw, dil, need_bn128) ? g_force_f8 : -1;
+    {
+        std::lock_guard<std::mutex> lock(g_tuned_mu);
+        auto it = g_tuned_f8.find(ShapeKey(N, Cin, Cout, Tout, Kw, 1, dil, need_bn128 ? 1 : 0));
+        if (it != g_tuned_f8.end()) return it->second;
+    }
+    int best = -1;
+    double best_cost = 1e30;
+    for (int k = 0; k < kNumF8Cfgs; ++k) {            // cost model: whole rounds of resident blocks, larger tiles preferred
+        if (!f8_feasible(k, Kw, dil, need_bn128)) continue;
+        const TileCfg& c = kCfgs[kF8Cfgs[k]];
+        const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns, waves = c.mw * c.nw;
+        const size_t lds = 2 * (size_t)bm * ROWB + 2 * (size_t)cfg_xrows(c, 1, Kw, dil) * ROWB;
+        int per_cu = (int)((160 * 1024) / lds);
+        if (per_cu > 16 / waves) per_cu = 16 / waves;
+        if (per_cu < 1) continue;
+        const long blocks = (long)((Cout + bm - 1) / bm) * N * ((Tout + bn - 1) / bn);
+        const long rounds = (blocks + 256L * per_cu - 1) / (256L * per_cu);
+        const double cost = (double)rounds * bm * bn * per_cu / c.eff * (1.0 + 1e-3 * k);
+        if (cost < best_cost) { best_cost = cost; best = k; }
+    }
+    return best;
+}
+
+extern "C" int w2l_conv1d_igemm_fp8(const void* xq, int64_t x_bstride, int64_t x_rows_total, const void* wq, void* y, int y_f32,
+                                    float descale, const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout,
+                                    int Kw, int dil, void* stream) {
+    W2L_CHECK_ARG(xq && wq && y, "conv1d_igemm_fp8: null pointer");
+    W2L_CHECK_ARG(N > 0 && Tout > 0 && Kw > 0 && dil > 0, "conv1d_igemm_fp8: bad sizes");
+    W2L_CHECK_ARG(Cin % 128 == 0 && Cin > 0, "conv1d_igemm_fp8: Cin=%d must be a positive multiple of 128", Cin);
+    W2L_CHECK_ARG(Cout % 64 == 0 && Cout > 0, "conv1d_igemm_fp8: Cout=%d must be a positive multiple of 64", Cout);
+    W2L_CHECK_ARG(x_bstride % Cin == 0, "conv1d_igemm_fp8: x_bstride must be a multiple of Cin");
+    W2L_CHECK_ARG(descale > 0.f, "conv1d_igemm_fp8: descale must be positive");
+    IgemmParams p;
+    p.x = (const bf16_raw*)xq;
+    p.w = (const bf16_raw*)wq;
+    p.y = y;
+    p.bias = bias;
+    p.stats = stats_partial;
+    p.x_rows_per_utt = x_bstride / Cin;
+    p.x_max_row = x_rows_total - 1;
+    p.N = N; p.Cin = Cin; p.Cout = Cout; p.Tout = Tout; p.Kw = Kw; p.stride = 1; p.dil = dil;
+    p.y_f32 = y_f32; p.accumulate = 0;
+    p.splits = 1; p.slabs = nullptr; p.tickets = nullptr;
+    p.descale = descale;
+    const int64_t need = (int64_t)(N - 1) * p.x_rows_per_utt + (int64_t)(Tout - 1) + (int64_t)(Kw - 1) * dil;
+    W2L_CHECK_ARG(need <= p.x_max_row, "conv1d_igemm_fp8: padded input too small (need row %lld, have %lld)",
+                  (long long)need, (long long)p.x_max_row);
+    const int k = choose_f8(N, Cin, Cout, Tout, Kw, dil, stats_partial != nullptr);
+    W2L_CHECK_ARG(k >= 0, "conv1d_igemm_fp8: no block shape fits LDS (Kw=%d dil=%d)", Kw, dil);
+    const TileCfg& c = kCfgs[kF8Cfgs[k]];
+    const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
+    p.tiles_t = (Tout + bn - 1) / bn;
+    p.ncols = N * p.tiles_t;
+    p.xrows_lds = cfg_xrows(c, 1, Kw, dil);
+    const int tiles_m = (Cout + bm - 1) / bm;
+    const size_t lds = 2 * (size_t)bm * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
+    hipStream_t st = (hipStream_t)stream;
+    switch (k) {
+        case 0: return launch_f8<2, 2, 4, 4>(p, tiles_m, lds, st);
+        case 1: return launch_f8<4, 2, 4, 4>(p, tiles_m, lds, st);
+        case 2: return launch_f8<2, 4, 4, 4>(p, tiles_m, lds, st);
+        case 3: return launch_f8<2, 4, 6, 4>(p, tiles_m, lds, st);
+        default: return launch_f8<2, 4, 8, 4>(p, tiles_m, lds, st);
+    }
+}
+
+// measure the e4m3 block shapes for this problem and remember the fastest (SYNCHRONISING: warm-up only)
+extern "C" int w2l_conv1d_igemm_fp8_tune(const void* xq, int64_t x_bstride, int64_t x_rows_total, const void* wq, void* y,
+                                         int y_f32, const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout,
+                                         int Kw, int dil, int reps, void* stream) {
+    const bool need128 = stats_partial != nullptr;
+    const ShapeKey key(N, Cin, Cout, Tout, Kw, 1, dil, need128 ? 1 : 0);
+    {
+        std::lock_guard<std::mutex> lock(g_tuned_mu);
+        if (g_tuned_f8.count(key)) return 0;
+    }
+    hipEvent_t e0, e1;
+    W2L_CHECK_HIP(hipEventCreate(&e0));
+    W2L_CHECK_HIP(hipEventCreate(&e1));
+    hipStream_t st = (hipStream_t)stream;
+    int best = -1;
+    float best_ms = 1e30f;
+    const int saved = g_force_f8;
+    if (reps < 1) reps = 1;
+    for (int k = 0; k < kNumF8Cfgs; ++k) {
+        if (!f8_feasible(k, Kw, dil, need128)) continue;
+        g_force_f8 = k;
+        if (w2l_conv1d_igemm_fp8(xq, x_bstride, x_rows_total, wq, y, y_f32, 1.f, bias, stats_partial, N, Cin, Cout, Tout, Kw, dil,
+                                 stream) != 0)
+            continue;
+        (void)hipEventRecord(e0, st);
+        for (int r = 0; r < reps; ++r)
+            w2l_conv1d_igemm_fp8(xq, x_bstride, x_rows_total, wq, y, y_f32, 1.f, bias, stats_partial, N, Cin, Cout, Tout, Kw, dil,
+                                 stream);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+        if (ms < best_ms) { best_ms = ms; best = k; }
+    }
+    g_force_f8 = saved;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    W2L_CHECK_ARG(best >= 0, "conv1d_igemm_fp8_tune: no feasible block shape");
+    std::lock_guard<std::mutex> lock(g_tuned_mu);
+    g_tuned_f8[key] = best;
+    return 0;
 }
 
 // Tuning-cache (de)serialisation used by w2l_tune_save / w2l_tune_load (runtime.hip).

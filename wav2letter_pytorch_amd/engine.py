@@ -108,6 +108,8 @@ class Act:
     pad_r: int
     pad_mode: int
     lens: Optional[torch.Tensor] = None   # int32 [N] on device: frames t >= lens[n] are zero
+    q: Optional[torch.Tensor] = None      # fp8 mode: the same buffer as OCP e4m3 bytes, value * q_scale
+    q_scale: float = 1.0
 
     @property
     def rows(self) -> int:
@@ -357,11 +359,43 @@ def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw
                                Tout, Kw, stride, dil, st), 'w2l_conv1d_igemm')
 
 
+# fp8 mode (BASELINE config 5): per-tensor scales of the e4m3 operands.  Activations: clamp(0, 20) outputs times 16 stay
+# below e4m3's 448; ReLU / linear outputs (BatchNorm-normalised, a few units wide) times 8, saturating beyond 56.  Weights:
+# the largest power of two that keeps |w| * scale <= 448, re-derived from the tensor's amax every FP8_WEIGHT_RESCALE
+# quantisations (one host sync per weight then; weights move by lr * grad per step, and the conversion saturates).
+FP8_ACT_SCALE = {ACT_CLAMP20: 16.0, ACT_RELU: 8.0, ACT_NONE: 8.0}
+FP8_WEIGHT_RESCALE = 256
+
+
+def _fp8_weights(conv: ConvSpec, pk: '_PackedW'):
+    """(e4m3 [Kw, CoutP, CinP] operand, scale) of a conv weight, requantised from the bf16 pack when the weight changed"""
+    w = conv.weight
+    st = w.__dict__.get('_w2l_fp8')
+    if st is not None and st['version'] == pk.version and st['q'].device == pk.fwd_hi.device:
+        return st['q'], st['scale']
+    if st is None or st['age'] >= FP8_WEIGHT_RESCALE or st['q'].shape != pk.fwd_hi.shape:
+        amax = float(pk.fwd_hi.abs().amax())                     # host sync: first use and every FP8_WEIGHT_RESCALE steps
+        scale = 2.0 ** int(torch.floor(torch.log2(torch.tensor(448.0 / max(amax, 1e-30)))))
+        st = {'q': torch.empty(pk.fwd_hi.shape, dtype=torch.uint8, device=pk.fwd_hi.device), 'scale': scale, 'age': 0}
+        w.__dict__['_w2l_fp8'] = st
+    check(lib.w2l_quantize_e4m3(ptr(pk.fwd_hi), 0, pk.fwd_hi.numel(), st['scale'], ptr(st['q']), stream_ptr()),
+          'w2l_quantize_e4m3')
+    st['version'] = pk.version
+    st['age'] += 1
+    return st['q'], st['scale']
+
+
 class StackEngine:
     """Executes a list of UnitSpec.  ``precise`` selects the split-bf16 (near-fp32) mode used
-    for parity against the fp32 reference; the default is bf16 operands with fp32 accumulate."""
+    for parity against the fp32 reference; the default is bf16 operands with fp32 accumulate; ``fp8`` runs the forward
+    convolutions of the units on e4m3 operands (activations and weights quantised per tensor, fp32 accumulate) while
+    the classifier, every gradient and all statistics stay as in bf16 mode."""
 
-    def __init__(self, units: Sequence[UnitSpec], head: Optional[ConvSpec], n_labels: int, precise: bool = False):
+    def __init__(self, units: Sequence[UnitSpec], head: Optional[ConvSpec], n_labels: int, precise: bool = False,
+                 fp8: bool = False):
+        if fp8 and precise:
+            raise ValueError('fp8 operands and the fp32 parity mode exclude each other')
+        self.fp8 = fp8
         """``head`` = the classifier conv followed by (log_)softmax; ``None`` runs an OPEN stack whose result is the last
         unit's activation as fp32 [N, C, T'] (stand-alone Conv1dBlock / MaskedConv1d / JasperBlock modules)."""
         self.units = list(units)
@@ -474,10 +508,14 @@ class StackEngine:
                     _dropout_calls += 1
                     uc.offset = _dropout_calls
             d = self._desc(uc, N, Tout, coutp, p, uc.lens_out)
-            check(lib.w2l_bn_act_fwd(C.byref(d), ptr(out_hi), ptr(out_lo), opl + Tout + opr, opl, opr, omode, st()),
-                  'w2l_bn_act_fwd')
+            out_q, q_scale = None, 1.0
+            if self.fp8 and coutp % 128 == 0 and self._fp8_consumers(ui + 1):
+                out_q = torch.empty(N, opl + Tout + opr, coutp, dtype=torch.uint8, device=dev)
+                q_scale = FP8_ACT_SCALE[u.act]
+            check(lib.w2l_bn_act_fwd_q(C.byref(d), ptr(out_hi), ptr(out_lo), ptr(out_q), q_scale, opl + Tout + opr, opl, opr,
+                                       omode, st()), 'w2l_bn_act_fwd_q')
             uc.out_index = ui + 1
-            acts.append(Act(out_hi, out_lo, N, Tout, conv.cout, coutp, opl, opr, omode, uc.lens_out))
+            acts.append(Act(out_hi, out_lo, N, Tout, conv.cout, coutp, opl, opr, omode, uc.lens_out, out_q, q_scale))
             ctx['units'].append(uc)
 
         if self._nbt_pending:
@@ -502,6 +540,15 @@ class StackEngine:
         for hook in list(AFTER_FORWARD):
             hook()
         return out, ctx
+
+    def _fp8_consumers(self, act_index: int) -> bool:
+        """does a stride-1 dense conv of some unit read this activation (the e4m3 copy is written only then)?"""
+        for u in self.units:
+            if u.src == act_index and u.dw is None and u.main.stride == 1:
+                return True
+            if u.res is not None and u.res_src == act_index and u.res.stride == 1:
+                return True
+        return False
 
     def _plan_lens(self, lens, dev):
         """Length bookkeeping of the MaskedConv1d chain (jasper.py:109-121): lens <- (lens + 2p - d(k-1) - 1) / s + 1 in
@@ -559,9 +606,34 @@ class StackEngine:
             tiles = lib.w2l_conv_stat_tiles(N, Tout)
             stats = torch.empty(tiles, 2, pk.coutp, dtype=torch.float32, device=src.hi.device)
         bias = _padded_vec(conv.bias, pk.coutp, 0.0)
-        _igemm(src, src.pad_l - conv.pad_l, pk.fwd_hi, pk.fwd_lo, y, bias, stats, pk.cinp, pk.coutp, Tout, conv.kernel,
-               conv.stride, conv.dilation, self.precise, alg_flops=2.0 * N * Tout * conv.cout * conv.cin * conv.kernel)
+        flops = 2.0 * N * Tout * conv.cout * conv.cin * conv.kernel
+        if self.fp8 and src.q is not None and conv.stride == 1 and pk.cinp % 128 == 0 and not force_f32:
+            self._igemm_fp8(conv, pk, src, y, bias, stats, Tout, flops)
+        else:
+            _igemm(src, src.pad_l - conv.pad_l, pk.fwd_hi, pk.fwd_lo, y, bias, stats, pk.cinp, pk.coutp, Tout, conv.kernel,
+                   conv.stride, conv.dilation, self.precise, alg_flops=flops)
         return y, stats, Tout
+
+    def _igemm_fp8(self, conv: ConvSpec, pk: _PackedW, src: Act, y, bias, stats, Tout, flops):
+        """forward conv on e4m3 operands (w2l_conv1d_igemm_fp8): y = (xq * wq) / (x scale * w scale) + bias"""
+        wq, w_scale = _fp8_weights(conv, pk)
+        N, cin, cout = src.N, pk.cinp, pk.coutp
+        row_off = src.pad_l - conv.pad_l
+        xq = C.c_void_p(src.q.data_ptr() + row_off * src.CP)
+        bstride, rows_total = src.rows * src.CP, N * src.rows - row_off
+        y_f32 = int(y.dtype == torch.float32)
+        st = stream_ptr()
+        if AUTOTUNE:
+            key = ('fp8', N, cin, cout, Tout, conv.kernel, conv.dilation, stats is not None, src.q.device.index)
+            if key not in _tuned_shapes:
+                _tuned_shapes.add(key)
+                check(lib.w2l_conv1d_igemm_fp8_tune(xq, bstride, rows_total, ptr(wq), ptr(y), y_f32, ptr(bias), ptr(stats), N,
+                                                    cin, cout, Tout, conv.kernel, conv.dilation, TUNE_REPS, st),
+                      'w2l_conv1d_igemm_fp8_tune')
+        with _timed('conv_igemm_fp8_kernel', flops):
+            check(lib.w2l_conv1d_igemm_fp8(xq, bstride, rows_total, ptr(wq), ptr(y), y_f32, 1.0 / (src.q_scale * w_scale),
+                                           ptr(bias), ptr(stats), N, cin, cout, Tout, conv.kernel, conv.dilation, st),
+                  'w2l_conv1d_igemm_fp8')
 
     @staticmethod
     def _dw_weight(dwc: ConvSpec, cp: int) -> torch.Tensor:

@@ -287,7 +287,7 @@ class Jasper(ConvCTCASR):
             units += us
             a_in = len(units)
         head = conv_spec(self.final_layer[0], None, 0, 0, PAD_ZERO, 'head')
-        return StackEngine(units, head, len(self.labels), precise=self.precision == 'fp32')
+        return StackEngine(units, head, len(self.labels), precise=self.precision == 'fp32', fp8=self.precision == 'fp8')
 
     def engine(self) -> StackEngine:
         return self._cached_engine(self._build_engine)

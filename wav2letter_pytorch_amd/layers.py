@@ -14,8 +14,9 @@ from .engine import ACT_NONE, PAD_ZERO, ConvSpec, StackEngine, UnitSpec
 
 
 def default_precision(cfg=None) -> str:
-    """'bf16' (bf16 operands, fp32 accumulate: the production mode) or 'fp32' (split-bf16,
-    three MFMA passes per product: the parity mode against the fp32 reference)."""
+    """'bf16' (bf16 operands, fp32 accumulate: the production mode), 'fp32' (split-bf16, three MFMA passes per
+    product: the parity mode against the fp32 reference) or 'fp8' (forward convolutions on e4m3 operands through the
+    block-scaled MFMA at twice the bf16 rate; gradients, statistics and the classifier as in bf16 mode)."""
     p = None
     if cfg is not None:
         try:
@@ -23,8 +24,8 @@ def default_precision(cfg=None) -> str:
         except Exception:
             p = None
     p = p or os.environ.get('W2L_PRECISION', 'bf16')
-    if p not in ('bf16', 'fp32'):
-        raise ValueError(f"precision must be 'bf16' or 'fp32', got {p!r}")
+    if p not in ('bf16', 'fp32', 'fp8'):
+        raise ValueError(f"precision must be 'bf16', 'fp32' or 'fp8', got {p!r}")
     return p
 
 
@@ -155,6 +156,6 @@ def solo_engine(owner: nn.Module, units_fn: Callable[[], list]) -> StackEngine:
     key = tuple((id(t), t.device) for t in chain(owner.parameters(), owner.buffers())) + (prec,)
     hit = owner.__dict__.get('_solo_engine')
     if hit is None or hit[0] != key:
-        hit = (key, StackEngine(units_fn(), None, 0, precise=prec == 'fp32'))
+        hit = (key, StackEngine(units_fn(), None, 0, precise=prec == 'fp32', fp8=prec == 'fp8'))
         owner.__dict__['_solo_engine'] = hit
     return hit[1]

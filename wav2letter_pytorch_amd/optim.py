@@ -12,6 +12,8 @@ do): ``join()`` (also called by ``state_dict``) makes the caller's stream wait f
 that reads the parameters outside the step engine must call it first."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import engine as E
@@ -27,7 +29,8 @@ def _is_tap_major(t: torch.Tensor) -> bool:
 
 
 class FusedSGD(torch.optim.SGD):
-    recycle_grads = True      # zero the consumed conv-weight gradients in the update kernel and hand them back as the next dW
+    # zero the consumed conv-weight gradients in the update kernel and hand them back as the next dW (W2L_RECYCLE_GRADS=0: off)
+    recycle_grads = os.environ.get('W2L_RECYCLE_GRADS', '1') != '0'
     overlap = False           # opt-in (trainer.Trainer and bench.py set it): whoever enables it must join() before
                               # reading parameters outside the step engine (checkpoints, .cpu() copies, ...)
 

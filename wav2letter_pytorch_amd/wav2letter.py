@@ -86,7 +86,7 @@ class Wav2Letter(ConvCTCASR):
             raise NotImplementedError('the classifier block must be a plain 1x1 convolution (wav2letter.py:69)')
         units = [b.unit(i, f'conv1d_{i}') for i, b in enumerate(body)]
         head = conv_spec(head_blk.conv1, None, 0, 0, PAD_REFLECT, 'head')
-        return StackEngine(units, head, len(self.labels), precise=self.precision == 'fp32')
+        return StackEngine(units, head, len(self.labels), precise=self.precision == 'fp32', fp8=self.precision == 'fp8')
 
     def engine(self) -> StackEngine:
         return self._cached_engine(self._build_engine)
