@@ -64,6 +64,20 @@ def cpu_baseline(budget_s=20.0):
                       f'torch CPU ops on {cores} threads of {os.cpu_count()} host cores'}
 
 
+def csrc_fingerprint():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, include/w2l_hip.h): stamps profiles/*_pmc_bench.json, so that
+    counters collected on other kernels are never quoted (tools/prof_summary.py writes the same stamp)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, 'wav2letter_pytorch_amd', 'csrc')
+    for f in sorted(glob.glob(os.path.join(src, '*.hip')) + glob.glob(os.path.join(src, '*.h'))
+                    + [os.path.join(ROOT, 'include', 'w2l_hip.h')]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def _launcher():
     """wav2letter_pytorch_amd/launch.py loaded by path: importing the package would load libw2l_hip.so (and the HIP
     runtime) into the parent, which only spawns the ranks"""
@@ -267,14 +281,20 @@ def main():
                 'unit': 'TFLOP/s', 'frac': round(ach / BF16_DENSE_PEAK_TFLOPS, 4), 'traffic': None,
                 'launches_per_step': cnt // 3, 'avg_launch_ms': round(tt / cnt * 1e3, 4),
                 'alg_gflop_per_launch': round(fl / cnt / 1e9, 2)}
-        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_bench.json')
-        if args.model == 'wav2letter' and args.mid_layers == 20 and args.batch == 32 and os.path.exists(pmc_file):
+        pmc_file = os.path.join(ROOT, 'profiles', 'r02_pmc_bench.json')
+        if (args.model == 'wav2letter' and args.mid_layers == 20 and args.batch == 32 and args.dtype == 'bf16'
+                and os.path.exists(pmc_file)):
             # HBM-side bytes per launch from the committed PMC passes of this same command (tools/make_profiles.sh):
-            # FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 FETCH correction applied (tools/prof_summary.py)
-            k = json.load(open(pmc_file))['kernels'].get(name, {})
-            if 'traffic_bytes_per_launch' in k:
+            # FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 FETCH correction applied (tools/prof_summary.py).  The file
+            # carries the fingerprint of the kernel sources it was measured on: a different build reports traffic = null.
+            pmc = json.load(open(pmc_file))
+            k = pmc['kernels'].get(name, {})
+            if pmc.get('csrc_sha') == csrc_fingerprint() and 'traffic_bytes_per_launch' in k:
                 roof['traffic'] = round(k['traffic_bytes_per_launch'])
-                roof['traffic_source'] = 'profiles/r01_pmc_bench.json (rocprofv3 --pmc, mean over the step\'s launches)'
+                roof['traffic_source'] = ('profiles/r02_pmc_bench.json (rocprofv3 --pmc, mean over the step\'s launches; '
+                                          'kernel sources ' + pmc['csrc_sha'] + ')')
+            else:
+                roof['traffic_source'] = 'none: profiles/r02_pmc_bench.json was measured on other kernel sources'
         if 'conv_igemm_fp8_kernel' in agg:
             # fp8 mode: the forward convolutions of the units ran on e4m3 operands; they are priced against the fp8 peak, the
             # bf16 launches left in `roof` (first layer, classifier, data gradients) against the bf16 peak

@@ -87,13 +87,13 @@ def test_fp8_rejects_unsupported_shapes(L):
     assert rc != 0 and b'multiple of 128' in L.lib.w2l_last_error()
 
 
-def _fp8_step(layers, N, T, seed, dropout=False):
+def _fp8_step(layers, N, T, seed, dropout=False, tie=2.0):
     from oracle import w2l_oracle as O
     from gpu_helpers import compare_step
     sd = O.init_wav2letter_state(layers, seed=seed)
     model = build_w2l(layers, sd, 'fp8', dropout=dropout).train()
     x, il, tg, tl = O.synthetic_batch(N, T, seed=seed + 1, s_lo=max(2, T // 12), s_hi=max(3, T // 6))
-    errs, stats, out, out_lens, ref = compare_step(model, layers, sd, x, il, tg, tl, 'bf16', drop=dropout, tie=2.0, max_frac=0.3)
+    errs, stats, out, out_lens, ref = compare_step(model, layers, sd, x, il, tg, tl, 'bf16', drop=dropout, tie=tie, max_frac=0.3)
     return model, errs, stats
 
 
@@ -107,9 +107,9 @@ def test_w2l_small_stack_fp8_vs_oracle():
     worst = max((v, k) for k, v in errs.items() if k not in ('log_probs', 'loss'))
     print(f'fp8 small stack: log-probs {errs["log_probs"]:.3f} loss {errs["loss"]:.4f} worst grad {worst[0]:.3f} ({worst[1]}) '
           f'stats {max(stats.values()):.3f}')
-    assert errs['log_probs'] < 1.5e-1 and errs['loss'] < 5e-2
-    assert worst[0] < 3e-1
-    assert max(stats.values()) < 1e-1
+    assert errs['log_probs'] < 8e-2 and errs['loss'] < 1e-2          # measured 2.8e-2 / 4e-4
+    assert worst[0] < 2.5e-1                                          # measured 0.12
+    assert max(stats.values()) < 8e-2                                 # measured 3.3e-2
     w = model.conv1ds.conv1d_1.conv1.weight
     st = w._w2l_fp8
     assert st['q'].dtype == torch.uint8 and st['scale'] >= 1 and float(w.detach().abs().max()) * st['scale'] <= 448
@@ -120,7 +120,7 @@ def test_w2l_full_table_fp8_properties_and_loss():
     non-zero, and the loss close to the oracle's with the device's masks and gates replayed"""
     from oracle import w2l_oracle as O
     layers = list(O.W2L_LAYERS)
-    model, errs, stats = _fp8_step(layers, N=4, T=1000, seed=0, dropout=True)
+    model, errs, stats = _fp8_step(layers, N=4, T=1000, seed=0, dropout=True, tie='skip')
     print(f'fp8 full table: log-probs {errs["log_probs"]:.3f} loss {errs["loss"]:.4f}')
     assert errs['loss'] < 1e-1
     assert errs['log_probs'] < 5e-1

@@ -46,8 +46,11 @@ def pmc(out, dirs):
         if 'FETCH_SIZE' in e and 'WRITE_SIZE' in e:
             e['traffic_bytes_per_launch'] = 2 * e['FETCH_SIZE'] * 1024 + e['WRITE_SIZE'] * 1024
         res[k] = e
-    json.dump({'note': 'per-launch means; traffic = 2*FETCH_SIZE KiB + WRITE_SIZE KiB (gfx950 correction)', 'kernels': res},
-              open(out, 'w'), indent=1, sort_keys=True)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_fingerprint                    # the kernel sources these counters were measured on
+    json.dump({'note': 'per-launch means; traffic = 2*FETCH_SIZE KiB + WRITE_SIZE KiB (gfx950 correction)',
+               'csrc_sha': csrc_fingerprint(), 'kernels': res}, open(out, 'w'), indent=1, sort_keys=True)
 
 
 if __name__ == '__main__':

@@ -29,8 +29,10 @@ def _is_tap_major(t: torch.Tensor) -> bool:
 
 
 class FusedSGD(torch.optim.SGD):
-    # zero the consumed conv-weight gradients in the update kernel and hand them back as the next dW (W2L_RECYCLE_GRADS=0: off)
-    recycle_grads = os.environ.get('W2L_RECYCLE_GRADS', '1') != '0'
+    # W2L_RECYCLE_GRADS=1: zero the consumed conv-weight gradients in the update kernel and hand them back as the next dW
+    # (no fill launches for split-K weight gradients).  Off by default: measured NEUTRAL on the full Wav2Letter table
+    # (13.54 vs 13.50 ms per step) -- the fills already ran hidden on the weight-gradient stream.
+    recycle_grads = os.environ.get('W2L_RECYCLE_GRADS', '0') == '1'
     overlap = False           # opt-in (trainer.Trainer and bench.py set it): whoever enables it must join() before
                               # reading parameters outside the step engine (checkpoints, .cpu() copies, ...)
 
