@@ -248,6 +248,24 @@ int w2l_bn_bwd_finalize(const float* partial, int nblocks, int C, int ncomp, flo
 int w2l_bn_act_bwd_apply(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2, const float* sums,
                          void* dy_hi, void* dy_lo, int halo, void* dy2_hi, void* dy2_lo, int halo2, void* stream);
 
+/* The data gradient of a stride-1 nn.Conv1d FUSED with w2l_bn_act_bwd_reduce of the layer that produced the conv's input
+ * (d describes that layer: bf16 y, one branch).  dxp [flat_rows][d->C] bf16 is the gradient wrt the padded activation,
+ * computed over the shared-halo dy buffer as one sequence exactly like w2l_conv1d_igemm_ws(N = 1, Tout = flat_rows, w =
+ * the flipped-tap operand); row v of it is padded row v % per of utterance v / per (per >= pad_l + d->T + pad_r).  The
+ * epilogue, which holds that gradient in registers, also writes partial[tile][2][d->C] -- per 128-row tile
+ * (w2l_conv_stat_tiles(1, flat_rows) rows) the sums of g*gate and g*gate*xhat, every padded row counted with the gate
+ * and xhat of its source frame (itself, or its mirror under reflect padding) -- so the separate reduction pass over dxp
+ * and y (and its launch on the backward critical path) disappears; w2l_bn_bwd_finalize(partial, tiles, C, 2, ...) follows.
+ * Replaces the reduction half of autograd's batch_norm backward at wav2letter.py:43 / jasper.py:363. */
+int w2l_conv1d_dgrad_bnreduce_ws(const void* dy, int64_t dy_rows_total, const void* w_dgr, void* dxp, float* partial,
+                                 const w2l_bnact_t* d, int pad_l, int pad_r, int pad_mode, int per, int Cconv_out,
+                                 int flat_rows, int Kw, int dil, void* splitk_ws, int64_t splitk_ws_bytes, void* stream);
+/* measure-and-pick of the block shape for that launch (SYNCHRONISING; warm-up only) */
+int w2l_conv1d_dgrad_bnreduce_tune_ws(const void* dy, int64_t dy_rows_total, const void* w_dgr, void* dxp, float* partial,
+                                      const w2l_bnact_t* d, int pad_l, int pad_r, int pad_mode, int per, int Cconv_out,
+                                      int flat_rows, int Kw, int dil, int reps, void* splitk_ws, int64_t splitk_ws_bytes,
+                                      void* stream);
+
 /* ---- log_softmax + CTC (wav2letter.py:86-87, jasper.py:469-473, base_asr_models.py:23,81,90) ---- */
 /* logits fp32 [N][T][CP] (first C valid) -> out fp32 [N][T][C]; mode 0 log_softmax, 1 softmax */
 int w2l_log_softmax_fwd(const float* logits, int N, int T, int C, int CP, int mode, float* out, void* stream);

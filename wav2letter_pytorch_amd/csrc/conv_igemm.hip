@@ -16,6 +16,7 @@
 // its autograd data gradient.  Padding is physical: the producer kernel writes the
 // reflect (wav2letter.py:28-34) or zero halo, so the hot loop has no padding logic.
 #include "common.h"
+#include "../../include/w2l_hip.h"
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -42,6 +43,18 @@ struct IgemmParams {
     float* slabs;             // [tiles][splits][BM*BN]
     unsigned* tickets;        // [tiles], zero between launches
     float descale;            // F8 kernels: y = acc * descale (+ bias), descale = 1 / (activation scale * weight scale)
+    // EPI == 1 (data gradient fused with the BatchNorm-backward reduction of the layer that produced the conv's input):
+    // the output tile IS the gradient wrt that layer's padded activation, so the epilogue also forms, per channel,
+    // sum g*gate and sum g*gate*xhat over its rows (what bn_act_bwd_reduce_kernel computes in a pass of its own)
+    const bf16_raw* bn_y;     // that layer's conv output [N][T][C] (C = this launch's Cout)
+    const float* bn_scale;    // its BatchNorm scale / shift / mean / invstd
+    const float* bn_shift;
+    const float* bn_mean;
+    const float* bn_invstd;
+    const uint8_t* bn_mask;   // dropout keep bits (one byte per 8 channels) or NULL
+    const int32_t* bn_lens;   // optional [N] valid lengths
+    int bn_T, bn_pad_l, bn_pad_mode, bn_per, bn_Tp, bn_act;
+    float bn_gk;              // 1 / (1 - p) with dropout, else 1
 };
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -68,9 +81,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base
 // F8: operands are OCP e4m3 bytes (x [.][rows][Cin], w [Kw][Cout][Cin], one byte per element): a 128-byte LDS row is 128
 // channels, a K step is one tap of a 128-channel chunk, and its MS x NS MFMAs are v_mfma_scale_f32_16x16x128_f8f6f4 (twice
 // the bf16 rate); LDS-DMA, swizzle, window reuse, split-K and the epilogue are the bf16 kernel's.  PIPE = 0 only.
-template <int MW, int NW, int MS, int NS, int S, int PIPE, bool F8 = false>
+template <int MW, int NW, int MS, int NS, int S, int PIPE, bool F8 = false, int EPI = 0>
 __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams p) {
     static_assert(!(F8 && PIPE != 0), "the e4m3 kernel is built for K-loop structure 0 only");
+    static_assert(EPI == 0 || (!F8 && S == 1), "the fused BatchNorm-backward epilogue belongs to bf16 data gradients");
     constexpr int ESZ = F8 ? 1 : 2;                // bytes per operand element
     constexpr int BKE = ROWB / ESZ;                // channels per K chunk (one 128-byte LDS row)
     constexpr int BM = 16 * MW * MS, BN = 16 * NW * NS, NWAVES = MW * NW, NT = 64 * NWAVES;
@@ -363,6 +377,12 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
         if (p.bias && co_ok) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s1[mi][r] = 0.f; s2[mi][r] = 0.f; }
+        // EPI 1: BatchNorm constants of this lane's four channels (the producing layer's, see IgemmParams)
+        f32x4 bsc = f32x4{1.f, 1.f, 1.f, 1.f}, bsh = f32x4{0.f, 0.f, 0.f, 0.f}, bmu = bsh, bis = bsh;
+        if (EPI == 1 && co_ok) {
+            if (p.bn_scale) { bsc = *reinterpret_cast<const f32x4*>(p.bn_scale + co); bsh = *reinterpret_cast<const f32x4*>(p.bn_shift + co); }
+            if (p.bn_mean) { bmu = *reinterpret_cast<const f32x4*>(p.bn_mean + co); bis = *reinterpret_cast<const f32x4*>(p.bn_invstd + co); }
+        }
 #pragma unroll
         for (int ni = 0; ni < NS; ++ni) {
             const int t = t0 + (wn * NS + ni) * 16 + fr;
@@ -380,8 +400,42 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
                     for (int r = 0; r < 4; ++r) o[r] = f32_to_bf16_bits(v[r]);
                     *reinterpret_cast<u16x4*>(reinterpret_cast<bf16_raw*>(p.y) + off) = o;
                 }
+                if constexpr (EPI == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { s1[mi][r] += v[r]; s2[mi][r] += v[r] * v[r]; }
+                    for (int r = 0; r < 4; ++r) { s1[mi][r] += v[r]; s2[mi][r] += v[r] * v[r]; }
+                } else {
+                    // flat output row t = padded row u of utterance nu; its gradient belongs to source frame ts (itself, or
+                    // its mirror image when the row is a reflected halo row -- the fold of bn_act.hip add_grad8 is linear,
+                    // so every padded row simply counts with its source frame's gate and xhat)
+                    const int nu = (int)((unsigned)t / (unsigned)p.bn_per);
+                    const int u = t - nu * p.bn_per;
+                    int ts = u - p.bn_pad_l;
+                    bool live = u < p.bn_Tp;
+                    if (ts < 0 || ts >= p.bn_T) {
+                        if (p.bn_pad_mode == 1) ts = ts < 0 ? -ts : 2 * (p.bn_T - 1) - ts;
+                        else live = false;
+                    }
+                    if (live && p.bn_lens && ts >= p.bn_lens[nu]) live = false;     // masked frame: no gradient through it
+                    if (live) {
+                        const int64_t row = (int64_t)nu * p.bn_T + ts;
+                        const u16x4 yv = *reinterpret_cast<const u16x4*>(p.bn_y + row * Cout + co);
+                        unsigned bits = 0xFu;
+                        if (p.bn_mask) bits = (unsigned)p.bn_mask[row * (Cout >> 3) + (co >> 3)] >> (co & 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float yf = bf16_bits_to_f32(yv[r]);
+                            const bool keep = (bits >> r) & 1u;
+                            float z = yf * bsc[r] + bsh[r];
+                            z = keep ? z * p.bn_gk : 0.f;
+                            bool pass = keep;
+                            if (p.bn_act == 1) pass = pass && z >= 0.f && z <= 20.f;
+                            else if (p.bn_act == 2) pass = pass && z > 0.f;
+                            const float g = pass ? v[r] * p.bn_gk : 0.f;
+                            s1[mi][r] += g;
+                            s2[mi][r] += g * ((yf - bmu[r]) * bis[r]);
+                        }
+                    }
+                }
             }
         }
     }
@@ -442,7 +496,19 @@ constexpr TileCfg kCfgs[] = {
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 template <int MW, int NW, int MS, int NS, int PIPE>
-int launch_cfg1(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream) {
+int launch_cfg1(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream, int epi = 0) {
+    if (epi == 1) {
+        if constexpr ((16 * NW * NS) % 128 == 0) {        // statistics rows are per 128-column tile
+            auto kern1 = conv_igemm_kernel<MW, NW, MS, NS, 1, PIPE, false, 1>;
+            W2L_CHECK_HIP(w2l_allow_big_lds((const void*)kern1));
+            hipLaunchKernelGGL(kern1, dim3(tiles_m * p.ncols), dim3(64 * MW * NW), lds, stream, p);
+            W2L_CHECK_LAUNCH();
+            return 0;
+        } else {
+            w2l_set_error("conv1d_igemm: the fused BatchNorm-backward epilogue needs a block shape of 128-column tiles");
+            return 1;
+        }
+    }
     if (p.stride == 2) {
         if constexpr (MW == 2 && NW == 2 && MS == 4 && NS == 4) {
             auto kern2 = conv_igemm_kernel<2, 2, 4, 4, 2, PIPE>;
@@ -463,8 +529,9 @@ int launch_cfg1(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t strea
 }
 
 template <int MW, int NW, int MS, int NS>
-int launch_cfg(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream, int pipe) {
-    return pipe ? launch_cfg1<MW, NW, MS, NS, 1>(p, tiles_m, lds, stream) : launch_cfg1<MW, NW, MS, NS, 0>(p, tiles_m, lds, stream);
+int launch_cfg(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream, int pipe, int epi = 0) {
+    return pipe ? launch_cfg1<MW, NW, MS, NS, 1>(p, tiles_m, lds, stream, epi)
+                : launch_cfg1<MW, NW, MS, NS, 0>(p, tiles_m, lds, stream, epi);
 }
 
 // e4m3 launches: K-loop structure 0, stride 1, a subset of the block shapes (indices into kCfgs)
@@ -569,10 +636,31 @@ static bool split_feasible(int cfg_i, int splits, int N, int Cin, int Cout, int 
     return tiles * sizeof(unsigned) <= kTicketBytes && splitk_bytes(cfg_i, splits, N, Cout, Tout) <= (size_t)ws_bytes;
 }
 
+// the BatchNorm-backward side of a fused data-gradient launch (w2l_conv1d_dgrad_bnreduce_ws); NULL: plain launch
+struct BnBwdArgs {
+    const w2l_bnact_t* d;
+    int pad_l, pad_r, pad_mode, per;
+};
+
+static int igemm_launch(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y, int y_f32,
+                        int accumulate, const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout, int Kw,
+                        int stride, int dil, void* splitk_ws, int64_t splitk_ws_bytes, void* stream, const BnBwdArgs* bb);
+
 extern "C" int w2l_conv1d_igemm_ws(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y,
                                    int y_f32, int accumulate, const float* bias, float* stats_partial, int N, int Cin,
                                    int Cout, int Tout, int Kw, int stride, int dil, void* splitk_ws, int64_t splitk_ws_bytes,
                                    void* stream) {
+    return igemm_launch(xp, x_bstride, x_rows_total, w, y, y_f32, accumulate, bias, stats_partial, N, Cin, Cout, Tout, Kw,
+                        stride, dil, splitk_ws, splitk_ws_bytes, stream, nullptr);
+}
+
+// thread-local hand-over of the fused launch's descriptor to the tuner's inner launches (same thread, see g_force_cfg)
+static thread_local const BnBwdArgs* g_tune_bb = nullptr;
+
+static int igemm_launch(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y, int y_f32,
+                        int accumulate, const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout, int Kw,
+                        int stride, int dil, void* splitk_ws, int64_t splitk_ws_bytes, void* stream, const BnBwdArgs* bb) {
+    if (bb == nullptr) bb = g_tune_bb;
     W2L_CHECK_ARG(xp && w && y, "conv1d_igemm: null pointer");
     W2L_CHECK_ARG(N > 0 && Tout > 0 && Kw > 0 && (stride == 1 || stride == 2) && dil > 0,
                   "conv1d_igemm: bad sizes (stride must be 1 or 2)");
@@ -591,12 +679,33 @@ extern "C" int w2l_conv1d_igemm_ws(const void* xp, int64_t x_bstride, int64_t x_
     p.N = N; p.Cin = Cin; p.Cout = Cout; p.Tout = Tout; p.Kw = Kw; p.stride = stride; p.dil = dil;
     p.y_f32 = y_f32; p.accumulate = accumulate;
     p.descale = 1.f;
+    int epi = 0;
+    if (bb != nullptr) {
+        const w2l_bnact_t* d = bb->d;
+        W2L_CHECK_ARG(d && d->y && !d->y_f32 && !d->y2 && stats_partial && !y_f32 && !accumulate && !bias && N == 1 && stride == 1,
+                      "conv1d_dgrad_bnreduce: needs a bf16 single-branch layer, a statistics buffer and a flat bf16 output");
+        W2L_CHECK_ARG(d->C == Cout && bb->per > 0 && bb->pad_l >= 0 && bb->pad_r >= 0 &&
+                      (int64_t)d->N * bb->per <= Tout && bb->per >= bb->pad_l + d->T + bb->pad_r,
+                      "conv1d_dgrad_bnreduce: geometry mismatch (C=%d vs %d, per=%d, N=%d, rows=%d)", d->C, Cout, bb->per,
+                      d->N, Tout);
+        W2L_CHECK_ARG(d->drop_p == 0.f || d->mask, "conv1d_dgrad_bnreduce: dropout needs the recorded mask");
+        p.bn_y = (const bf16_raw*)d->y;
+        p.bn_scale = d->scale; p.bn_shift = d->shift; p.bn_mean = d->mean; p.bn_invstd = d->invstd;
+        p.bn_mask = d->drop_p > 0.f ? d->mask : nullptr;
+        p.bn_lens = d->lens;
+        p.bn_T = d->T; p.bn_pad_l = bb->pad_l; p.bn_pad_mode = bb->pad_mode; p.bn_per = bb->per;
+        p.bn_Tp = bb->pad_l + d->T + bb->pad_r;
+        p.bn_act = d->act;
+        p.bn_gk = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
+        epi = 1;
+    }
     // the last valid output row must only need rows that exist in the padded buffer
     const int64_t need = (int64_t)(N - 1) * p.x_rows_per_utt + (int64_t)(Tout - 1) * stride + (int64_t)(Kw - 1) * dil;
     W2L_CHECK_ARG(need <= p.x_max_row, "conv1d_igemm: padded input too small (need row %lld, have %lld)",
                   (long long)need, (long long)p.x_max_row);
     // BatchNorm partial statistics are laid out per 128-row column tile (w2l_conv_stat_tiles)
-    const int ci = choose_cfg(N, Cin, Cout, Tout, Kw, stride, dil, stats_partial != nullptr);
+    const int ci = choose_cfg(N, Cin, Cout, Tout, Kw, stride, dil, stats_partial != nullptr);     // (a fused data gradient
+    // shares the table with forward launches: its N = 1, Tout = flat rows shape never coincides with one of theirs)
     W2L_CHECK_ARG(ci >= 0, "conv1d_igemm: no block shape fits LDS (Kw=%d dil=%d stride=%d)", Kw, dil, stride);
     const int pipe = (ci % kBaseCfgs) / kNumCfgs;
     const TileCfg& c = kCfgs[ci % kNumCfgs];
@@ -614,28 +723,38 @@ extern "C" int w2l_conv1d_igemm_ws(const void* xp, int64_t x_bstride, int64_t x_
     const size_t lds = 2 * (size_t)bm * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
     hipStream_t st = (hipStream_t)stream;
     switch (ci % kNumCfgs) {
-        case 0: return launch_cfg<2, 2, 2, 4>(p, tiles_m, lds, st, pipe);
-        case 1: return launch_cfg<2, 2, 3, 4>(p, tiles_m, lds, st, pipe);
-        case 2: return launch_cfg<2, 2, 4, 4>(p, tiles_m, lds, st, pipe);
-        case 3: return launch_cfg<2, 2, 5, 4>(p, tiles_m, lds, st, pipe);
-        case 4: return launch_cfg<4, 2, 3, 4>(p, tiles_m, lds, st, pipe);
-        case 5: return launch_cfg<4, 2, 4, 4>(p, tiles_m, lds, st, pipe);
-        case 6: return launch_cfg<2, 3, 2, 3>(p, tiles_m, lds, st, pipe);
-        case 7: return launch_cfg<2, 3, 3, 3>(p, tiles_m, lds, st, pipe);
-        case 8: return launch_cfg<2, 3, 4, 3>(p, tiles_m, lds, st, pipe);
-        case 9: return launch_cfg<2, 3, 5, 3>(p, tiles_m, lds, st, pipe);
-        case 10: return launch_cfg<2, 4, 2, 4>(p, tiles_m, lds, st, pipe);
-        case 11: return launch_cfg<2, 4, 3, 4>(p, tiles_m, lds, st, pipe);
-        case 12: return launch_cfg<2, 4, 4, 4>(p, tiles_m, lds, st, pipe);
-        case 13: return launch_cfg<2, 4, 5, 4>(p, tiles_m, lds, st, pipe);
-        case 14: return launch_cfg<2, 4, 6, 4>(p, tiles_m, lds, st, pipe);
-        case 15: return launch_cfg<2, 4, 7, 4>(p, tiles_m, lds, st, pipe);
-        case 16: return launch_cfg<2, 4, 8, 4>(p, tiles_m, lds, st, pipe);
-        case 17: return launch_cfg<2, 3, 4, 6>(p, tiles_m, lds, st, pipe);
-        case 18: return launch_cfg<2, 3, 5, 6>(p, tiles_m, lds, st, pipe);
-        case 19: return launch_cfg<2, 3, 6, 6>(p, tiles_m, lds, st, pipe);
-        default: return launch_cfg<2, 3, 7, 6>(p, tiles_m, lds, st, pipe);
+        case 0: return launch_cfg<2, 2, 2, 4>(p, tiles_m, lds, st, pipe, epi);
+        case 1: return launch_cfg<2, 2, 3, 4>(p, tiles_m, lds, st, pipe, epi);
+        case 2: return launch_cfg<2, 2, 4, 4>(p, tiles_m, lds, st, pipe, epi);
+        case 3: return launch_cfg<2, 2, 5, 4>(p, tiles_m, lds, st, pipe, epi);
+        case 4: return launch_cfg<4, 2, 3, 4>(p, tiles_m, lds, st, pipe, epi);
+        case 5: return launch_cfg<4, 2, 4, 4>(p, tiles_m, lds, st, pipe, epi);
+        case 6: return launch_cfg<2, 3, 2, 3>(p, tiles_m, lds, st, pipe, epi);
+        case 7: return launch_cfg<2, 3, 3, 3>(p, tiles_m, lds, st, pipe, epi);
+        case 8: return launch_cfg<2, 3, 4, 3>(p, tiles_m, lds, st, pipe, epi);
+        case 9: return launch_cfg<2, 3, 5, 3>(p, tiles_m, lds, st, pipe, epi);
+        case 10: return launch_cfg<2, 4, 2, 4>(p, tiles_m, lds, st, pipe, epi);
+        case 11: return launch_cfg<2, 4, 3, 4>(p, tiles_m, lds, st, pipe, epi);
+        case 12: return launch_cfg<2, 4, 4, 4>(p, tiles_m, lds, st, pipe, epi);
+        case 13: return launch_cfg<2, 4, 5, 4>(p, tiles_m, lds, st, pipe, epi);
+        case 14: return launch_cfg<2, 4, 6, 4>(p, tiles_m, lds, st, pipe, epi);
+        case 15: return launch_cfg<2, 4, 7, 4>(p, tiles_m, lds, st, pipe, epi);
+        case 16: return launch_cfg<2, 4, 8, 4>(p, tiles_m, lds, st, pipe, epi);
+        case 17: return launch_cfg<2, 3, 4, 6>(p, tiles_m, lds, st, pipe, epi);
+        case 18: return launch_cfg<2, 3, 5, 6>(p, tiles_m, lds, st, pipe, epi);
+        case 19: return launch_cfg<2, 3, 6, 6>(p, tiles_m, lds, st, pipe, epi);
+        default: return launch_cfg<2, 3, 7, 6>(p, tiles_m, lds, st, pipe, epi);
     }
+}
+
+extern "C" int w2l_conv1d_dgrad_bnreduce_ws(const void* dy, int64_t dy_rows_total, const void* w_dgr, void* dxp, float* partial,
+                                            const w2l_bnact_t* d, int pad_l, int pad_r, int pad_mode, int per, int Cconv_out,
+                                            int flat_rows, int Kw, int dil, void* splitk_ws, int64_t splitk_ws_bytes,
+                                            void* stream) {
+    W2L_CHECK_ARG(d != nullptr, "conv1d_dgrad_bnreduce: null descriptor");
+    const BnBwdArgs bb{d, pad_l, pad_r, pad_mode, per};
+    return igemm_launch(dy, dy_rows_total * Cconv_out, dy_rows_total, w_dgr, dxp, 0, 0, nullptr, partial, 1, Cconv_out, d->C,
+                        flat_rows, Kw, 1, dil, splitk_ws, splitk_ws_bytes, stream, &bb);
 }
 
 extern "C" int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y,
@@ -714,6 +833,20 @@ extern "C" int w2l_conv1d_igemm_tune_ws(const void* xp, int64_t x_bstride, int64
     std::lock_guard<std::mutex> lock(g_tuned_mu);
     g_tuned[key] = best;
     return 0;
+}
+
+// measure-and-pick for a fused data gradient: the candidates run with the fused epilogue (SYNCHRONISING; warm-up only)
+extern "C" int w2l_conv1d_dgrad_bnreduce_tune_ws(const void* dy, int64_t dy_rows_total, const void* w_dgr, void* dxp,
+                                                 float* partial, const w2l_bnact_t* d, int pad_l, int pad_r, int pad_mode,
+                                                 int per, int Cconv_out, int flat_rows, int Kw, int dil, int reps,
+                                                 void* splitk_ws, int64_t splitk_ws_bytes, void* stream) {
+    W2L_CHECK_ARG(d != nullptr, "conv1d_dgrad_bnreduce_tune: null descriptor");
+    const BnBwdArgs bb{d, pad_l, pad_r, pad_mode, per};
+    g_tune_bb = &bb;
+    const int rc = w2l_conv1d_igemm_tune_ws(dy, dy_rows_total * Cconv_out, dy_rows_total, w_dgr, dxp, 0, nullptr, partial, 1,
+                                            Cconv_out, d->C, flat_rows, Kw, 1, dil, reps, splitk_ws, splitk_ws_bytes, stream);
+    g_tune_bb = nullptr;
+    return rc;
 }
 
 extern "C" int w2l_conv1d_igemm_tune(const void* xp, int64_t x_bstride, int64_t x_rows_total, const void* w, void* y,

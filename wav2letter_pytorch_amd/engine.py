@@ -311,6 +311,10 @@ _retired_ws = []                   # outgrown workspaces (grown only while shape
 # W2L_DETERMINISTIC=1: split weight-gradient reductions go through slabs summed in a fixed order instead of fp32 atomics
 # (bit-reproducible gradients, no zero fills) -- measured 6 % slower on the Wav2Letter table (943 vs 1004 TFLOP/s), so opt-in
 DETERMINISTIC_WGRAD = os.environ.get('W2L_DETERMINISTIC', '0') == '1'
+# the BatchNorm-backward reduction of a layer is formed in the epilogue of the data-gradient convolution that produces the
+# gradient wrt its output (w2l_conv1d_dgrad_bnreduce_ws): one kernel less per layer on the backward critical path, where it
+# queued behind the weight-gradient blocks of the side stream.  W2L_FUSED_BN_REDUCE=0: separate w2l_bn_act_bwd_reduce pass.
+FUSED_BN_REDUCE = os.environ.get('W2L_FUSED_BN_REDUCE', '1') != '0'
 
 
 def _wgrad_workspace(dev, cin, cout, kw):
@@ -667,7 +671,7 @@ class StackEngine:
 
     def _dw_backward(self, dwc: ConvSpec, dmid, src: Act, mid: Act, need_dx: bool, grads):
         """depthwise weight gradient (+ data gradient) from the gradient wrt the pointwise conv's input"""
-        g, _, _, _, per = dmid
+        g, _, _, _, per = dmid[:5]
         N, cp = src.N, src.CP
         dev = g.device
         row_off = src.pad_l - dwc.pad_l
@@ -825,8 +829,19 @@ class StackEngine:
         self._wgrad(head, pk, dy_hi, dy_lo, hh, Th, last, grads)
         if head.bias is not None:
             grads[id(head.bias)] = colsum[: head.cout]          # travels with the pool
-        act_grads[len(acts) - 1].append(self._dgrad(head, pk, dy_hi, dy_lo, hh, Th, last))
+        act_grads[len(acts) - 1].append(self._dgrad(head, pk, dy_hi, dy_lo, hh, Th, last, self._producer(ctx, len(acts) - 1)))
         return pool_off
+
+    def _producer(self, ctx, act_index: int):
+        """the unit context whose BatchNorm-backward sums can be formed by the data gradient wrt activation ``act_index``
+        (None: the spectrogram, a unit with a residual branch / without BatchNorm, the fp32 parity mode, or switched off)"""
+        if not FUSED_BN_REDUCE or self.precise or act_index < 1:
+            return None
+        uc = ctx['units'][act_index - 1]
+        u = uc.unit
+        if u.res is not None or not u.main.has_bn or uc.y is None or uc.y.dtype != torch.bfloat16:
+            return None
+        return (uc, ctx['training'])
 
     def _units_backward(self, ctx, act_grads, small_pool, pool_off, grads, batch_stats: bool):
         """the units in reverse: BatchNorm / activation backward -> dy -> weight gradient (side stream) -> data gradient"""
@@ -851,11 +866,17 @@ class StackEngine:
             g2 = self._gsrc(srcs[1]) if len(srcs) > 1 else None
             sums = None
             if u.main.has_bn or (u.res is not None and u.res.has_bn):
-                nb = lib.w2l_bn_bwd_blocks(N, Tout, coutp)
                 ncomp = 4 if u.res is not None else 2
-                partial = torch.empty(nb, ncomp, coutp, dtype=torch.float32, device=dev)
-                check(lib.w2l_bn_act_bwd_reduce(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(partial),
-                                                st()), 'w2l_bn_act_bwd_reduce')
+                fused = [s_[5] for s_ in srcs if len(s_) > 5 and s_[5] is not None]
+                if len(fused) == len(srcs) and ncomp == 2:
+                    # every gradient source was a data-gradient convolution that formed the sums in its epilogue
+                    partial = fused[0] if len(fused) == 1 else torch.cat(fused, 0)
+                    nb = partial.shape[0]
+                else:
+                    nb = lib.w2l_bn_bwd_blocks(N, Tout, coutp)
+                    partial = torch.empty(nb, ncomp, coutp, dtype=torch.float32, device=dev)
+                    check(lib.w2l_bn_act_bwd_reduce(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(partial),
+                                                    st()), 'w2l_bn_act_bwd_reduce')
                 sums = small_pool[pool_off: pool_off + 4 * coutp].view(4, coutp)
                 pool_off += 4 * coutp
                 check(lib.w2l_bn_bwd_finalize(ptr(partial), nb, coutp, ncomp, ptr(sums), st()), 'w2l_bn_bwd_finalize')
@@ -896,12 +917,12 @@ class StackEngine:
                 else:
                     self._set(grads, main.bias, self._dy_colsum(dy_hi, dy_lo, h1, N, Tout, coutp, main.cout))
             if u.dw is not None:
-                dmid = self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src)
+                dmid = self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src)      # (wrt the depthwise output: no BatchNorm there)
                 gsrc = self._dw_backward(u.dw, dmid, acts[u.src], uc.mid, need_dx_main, grads)
                 if gsrc is not None:
                     act_grads[u.src].append(gsrc)
             elif need_dx_main:
-                act_grads[u.src].append(self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src))
+                act_grads[u.src].append(self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, self._producer(ctx, u.src)))
             if res is not None:
                 pkr = pack_weights(res, precise)
                 rsrc = acts[u.res_src]
@@ -912,7 +933,8 @@ class StackEngine:
                     else:
                         self._set(grads, res.bias, self._dy_colsum(dy2_hi, dy2_lo, h2, N, Tout, coutp, res.cout))
                 if self._needs_grad(u.res_src, ctx):
-                    act_grads[u.res_src].append(self._dgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc))
+                    act_grads[u.res_src].append(self._dgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc,
+                                                            self._producer(ctx, u.res_src)))
     # ------------------------------------------------------------------ helpers
     def _needs_grad(self, act_index: int, ctx=None) -> bool:
         # the spectrogram needs no gradient in training (base_asr_models.py:78-85); computed only on request
@@ -924,7 +946,7 @@ class StackEngine:
         N, C0, T0 = ctx['x_shape']
         a0 = ctx['acts'][0]
         total = None
-        for (g, pl, pr, mode, per) in srcs:
+        for (g, pl, pr, mode, per, *_) in srcs:
             gv = g.view(N, per, a0.CP)[:, :pl + T0 + pr, :C0].float()
             core = gv[:, pl:pl + T0].clone()
             if mode == PAD_REFLECT:
@@ -971,7 +993,7 @@ class StackEngine:
         self._notify(param, grad, storage)
 
     def _gsrc(self, s) -> GradSrc:
-        t, pl, pr, mode, rows = s
+        t, pl, pr, mode, rows = s[:5]
         g = GradSrc()
         g.dxp = t.data_ptr()
         g.f32 = int(t.dtype == torch.float32)
@@ -1084,7 +1106,35 @@ class StackEngine:
             g = g[:cout, :cin, :]
         self._set(grads, w, g, storage=dw)
 
-    def _dgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act):
+    def _dgrad_fused(self, conv: ConvSpec, pk: _PackedW, dy_hi, halo, hb, per, flat_rows, total, dxp, src: Act, producer,
+                     flops) -> torch.Tensor:
+        """data gradient + the BatchNorm-backward sums of the layer that produced ``src`` (w2l_conv1d_dgrad_bnreduce_ws);
+        returns partial [tiles][2][C]"""
+        uc, training = producer
+        dev = dxp.device
+        p = uc.unit.drop_p if (training and uc.mask is not None) else 0.0
+        d = self._desc(uc, src.N, src.T, src.CP, p, uc.lens_out)
+        tiles = lib.w2l_conv_stat_tiles(1, flat_rows)
+        partial = torch.empty(tiles, 2, src.CP, dtype=torch.float32, device=dev)
+        row_off = halo - hb
+        dy_ptr = C.c_void_p(dy_hi.data_ptr() + row_off * pk.coutp * 2)
+        rows_total = total - row_off
+        ws = _splitk_workspace(dev, 1, pk.cinp, flat_rows)
+        st = stream_ptr()
+        args = (dy_ptr, rows_total, ptr(pk.dgr_hi), ptr(dxp), ptr(partial), C.byref(d), conv.pad_l, conv.pad_r, conv.pad_mode,
+                per, pk.coutp, flat_rows, conv.kernel, conv.dilation)
+        if AUTOTUNE:
+            key = ('dgrad+bn', pk.coutp, pk.cinp, flat_rows, conv.kernel, conv.dilation, dev.index)
+            if key not in _tuned_shapes:
+                _tuned_shapes.add(key)
+                _tune_state['dirty'] = True
+                check(lib.w2l_conv1d_dgrad_bnreduce_tune_ws(*args, TUNE_REPS, ptr(ws), ws.numel(), st),
+                      'w2l_conv1d_dgrad_bnreduce_tune_ws')
+        with _timed('conv_igemm_kernel', flops):
+            check(lib.w2l_conv1d_dgrad_bnreduce_ws(*args, ptr(ws), ws.numel(), st), 'w2l_conv1d_dgrad_bnreduce_ws')
+        return partial
+
+    def _dgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, producer=None):
         """dXpad (gradient wrt the conv's padded input) through the same implicit-GEMM kernel, run over
         the shared-halo dy buffer as ONE sequence of N*(Tout+halo) rows: tiles never straddle a partially
         filled per-utterance remainder.  Row v of utterance n lands at output row n*(Tout+halo) + v."""
@@ -1112,9 +1162,13 @@ class StackEngine:
         flat_rows = N * per
         dxp = torch.empty(flat_rows, pk.cinp, dtype=torch.float32 if self.precise else torch.bfloat16, device=dev)
         total = dy_hi.shape[0]
+        flops = 2.0 * N * Tout * conv.cout * conv.cin * conv.kernel
+        if producer is not None and conv.stride == 1 and per >= Tp and src.CP == pk.cinp:
+            partial = self._dgrad_fused(conv, pk, dy_hi, halo, hb, per, flat_rows, total, dxp, src, producer, flops)
+            return (dxp, conv.pad_l, conv.pad_r, conv.pad_mode, per, partial)
         dyact = Act(dy_hi, dy_lo, 1, total, pk.coutp, pk.coutp, 0, 0, PAD_ZERO)
         _igemm(dyact, halo - hb, pk.dgr_hi, pk.dgr_lo, dxp, None, None, pk.coutp, pk.cinp, flat_rows, conv.kernel, 1,
-               conv.dilation, self.precise, alg_flops=2.0 * N * Tout * conv.cout * conv.cin * conv.kernel)
+               conv.dilation, self.precise, alg_flops=flops)
         if per < Tp:                      # strided case: the last (Tp - Tup - hb) padded rows receive no gradient
             full = torch.zeros(N, Tp, pk.cinp, dtype=dxp.dtype, device=dev)
             full[:, :per] = dxp.view(N, per, pk.cinp)
