@@ -377,12 +377,6 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
         if (p.bias && co_ok) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s1[mi][r] = 0.f; s2[mi][r] = 0.f; }
-        // EPI 1: BatchNorm constants of this lane's four channels (the producing layer's, see IgemmParams)
-        f32x4 bsc = f32x4{1.f, 1.f, 1.f, 1.f}, bsh = f32x4{0.f, 0.f, 0.f, 0.f}, bmu = bsh, bis = bsh;
-        if (EPI == 1 && co_ok) {
-            if (p.bn_scale) { bsc = *reinterpret_cast<const f32x4*>(p.bn_scale + co); bsh = *reinterpret_cast<const f32x4*>(p.bn_shift + co); }
-            if (p.bn_mean) { bmu = *reinterpret_cast<const f32x4*>(p.bn_mean + co); bis = *reinterpret_cast<const f32x4*>(p.bn_invstd + co); }
-        }
 #pragma unroll
         for (int ni = 0; ni < NS; ++ni) {
             const int t = t0 + (wn * NS + ni) * 16 + fr;
@@ -403,37 +397,93 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
                 if constexpr (EPI == 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { s1[mi][r] += v[r]; s2[mi][r] += v[r] * v[r]; }
-                } else {
-                    // flat output row t = padded row u of utterance nu; its gradient belongs to source frame ts (itself, or
-                    // its mirror image when the row is a reflected halo row -- the fold of bn_act.hip add_grad8 is linear,
-                    // so every padded row simply counts with its source frame's gate and xhat)
-                    const int nu = (int)((unsigned)t / (unsigned)p.bn_per);
-                    const int u = t - nu * p.bn_per;
-                    int ts = u - p.bn_pad_l;
-                    bool live = u < p.bn_Tp;
-                    if (ts < 0 || ts >= p.bn_T) {
-                        if (p.bn_pad_mode == 1) ts = ts < 0 ? -ts : 2 * (p.bn_T - 1) - ts;
-                        else live = false;
-                    }
-                    if (live && p.bn_lens && ts >= p.bn_lens[nu]) live = false;     // masked frame: no gradient through it
-                    if (live) {
-                        const int64_t row = (int64_t)nu * p.bn_T + ts;
-                        const u16x4 yv = *reinterpret_cast<const u16x4*>(p.bn_y + row * Cout + co);
-                        unsigned bits = 0xFu;
-                        if (p.bn_mask) bits = (unsigned)p.bn_mask[row * (Cout >> 3) + (co >> 3)] >> (co & 4);
+                }
+            }
+        }
+    }
+    if constexpr (EPI == 1) {
+        // ---- BatchNorm-backward sums of the layer that produced this conv's input (see IgemmParams).  Flat output row t is
+        // padded row u of utterance nu; its gradient belongs to source frame ts (itself, or its mirror image when the row is
+        // a reflected halo row -- the fold of bn_act.hip add_grad8 is linear, so every padded row simply counts with its
+        // source frame's gate and xhat).  The y / mask loads of CH channel blocks are issued together, from clamped (always
+        // valid) addresses and outside any branch, so they overlap instead of forming one dependent chain per element.
+        int64_t yrow[NS];
+        bool live[NS];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float yf = bf16_bits_to_f32(yv[r]);
-                            const bool keep = (bits >> r) & 1u;
-                            float z = yf * bsc[r] + bsh[r];
-                            z = keep ? z * p.bn_gk : 0.f;
-                            bool pass = keep;
-                            if (p.bn_act == 1) pass = pass && z >= 0.f && z <= 20.f;
-                            else if (p.bn_act == 2) pass = pass && z > 0.f;
-                            const float g = pass ? v[r] * p.bn_gk : 0.f;
-                            s1[mi][r] += g;
-                            s2[mi][r] += g * ((yf - bmu[r]) * bis[r]);
-                        }
+        for (int ni = 0; ni < NS; ++ni) {
+            const int t = t0 + (wn * NS + ni) * 16 + fr;
+            const int tc = t < Tout ? t : Tout - 1;
+            const int nu = (int)((unsigned)tc / (unsigned)p.bn_per);
+            const int u = tc - nu * p.bn_per;
+            int ts = u - p.bn_pad_l;
+            bool lv = t < Tout && u < p.bn_Tp;
+            if (ts < 0 || ts >= p.bn_T) {
+                if (p.bn_pad_mode == 1) ts = ts < 0 ? -ts : 2 * (p.bn_T - 1) - ts;
+                else lv = false;
+            }
+            ts = ts < 0 ? 0 : (ts >= p.bn_T ? p.bn_T - 1 : ts);
+            if (lv && p.bn_lens && ts >= p.bn_lens[nu]) lv = false;          // masked frame: no gradient through it
+            live[ni] = lv;
+            yrow[ni] = (int64_t)nu * p.bn_T + ts;
+        }
+        constexpr int CH = MS % 4 == 0 ? 4 : (MS % 2 == 0 ? 2 : 1);
+        __syncthreads();                               // main-loop LDS is dead from here: the sums go straight into it
+        float* red = reinterpret_cast<float*>(smem);   // [NW][2][BM]
+#pragma unroll
+        for (int m0i = 0; m0i < MS; m0i += CH) {
+            u16x4 yv[CH][NS];
+            unsigned mb[CH][NS];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                int co = m0 + (wm * MS + m0i + c) * 16 + fq * 4;
+                co = co < Cout ? co : Cout - 4;
+#pragma unroll
+                for (int ni = 0; ni < NS; ++ni) {
+                    yv[c][ni] = *reinterpret_cast<const u16x4*>(p.bn_y + yrow[ni] * Cout + co);
+                    mb[c][ni] = p.bn_mask ? (unsigned)p.bn_mask[yrow[ni] * (Cout >> 3) + (co >> 3)] : 0xFFu;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int mi = m0i + c;
+                const int co = m0 + (wm * MS + mi) * 16 + fq * 4;
+                const bool co_ok = co < Cout;
+                const int cc = co_ok ? co : Cout - 4;
+                f32x4 bsc = f32x4{1.f, 1.f, 1.f, 1.f}, bsh = f32x4{0.f, 0.f, 0.f, 0.f}, bmu = bsh, bis = bsh;
+                if (p.bn_scale) { bsc = *reinterpret_cast<const f32x4*>(p.bn_scale + cc); bsh = *reinterpret_cast<const f32x4*>(p.bn_shift + cc); }
+                if (p.bn_mean) { bmu = *reinterpret_cast<const f32x4*>(p.bn_mean + cc); bis = *reinterpret_cast<const f32x4*>(p.bn_invstd + cc); }
+#pragma unroll
+                for (int ni = 0; ni < NS; ++ni) {
+                    const bool on = live[ni] && co_ok;
+                    const unsigned bits = mb[c][ni] >> (co & 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float yf = bf16_bits_to_f32(yv[c][ni][r]);
+                        const bool keep = (bits >> r) & 1u;
+                        float z = yf * bsc[r] + bsh[r];
+                        z = keep ? z * p.bn_gk : 0.f;
+                        bool pass = keep && on;
+                        if (p.bn_act == 1) pass = pass && z >= 0.f && z <= 20.f;
+                        else if (p.bn_act == 2) pass = pass && z > 0.f;
+                        const float g = pass ? acc[mi][ni][r] * p.bn_gk : 0.f;
+                        s1[mi][r] += g;
+                        s2[mi][r] += g * ((yf - bmu[r]) * bis[r]);
+                    }
+                }
+                // this channel block is complete: combine the 16 column lanes and park the sums in LDS right away (keeping
+                // all MS blocks' sums in registers next to the accumulators spills)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = s1[mi][r], b = s2[mi][r];
+#pragma unroll
+                    for (int m = 1; m < 16; m <<= 1) {
+                        a += __shfl_xor(a, m, 64);
+                        b += __shfl_xor(b, m, 64);
+                    }
+                    if (fr == 0) {
+                        const int cl = (wm * MS + mi) * 16 + fq * 4 + r;
+                        red[(wn * 2 + 0) * BM + cl] = a;
+                        red[(wn * 2 + 1) * BM + cl] = b;
                     }
                 }
             }
@@ -444,24 +494,26 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
         constexpr int HALVES = BN / 128;
         constexpr int WPH = NW / HALVES;               // N-waves per 128-column half
         static_assert(BN % 128 == 0 || true, "");
-        __syncthreads();                               // main-loop LDS is dead from here
         float* red = reinterpret_cast<float*>(smem);   // [NW][2][BM]
+        if constexpr (EPI == 0) {
+            __syncthreads();                           // main-loop LDS is dead from here
 #pragma unroll
-        for (int mi = 0; mi < MS; ++mi)
+            for (int mi = 0; mi < MS; ++mi)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float a = s1[mi][r], b = s2[mi][r];
+                for (int r = 0; r < 4; ++r) {
+                    float a = s1[mi][r], b = s2[mi][r];
 #pragma unroll
-                for (int m = 1; m < 16; m <<= 1) {
-                    a += __shfl_xor(a, m, 64);
-                    b += __shfl_xor(b, m, 64);
+                    for (int m = 1; m < 16; m <<= 1) {
+                        a += __shfl_xor(a, m, 64);
+                        b += __shfl_xor(b, m, 64);
+                    }
+                    if (fr == 0) {
+                        const int cl = (wm * MS + mi) * 16 + fq * 4 + r;
+                        red[(wn * 2 + 0) * BM + cl] = a;
+                        red[(wn * 2 + 1) * BM + cl] = b;
+                    }
                 }
-                if (fr == 0) {
-                    const int cl = (wm * MS + mi) * 16 + fq * 4 + r;
-                    red[(wn * 2 + 0) * BM + cl] = a;
-                    red[(wn * 2 + 1) * BM + cl] = b;
-                }
-            }
+        }
         __syncthreads();
         const int tiles128 = (Tout + 127) / 128;
         for (int idx = tid; idx < BM * HALVES; idx += NT) {
