@@ -259,6 +259,21 @@ def test_conv_wgrad_every_plan(L):
                 assert relerr(outs[1].cpu().permute(1, 2, 0), 2 * wr.grad) < 2e-3, (splits, order)
             finally:
                 L.lib.w2l_wgrad_force_plan(0, -1)
+    # stream-K decomposition (order bit 1): persistent blocks cut the (tile, step) space into equal ranges that straddle
+    # tile boundaries (18 tiles x 18 steps over 20 blocks here); whole tiles are stored, pieces are added atomically
+    for order in (2, 3):
+        L.lib.w2l_wgrad_force_plan(0, order)
+        try:
+            assert L.lib.w2l_wgrad_needs_zero(N, Cin, Cout, Tout, Kw) == 1
+            assert L.lib.w2l_wgrad_needs_zero_ws(N, Cin, Cout, Tout, Kw, ws.numel()) == 0      # a workspace means the slab plan
+            dw = torch.zeros(Kw, Cout, Cin, device='cuda')
+            for rep in (1, 2):               # the second launch accumulates on top of the first
+                L.check(L.lib.w2l_conv1d_wgrad(C.c_void_p(dyh.data_ptr() + hb * Cout * 2), drows * Cout, L.ptr(xh), rows * Cin,
+                                               N * rows, L.ptr(dw), N, Cin, Cout, Tout, Kw, s, d, int(rep == 2), L.stream_ptr()))
+                torch.cuda.synchronize()
+                assert relerr(dw.cpu().permute(1, 2, 0), rep * wr.grad) < 2e-3, (order, rep)
+        finally:
+            L.lib.w2l_wgrad_force_plan(0, -1)
 
 
 @pytest.mark.parametrize('case', [c for c in CONV_CASES if c[4] == 1])

@@ -401,6 +401,29 @@ def test_deterministic_mode_is_bit_reproducible(monkeypatch):
         assert scale_err(ga.cpu().numpy(), gc.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('order', [2, 3])
+def test_stream_k_weight_gradients_end_to_end(order):
+    """every weight gradient of a step through the stream-K plan of conv_wgrad_kernel (forced; the tuner picks it per
+    shape): parity with the oracle as for the split-K plans.  The force hook is thread-local, so backward runs on this thread."""
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd import _lib as L
+    from wav2letter_pytorch_amd import engine as E
+    layers = [(128, 11, 2, 1, 0.0), (256, 13, 1, 1, 0.0), (320, 29, 1, 2, 0.0), (128, 5, 1, 1, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=71)
+    x, il, tg, tl = O.synthetic_batch(6, 700, seed=72, s_lo=20, s_hi=60)
+    old = E.AUTOTUNE
+    E.AUTOTUNE = False
+    L.lib.w2l_wgrad_force_plan(0, order)
+    try:
+        with torch.autograd.set_multithreading_enabled(False):
+            model = build_w2l(layers, sd, 'bf16').train()
+            errs, stats, *_ = compare_step(model, layers, sd, x, il, tg, tl, 'bf16')
+    finally:
+        L.lib.w2l_wgrad_force_plan(0, -1)
+        E.AUTOTUNE = old
+    check(errs, stats, 'bf16')
+
+
 def test_graphed_train_step():
     """the step captured into a hipGraph (graph.GraphedTrainStep): replays train like the eager step, and dropout masks
     change from replay to replay (device-side Philox offset)"""

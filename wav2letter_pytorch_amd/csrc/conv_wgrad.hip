@@ -40,6 +40,7 @@ struct WgradParams {
     int N, Cin, Cout, Tout, Kw, stride, dil;
     int tiles_m, tiles_n, kgroups, tsteps, total_steps, steps_per_split, atomic;
     int order;                 // block order inside a split: 1 = tap group fastest, 0 = co tile fastest
+    int streamk;               // 1: `gridDim.x` persistent blocks share the (tile, K step) space in equal contiguous ranges
     int xrows_lds;
     // split-K through a workspace (w2l_conv1d_wgrad_ws): partial tiles go to fp32 slabs, the block that draws a tile's last
     // ticket sums them in split order and writes dw with plain stores -- no atomics, no zero fill, bit-reproducible
@@ -74,7 +75,9 @@ __device__ __forceinline__ bf16x4 tr_read(unsigned lds_byte_addr) {      // 32-b
 
 // S1: the conv stride is 1 (every layer but a model's first): the row offsets of the k-substeps become ds_read immediates
 // instead of per-step VALU adds (the K loop is issue-bound).
-template <int KWB, bool S1>
+// SK: the stream-K decomposition (a block walks up to three tile segments); compiled separately so that the classic
+// one-segment kernel keeps its scalar-register budget (the segment loop's extra live scalars cost it 16 v_readlane per step).
+template <int KWB, bool S1, bool SK>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
@@ -82,32 +85,36 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    // (blockIdx.y, blockIdx.x) -> (split, tile).  The XCD remap runs on the linear block id because that is what the
-    // hardware deals round-robin to the XCDs: the ~64 blocks resident on one XCD are then consecutive tiles of ONE split.
-    // order 1 (tap group fastest): they cover all tap groups of a few co tiles of one ci tile, i.e. stream the same few
-    //          dy tiles and overlapping x windows through that XCD's L2;
-    // order 0 (co tile fastest, then ci tile, then tap group): all (co, ci) tiles of one or two tap groups.
-    // Which one wins depends on the shape (measured by w2l_conv1d_wgrad_tune).
-    int lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int split = lin / gridDim.x;
-    int tile = lin - split * gridDim.x;
-    const int tile_id = tile;
-    int tm, tn, kw0;
-    if (p.order) {
-        kw0 = (tile % p.kgroups) * KWB;            // first tap of this block's group
-        tile /= p.kgroups;
-        tm = tile % p.tiles_m;
-        tn = tile / p.tiles_m;
+    // ---- work decomposition.  The launch's work is the (tile, K step) space, tile-major; a block owns ONE contiguous range
+    // [w, w_end) of it:
+    //  * classic: grid = (tiles, splits); block (tile, split) owns steps [split*steps_per_split, ...) of its tile -- one
+    //    segment.  Whole rounds of the 512 resident blocks need tiles*splits to be a multiple of 512, which the big layers
+    //    miss (896x896x29: 735 tiles = 1.44 rounds at split 1; split 2 pays 186 MB of fp32 atomics for 93 MB of dw);
+    //  * stream-K (p.streamk): gridDim.x persistent blocks (one per resident slot) cut the whole space into equal ranges.  A
+    //    range spans at most three tiles; a tile a block covers completely is written with plain stores, the pieces of a
+    //    shared tile are added atomically (into the zero-filled dw), so the chip stays full for the whole launch and only
+    //    one piece per block -- not every tile times the split factor -- goes through atomics.
+    // The XCD remap runs on the linear block id because that is what the hardware deals round-robin to the XCDs: the ~64
+    // blocks resident on one XCD are then consecutive tiles.  order 1 (tap group fastest): all tap groups of a few co tiles
+    // of one ci tile, i.e. the same few dy tiles and overlapping x windows stream through that XCD's L2; order 0 (co tile
+    // fastest, then ci tile, then tap group): all (co, ci) tiles of one or two tap groups.  Measured per shape.
+    const int lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int S = p.total_steps;
+    int w, w_end;                                  // (tiles * S < 2^31 is checked by the launcher)
+    int split = 0;
+    if constexpr (SK) {
+        const int64_t W = (int64_t)p.tiles_m * p.tiles_n * p.kgroups * S;
+        w = (int)(W * lin / gridDim.x);
+        w_end = (int)(W * (lin + 1) / gridDim.x);
     } else {
-        tm = tile % p.tiles_m;
-        tile /= p.tiles_m;
-        tn = tile % p.tiles_n;
-        kw0 = (tile / p.tiles_n) * KWB;
+        split = lin / gridDim.x;
+        const int tl = lin - split * gridDim.x;
+        w = tl * S + split * p.steps_per_split;
+        w_end = w + p.steps_per_split;
+        if (w_end > (tl + 1) * S) w_end = (tl + 1) * S;
     }
-    const int ntaps = (p.Kw - kw0) < KWB ? (p.Kw - kw0) : KWB;
-    const int m0 = tm * BM, c0 = tn * BNC;
+    int tile_id = 0, kw0 = 0, ntaps = KWB, m0 = 0, c0 = 0, shift = 0;
     const int s = S1 ? 1 : p.stride, d = p.dil;
-    const int shift = kw0 * d;
     const int xrows = p.xrows_lds;                 // (BT-1)*s + (KWB-1)*d + 1 rounded up to 4
 
     char* abuf0 = smem;                            // dy tile  [BT][128 co]
@@ -120,27 +127,47 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     const int srow = lane >> 4;                    // 0..3
     const int schunk = lane & 15;                  // LDS 16-byte chunk
     unsigned a_voff[BT / 16];                      // byte offset of this lane's 16 B inside the step's dy tile
-#pragma unroll
-    for (int i = 0; i < BT / 16; ++i) {
-        const int r = (wave * (BT / 16) + i) * 4 + srow;
-        const int g = schunk ^ (row_key(r) << 1);
-        int co = m0 + g * 8;
-        co = co < p.Cout ? co : p.Cout - 8;
-        a_voff[i] = ((unsigned)r * (unsigned)p.Cout + (unsigned)co) * 2u;
-    }
     const unsigned x_max_row = (unsigned)p.x_max_row;          // rows * Cin * 2 < 2^32 is checked by the launcher
-    // the x window likewise (stride 1, <= 20 four-row groups): per-lane offsets inside the window, computed once
+    // the x window likewise (stride 1, <= 20 four-row groups): per-lane offsets inside the window, computed once per tile
     constexpr int XG = 5;
     const bool x_fast = S1 && (xrows >> 2) <= 4 * XG;
     unsigned x_voff[XG];
+    // tile id -> (tap group, co tile, ci tile) and everything that depends on them
+    auto set_tile = [&](int tile) {
+        tile_id = tile;
+        int tm, tn;
+        if (p.order) {
+            kw0 = (tile % p.kgroups) * KWB;            // first tap of this block's group
+            tile /= p.kgroups;
+            tm = tile % p.tiles_m;
+            tn = tile / p.tiles_m;
+        } else {
+            tm = tile % p.tiles_m;
+            tile /= p.tiles_m;
+            tn = tile % p.tiles_n;
+            kw0 = (tile / p.tiles_n) * KWB;
+        }
+        ntaps = (p.Kw - kw0) < KWB ? (p.Kw - kw0) : KWB;
+        m0 = tm * BM;
+        c0 = tn * BNC;
+        shift = kw0 * d;
 #pragma unroll
-    for (int i = 0; i < XG; ++i) {
-        const int r = (wave + 4 * i) * 4 + srow;
-        const int g = schunk ^ (row_key(r) << 1);
-        int ci = c0 + g * 8;
-        ci = ci < p.Cin ? ci : p.Cin - 8;
-        x_voff[i] = ((unsigned)r * (unsigned)p.Cin + (unsigned)ci) * 2u;
-    }
+        for (int i = 0; i < BT / 16; ++i) {
+            const int r = (wave * (BT / 16) + i) * 4 + srow;
+            const int g = schunk ^ (row_key(r) << 1);
+            int co = m0 + g * 8;
+            co = co < p.Cout ? co : p.Cout - 8;
+            a_voff[i] = ((unsigned)r * (unsigned)p.Cout + (unsigned)co) * 2u;
+        }
+#pragma unroll
+        for (int i = 0; i < XG; ++i) {
+            const int r = (wave + 4 * i) * 4 + srow;
+            const int g = schunk ^ (row_key(r) << 1);
+            int ci = c0 + g * 8;
+            ci = ci < p.Cin ? ci : p.Cin - 8;
+            x_voff[i] = ((unsigned)r * (unsigned)p.Cin + (unsigned)ci) * 2u;
+        }
+    };
     auto stage = [&](char* adst, char* bdst, int n, int ts) {
         const int t0 = ts * BT;
         // dy rows t0..t0+63 (rows >= Tout are zero by contract)
@@ -171,16 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     };
 
     f32x4 acc[KWB][4][4];
-#pragma unroll
-    for (int tp = 0; tp < KWB; ++tp)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[tp][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int step_begin = split * p.steps_per_split;
-    int step_end = step_begin + p.steps_per_split;
-    if (step_end > p.total_steps) step_end = p.total_steps;
+    int step_begin = 0, step_end = 0;              // this segment's K steps inside its tile
 
     // ---- tr-read lane geometry: within a 16-lane group, lane 4q+pp supplies row q, columns 4pp..4pp+3.
     // LDS row of fragment (ks, h) = ks*32 + h*4 + (kgrp*8 + q) [+ tap*d for the x window]; the swizzle key only
@@ -301,8 +319,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         }
         step_body(nt_tag, std::true_type{}, nullptr, nullptr, 0, 0, false);
     };
+    for (;;) {
+    {   // ---- one segment: steps [step_begin, step_end) of tile w / S
+        const int tile = w / S;
+        step_begin = w - tile * S;
+        const int left = w_end - w;
+        step_end = (S - step_begin) < left ? S : step_begin + left;
+        set_tile(tile);
+    }
+#pragma unroll
+    for (int tp = 0; tp < KWB; ++tp)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[tp][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (KWB == 1 || ntaps == KWB) run(std::integral_constant<int, KWB>{});
     else run(std::integral_constant<int, 1>{});
+    // the read pointers were toggled once per non-last step: bring them back to buffer 0 for a following segment
+    if (step_end > step_begin && ((step_end - step_begin - 1) & 1)) toggle();
+    // a piece of a tile (stream-K) is added atomically; a tile this block covered completely is stored
+    // (with p.accumulate -- dw already holds earlier passes -- every piece adds)
+    const bool piece = SK && (p.accumulate || !(step_begin == 0 && step_end == S));
 
     // ---- split-K through slabs: publish the partial tile, draw a ticket; only the last arriver goes on.  Agent-scope
     // release before the ticket / acquire after it: correct wherever the tile's blocks ran (they are a whole grid row apart).
@@ -367,12 +404,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
                     const int co = m0 + wm * 64 + mi * 16 + fq * 4 + r;
                     if (co < p.Cout && ci < p.Cin) {
                         float* dst = base + (int64_t)co * p.Cin + ci;
-                        if (p.atomic) atomicAdd(dst, acc[tp][mi][ni][r]);          // several blocks per element (no workspace)
+                        if (p.atomic || piece) atomicAdd(dst, acc[tp][mi][ni][r]);  // several blocks per element (no workspace)
                         else if (p.accumulate) *dst += acc[tp][mi][ni][r];         // one block per element: plain read-add-store
                         else *dst = acc[tp][mi][ni][r];
                     }
                 }
             }
+    }
+    if constexpr (!SK) {
+        break;
+    } else {
+        w += step_end - step_begin;
+        if (w >= w_end) break;
+        __syncthreads();    // the next segment's LDS-DMA reuses buffers the slowest wave may still be reading
+    }
     }
 }
 
@@ -386,6 +431,10 @@ std::mutex g_wtuned_mu;
 thread_local int g_force_splits = 0;      // per calling thread, like g_force_cfg of the implicit GEMM
 thread_local int g_force_order = -1;
 constexpr int kDefaultOrder = 1;
+
+// `order` values: bit 0 = block order, bit 1 = stream-K decomposition (then the split count is not used)
+constexpr int kStreamK = 2;
+constexpr int kResidentBlocks = 512;       // 256 CUs x 2 blocks (LDS and registers both allow two)
 
 int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out, int* order_out = nullptr) {
     const int kwb = Kw > 1 ? KWB_DEFAULT : 1;
@@ -418,6 +467,17 @@ int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out, int
         double cost = rounds * steps * per_step + (s > 1 ? 0.5 * out_us * s : 0.0);
         if (cost < best_cost * 0.97) { best_cost = cost; best = s; }
     }
+    // stream-K: every resident slot busy for W / G steps, one atomically added piece per block
+    if (order_out && g_force_order < 0) {
+        const int64_t W = (int64_t)tiles * total;
+        int64_t G = W / 16;
+        if (G > kResidentBlocks) G = kResidentBlocks;
+        if (G >= 64) {
+            const double sk_cost = ((double)W / (double)G + 10.0) * t_step_us * (G <= 256 ? 0.6 : 1.0) +
+                                   0.5 * out_us * (double)G / (double)tiles;
+            if (sk_cost < best_cost * 0.95) *order_out |= kStreamK;
+        }
+    }
     return best;
 }
 
@@ -426,11 +486,12 @@ int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out, int
 // testing / profiling hook: pin the split count (0 = automatic) and the block order (-1 = automatic)
 extern "C" void w2l_wgrad_force_plan(int splits, int order) {
     g_force_splits = splits > 0 ? splits : 0;
-    g_force_order = order >= 0 ? (order ? 1 : 0) : -1;
+    g_force_order = order >= 0 ? (order & 3) : -1;       // bit 0: block order, bit 1: stream-K
 }
 
 extern "C" int w2l_wgrad_needs_zero(int N, int Cin, int Cout, int Tout, int Kw) {
-    return plan_splits(N, Cin, Cout, Tout, Kw, nullptr) > 1;
+    int order = 0;
+    return plan_splits(N, Cin, Cout, Tout, Kw, nullptr, &order) > 1 || (order & kStreamK);
 }
 
 constexpr size_t kWgradTicketBytes = 64 * 1024;
@@ -450,7 +511,9 @@ static bool wgrad_ws_ok(int Cin, int Cout, int Kw, int splits, const void* ws, i
 
 // with a workspace of ws_bytes: does the launch still add into dw with atomics (i.e. need a zero-filled dw)?
 extern "C" int w2l_wgrad_needs_zero_ws(int N, int Cin, int Cout, int Tout, int Kw, int64_t ws_bytes) {
-    const int splits = plan_splits(N, Cin, Cout, Tout, Kw, nullptr);
+    int order = 0;
+    const int splits = plan_splits(N, Cin, Cout, Tout, Kw, nullptr, &order);
+    if (ws_bytes <= 0 && (order & kStreamK)) return 1;          // stream-K pieces are added atomically (no workspace form)
     if (splits <= 1) return 0;
     return wgrad_ws_need(Cin, Cout, Kw, splits) <= (size_t)(ws_bytes > 0 ? ws_bytes : 0) ? 0 : 1;
 }
@@ -478,7 +541,12 @@ extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const voi
     p.N = N; p.Cin = Cin; p.Cout = Cout; p.Tout = Tout; p.Kw = Kw; p.stride = stride; p.dil = dil;
     p.tiles_m = (Cout + BM - 1) / BM;
     p.tiles_n = (Cin + BNC - 1) / BNC;
-    const int splits = plan_splits(N, Cin, Cout, Tout, Kw, &p.tsteps, &p.order);
+    int order = 0;
+    int splits = plan_splits(N, Cin, Cout, Tout, Kw, &p.tsteps, &order);
+    p.order = order & 1;
+    // stream-K is the atomic path's alternative to split-K: with a workspace (deterministic slabs) the classic plan runs
+    p.streamk = (order & kStreamK) && ws == nullptr ? 1 : 0;
+    if (p.streamk) splits = 1;
     p.total_steps = N * p.tsteps;
     p.steps_per_split = (p.total_steps + splits - 1) / splits;
     const bool slabs = splits > 1 && wgrad_ws_ok(Cin, Cout, Kw, splits, ws, ws_bytes);
@@ -493,23 +561,28 @@ extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const voi
     p.xrows_lds = (xr + 3) & ~3;
     const size_t lds = 2 * BT * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
     dim3 grid(p.tiles_m * p.tiles_n * p.kgroups, splits), block(256);
-    if (kwb == 2) {
-        if (stride == 1) {
-            W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<2, true>));
-            hipLaunchKernelGGL((conv_wgrad_kernel<2, true>), grid, block, lds, (hipStream_t)stream, p);
-        } else {
-            W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<2, false>));
-            hipLaunchKernelGGL((conv_wgrad_kernel<2, false>), grid, block, lds, (hipStream_t)stream, p);
-        }
-    } else {
-        if (stride == 1) {
-            W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<1, true>));
-            hipLaunchKernelGGL((conv_wgrad_kernel<1, true>), grid, block, lds, (hipStream_t)stream, p);
-        } else {
-            W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<1, false>));
-            hipLaunchKernelGGL((conv_wgrad_kernel<1, false>), grid, block, lds, (hipStream_t)stream, p);
-        }
+    if (p.streamk) {
+        // one block per resident slot, but at least ~16 K steps each (short ranges are all prologue and epilogue)
+        const int64_t W = (int64_t)grid.x * p.total_steps;
+        W2L_CHECK_ARG(W < (1LL << 31), "conv1d_wgrad: (tile, step) space exceeds 32 bits");
+        int64_t g = W / 16;
+        if (g > kResidentBlocks) g = kResidentBlocks;
+        if (g < 1) g = 1;
+        grid = dim3((unsigned)g, 1);
     }
+#define W2L_WGRAD_LAUNCH(K, S1_, SK_)                                                                     \
+    do {                                                                                                  \
+        W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<K, S1_, SK_>));                    \
+        hipLaunchKernelGGL((conv_wgrad_kernel<K, S1_, SK_>), grid, block, lds, (hipStream_t)stream, p);   \
+    } while (0)
+    if (p.streamk) {
+        if (kwb == 2) { if (stride == 1) W2L_WGRAD_LAUNCH(2, true, true); else W2L_WGRAD_LAUNCH(2, false, true); }
+        else { if (stride == 1) W2L_WGRAD_LAUNCH(1, true, true); else W2L_WGRAD_LAUNCH(1, false, true); }
+    } else {
+        if (kwb == 2) { if (stride == 1) W2L_WGRAD_LAUNCH(2, true, false); else W2L_WGRAD_LAUNCH(2, false, false); }
+        else { if (stride == 1) W2L_WGRAD_LAUNCH(1, true, false); else W2L_WGRAD_LAUNCH(1, false, false); }
+    }
+#undef W2L_WGRAD_LAUNCH
     W2L_CHECK_LAUNCH();
     return 0;
 }
@@ -542,12 +615,16 @@ extern "C" int w2l_conv1d_wgrad_tune_ws(const void* dy, int64_t dy_bstride, cons
     float best_ms = 1e30f;
     if (reps < 1) reps = 1;
     const size_t bytes = (size_t)Kw * Cout * Cin * sizeof(float);
-    for (int ci = 0; ci < 2 * (int)(sizeof(cands) / sizeof(cands[0])); ++ci) {
-        const int s = cands[ci >> 1], order = ci & 1;
-        if (s > total || s > 0xffff || (s > 1 && total / s < 4)) break;
+    const int ncand = 2 * (int)(sizeof(cands) / sizeof(cands[0]));
+    for (int ci = -2; ci < ncand; ++ci) {
+        // ci = -2, -1: the stream-K decomposition in both block orders (no workspace form: skipped in deterministic mode)
+        const bool sk = ci < 0;
+        if (sk && ws != nullptr) continue;
+        const int s = sk ? 1 : cands[ci >> 1], order = sk ? (kStreamK | (ci & 1)) : (ci & 1);
+        if (!sk && (s > total || s > 0xffff || (s > 1 && total / s < 4))) break;
         g_force_splits = s;
         g_force_order = order;
-        const bool zero = s > 1 && !wgrad_ws_ok(Cin, Cout, Kw, s, ws, ws_bytes);    // atomics need a zero-filled dw
+        const bool zero = sk || (s > 1 && !wgrad_ws_ok(Cin, Cout, Kw, s, ws, ws_bytes));    // atomics need a zero-filled dw
         int rc = w2l_conv1d_wgrad_ws(dy, dy_bstride, xp, x_bstride, x_rows_total, dw_scratch, N, Cin, Cout, Tout, Kw, stride,
                                      dil, 0, ws, ws_bytes, stream);
         if (rc != 0) continue;
@@ -591,7 +668,7 @@ void w2l_wgrad_tune_dump(FILE* f) {
 }
 
 bool w2l_wgrad_tune_put(const int* v) {          // v[0..4] = key, v[5] = split count, v[6] = block order
-    if (v[5] < 1 || v[5] > 0xffff || v[0] < 1 || v[3] < 1 || v[6] < 0 || v[6] > 1) return false;
+    if (v[5] < 1 || v[5] > 0xffff || v[0] < 1 || v[3] < 1 || v[6] < 0 || v[6] > 3) return false;
     const int ts = (v[3] + BT - 1) / BT;
     if ((int64_t)v[5] > (int64_t)v[0] * ts) return false;
     std::lock_guard<std::mutex> lock(g_wtuned_mu);
