@@ -467,17 +467,8 @@ int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out, int
         double cost = rounds * steps * per_step + (s > 1 ? 0.5 * out_us * s : 0.0);
         if (cost < best_cost * 0.97) { best_cost = cost; best = s; }
     }
-    // stream-K: every resident slot busy for W / G steps, one atomically added piece per block
-    if (order_out && g_force_order < 0) {
-        const int64_t W = (int64_t)tiles * total;
-        int64_t G = W / 16;
-        if (G > kResidentBlocks) G = kResidentBlocks;
-        if (G >= 64) {
-            const double sk_cost = ((double)W / (double)G + 10.0) * t_step_us * (G <= 256 ? 0.6 : 1.0) +
-                                   0.5 * out_us * (double)G / (double)tiles;
-            if (sk_cost < best_cost * 0.95) *order_out |= kStreamK;
-        }
-    }
+    // (the stream-K decomposition is a candidate of the measured selection only: its kernel carries ~10 % more instructions
+    // per K step -- the segment loop's live scalars -- and beat the best split-K plan on one shape of the Wav2Letter table)
     return best;
 }
 
