@@ -110,12 +110,14 @@ int64_t w2l_conv_splitk_workspace_bytes(int N, int Cout, int Tout);
  *   y[n][t][co] = descale * sum_{kw,ci} wq[kw][co][ci] * xq[n][t + kw*dil][ci] (+ bias[co]),
  * xq / wq one byte per element, same layouts as the bf16 entry point (x_bstride in elements), Cin a multiple of 128,
  * stride 1; the products run on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the bf16 MFMA rate), fp32
- * accumulate; descale = 1 / (activation scale * weight scale) undoes the producers' per-tensor scaling.  Output bf16 or
+ * accumulate; descale = 1 / (activation scale * weight scale) undoes the producers' per-tensor scaling (descale_dev, optional:
+ * a further factor read from device memory -- the inverse scale w2l_quantize_e4m3_dyn derived from a device-side amax, as
+ * for the data gradient, where xq is the e4m3 copy of dy and wq the flipped-tap operand).  Output bf16 or
  * fp32, optional BatchNorm partial statistics as w2l_conv1d_igemm.  The _tune form measures the block shapes once per
  * shape (synchronising; warm-up only). */
 int w2l_conv1d_igemm_fp8(const void* xq, int64_t x_bstride, int64_t x_rows_total, const void* wq, void* y, int y_f32,
-                         float descale, const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout, int Kw,
-                         int dil, void* stream);
+                         float descale, const float* descale_dev, const float* bias, float* stats_partial, int N, int Cin,
+                         int Cout, int Tout, int Kw, int dil, void* stream);
 int w2l_conv1d_igemm_fp8_tune(const void* xq, int64_t x_bstride, int64_t x_rows_total, const void* wq, void* y, int y_f32,
                               const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout, int Kw, int dil,
                               int reps, void* stream);
@@ -247,6 +249,14 @@ int w2l_bn_bwd_finalize(const float* partial, int nblocks, int C, int ncomp, flo
  * sum(dy) == 0 identically (the reference's value is fp32 rounding noise); it is not computed. */
 int w2l_bn_act_bwd_apply(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2, const float* sums,
                          void* dy_hi, void* dy_lo, int halo, void* dy2_hi, void* dy2_lo, int halo2, void* stream);
+/* the same, also leaving max |dy| (amax[0]) and max |dy2| (amax[1]) in device memory (integer atomic max on the bit
+ * patterns: the caller zeroes amax first) -- the scale of the e4m3 copy of dy that the data gradient reads in fp8 mode */
+int w2l_bn_act_bwd_apply_amax(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2, const float* sums,
+                              void* dy_hi, void* dy_lo, int halo, void* dy2_hi, void* dy2_lo, int halo2, float* amax,
+                              void* stream);
+/* dst[i] = e4m3(src[i] * s), s = 2^floor(log2(224 / amax[0])) read from DEVICE memory (no host round trip; s = 1 when
+ * amax is 0); inv_scale[0] = 1 / s for the consumer (w2l_conv1d_igemm_fp8 descale_dev).  src bf16, n a multiple of 8. */
+int w2l_quantize_e4m3_dyn(const void* src_bf16, int64_t n, const float* amax, void* dst, float* inv_scale, void* stream);
 
 /* The data gradient of a stride-1 nn.Conv1d FUSED with w2l_bn_act_bwd_reduce of the layer that produced the conv's input
  * (d describes that layer: bf16 y, one branch).  dxp [flat_rows][d->C] bf16 is the gradient wrt the padded activation,

@@ -79,7 +79,10 @@ _SIGNATURES = {
     'w2l_bn_act_fwd': (c_i, [C.POINTER(BnActDesc), c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'w2l_bn_act_fwd_q': (c_i, [C.POINTER(BnActDesc), c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_p]),
     'w2l_quantize_e4m3': (c_i, [c_p, c_i, c_i64, c_f, c_p, c_p]),
-    'w2l_conv1d_igemm_fp8': (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_i, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'w2l_quantize_e4m3_dyn': (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p]),
+    'w2l_bn_act_bwd_apply_amax': (c_i, [C.POINTER(BnActDesc), C.POINTER(GradSrc), C.POINTER(GradSrc), c_p, c_p, c_p, c_i,
+                                        c_p, c_p, c_i, c_p, c_p]),
+    'w2l_conv1d_igemm_fp8': (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'w2l_conv1d_igemm_fp8_tune': (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'w2l_bn_bwd_blocks': (c_i, [c_i, c_i, c_i]),
     'w2l_bn_act_bwd_reduce': (c_i, [C.POINTER(BnActDesc), C.POINTER(GradSrc), C.POINTER(GradSrc), c_p, c_p]),

@@ -348,7 +348,8 @@ template <bool F32, bool GF32, bool HAS2>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(w2l_bnact_t d, w2l_gradsrc_t g1, w2l_gradsrc_t g2,
                                                                 int has_g2, const float* sums, bf16_raw* dy_hi,
                                                                 bf16_raw* dy_lo, int h1, bf16_raw* dy2_hi,
-                                                                bf16_raw* dy2_lo, int h2, float inv_keep) {
+                                                                bf16_raw* dy2_lo, int h2, float inv_keep, float* amax) {
+    float mx1 = 0.f, mx2 = 0.f;                  // fp8 mode: running max |dy| (and |dy2|) of this thread
     const int G = d.C >> 3;
     const int T = d.T, N = d.N;
     const float invM = 1.f / ((float)N * (float)T);
@@ -395,6 +396,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(w2l_bnact_t d, w2
             for (int j = 0; j < 8; ++j) o1[j] = o.g[j] * c1.sc[j];
         }
         store8_split(dy_hi, dy_lo, ((int64_t)h1 + (int64_t)n * (T + h1) + t) * d.C + c, o1);
+        if (amax) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx1 = fmaxf(mx1, fabsf(o1[j]));
+        }
         if (HAS2 && dy2_hi) {
             if (d.mean2) {
                 float sg[8], sgx[8];
@@ -407,7 +412,36 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(w2l_bnact_t d, w2
                 for (int j = 0; j < 8; ++j) o2[j] = o.g[j] * c2.sc[j];
             }
             store8_split(dy2_hi, dy2_lo, ((int64_t)h2 + (int64_t)n * (T + h2) + t) * d.C + c, o2);
+            if (amax) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mx2 = fmaxf(mx2, fabsf(o2[j]));
+            }
         }
+    }
+    if (amax) {          // non-negative floats order like their bit patterns: one integer atomic max per wave
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            mx1 = fmaxf(mx1, __shfl_xor(mx1, m, 64));
+            mx2 = fmaxf(mx2, __shfl_xor(mx2, m, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx1));
+            if (HAS2 && dy2_hi) atomicMax(reinterpret_cast<unsigned*>(amax) + 1, __float_as_uint(mx2));
+        }
+    }
+}
+
+// e4m3 quantisation with the scale taken from a device-resident amax (no host round trip): scale = the power of two that
+// puts amax at <= 224 (one binade of head-room below e4m3's 448); inv_scale[0] = 1 / scale for the consumer's epilogue
+__global__ __launch_bounds__(256) void quantize_e4m3_dyn_kernel(const bf16_raw* src, int64_t ngroups, const float* amax,
+                                                                 uint8_t* dst, float* inv_scale) {
+    const float a = amax[0];
+    const float scale = a > 0.f ? exp2f(floorf(log2f(224.f / a))) : 1.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) inv_scale[0] = 1.f / scale;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ngroups; i += (int64_t)gridDim.x * 256) {
+        float v[8];
+        load8<false>(src, i * 8, v);
+        *reinterpret_cast<uint2*>(dst + i * 8) = quant8_e4m3(v, scale);
     }
 }
 
@@ -583,6 +617,21 @@ extern "C" int w2l_bn_bwd_finalize(const float* partial, int nblocks, int C, int
 extern "C" int w2l_bn_act_bwd_apply(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2,
                                     const float* sums, void* dy_hi, void* dy_lo, int halo, void* dy2_hi, void* dy2_lo,
                                     int halo2, void* stream) {
+    return w2l_bn_act_bwd_apply_amax(d, g1, g2, sums, dy_hi, dy_lo, halo, dy2_hi, dy2_lo, halo2, nullptr, stream);
+}
+
+extern "C" int w2l_quantize_e4m3_dyn(const void* src_bf16, int64_t n, const float* amax, void* dst, float* inv_scale,
+                                     void* stream) {
+    W2L_CHECK_ARG(src_bf16 && dst && amax && inv_scale && n > 0 && n % 8 == 0, "quantize_e4m3_dyn: bad arguments");
+    hipLaunchKernelGGL(quantize_e4m3_dyn_kernel, dim3(elementwise_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_raw*)src_bf16, n / 8, amax, (uint8_t*)dst, inv_scale);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int w2l_bn_act_bwd_apply_amax(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2,
+                                         const float* sums, void* dy_hi, void* dy_lo, int halo, void* dy2_hi, void* dy2_lo,
+                                         int halo2, float* amax, void* stream) {
     if (int e = check_desc(d, "bn_act_bwd_apply")) return e;
     W2L_CHECK_ARG(g1 && g1->dxp && dy_hi, "bn_act_bwd_apply: null pointer");
     W2L_CHECK_ARG(!d->mean || sums, "bn_act_bwd_apply: BatchNorm backward needs the reduced sums");
@@ -599,7 +648,7 @@ extern "C" int w2l_bn_act_bwd_apply(const w2l_bnact_t* d, const w2l_gradsrc_t* g
     w2l_gradsrc_t g2v = g2 ? *g2 : *g1;
     W2L_DISPATCH_BWD(bn_act_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d, *g1, g2v, g2 ? 1 : 0,
                      sums, (bf16_raw*)dy_hi, (bf16_raw*)dy_lo, halo, (bf16_raw*)dy2_hi, (bf16_raw*)dy2_lo, halo2,
-                     inv_keep);
+                     inv_keep, amax);
     W2L_CHECK_LAUNCH();
     return 0;
 }

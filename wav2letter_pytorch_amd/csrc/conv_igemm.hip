@@ -43,6 +43,7 @@ struct IgemmParams {
     float* slabs;             // [tiles][splits][BM*BN]
     unsigned* tickets;        // [tiles], zero between launches
     float descale;            // F8 kernels: y = acc * descale (+ bias), descale = 1 / (activation scale * weight scale)
+    const float* descale_dev; // optional further factor in device memory (scale derived from a device-side amax)
     // EPI == 1 (data gradient fused with the BatchNorm-backward reduction of the layer that produced the conv's input):
     // the output tile IS the gradient wrt that layer's padded activation, so the epilogue also forms, per channel,
     // sum g*gate and sum g*gate*xhat over its rows (what bn_act_bwd_reduce_kernel computes in a pass of its own)
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
     // ---- epilogue: bias, optional accumulate, store, BatchNorm partial statistics ----
     // acc[mi][ni][r] = y[co = m0 + (wm*MS+mi)*16 + fq*4 + r][t = t0 + (wn*NS+ni)*16 + fr]
     const int Cout = p.Cout, Tout = p.Tout;
+    const float descale = F8 ? p.descale * (p.descale_dev ? p.descale_dev[0] : 1.f) : 1.f;
     float s1[MS][4], s2[MS][4];
 #pragma unroll
     for (int mi = 0; mi < MS; ++mi) {
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
         for (int ni = 0; ni < NS; ++ni) {
             const int t = t0 + (wn * NS + ni) * 16 + fr;
             const bool ok = co_ok && t < Tout;
-            f32x4 v = F8 ? acc[mi][ni] * p.descale + bias4 : acc[mi][ni] + bias4;
+            f32x4 v = F8 ? acc[mi][ni] * descale + bias4 : acc[mi][ni] + bias4;
             const int64_t off = ((int64_t)n * Tout + t) * Cout + co;
             if (ok) {
                 if (p.y_f32) {
@@ -731,6 +733,7 @@ static int igemm_launch(const void* xp, int64_t x_bstride, int64_t x_rows_total,
     p.N = N; p.Cin = Cin; p.Cout = Cout; p.Tout = Tout; p.Kw = Kw; p.stride = stride; p.dil = dil;
     p.y_f32 = y_f32; p.accumulate = accumulate;
     p.descale = 1.f;
+    p.descale_dev = nullptr;
     int epi = 0;
     if (bb != nullptr) {
         const w2l_bnact_t* d = bb->d;
@@ -947,8 +950,8 @@ static int choose_f8(int N, int Cin, int Cout, int Tout, int Kw, int dil, bool n
 }
 
 extern "C" int w2l_conv1d_igemm_fp8(const void* xq, int64_t x_bstride, int64_t x_rows_total, const void* wq, void* y, int y_f32,
-                                    float descale, const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout,
-                                    int Kw, int dil, void* stream) {
+                                    float descale, const float* descale_dev, const float* bias, float* stats_partial, int N,
+                                    int Cin, int Cout, int Tout, int Kw, int dil, void* stream) {
     W2L_CHECK_ARG(xq && wq && y, "conv1d_igemm_fp8: null pointer");
     W2L_CHECK_ARG(N > 0 && Tout > 0 && Kw > 0 && dil > 0, "conv1d_igemm_fp8: bad sizes");
     W2L_CHECK_ARG(Cin % 128 == 0 && Cin > 0, "conv1d_igemm_fp8: Cin=%d must be a positive multiple of 128", Cin);
@@ -967,6 +970,7 @@ extern "C" int w2l_conv1d_igemm_fp8(const void* xq, int64_t x_bstride, int64_t x
     p.y_f32 = y_f32; p.accumulate = 0;
     p.splits = 1; p.slabs = nullptr; p.tickets = nullptr;
     p.descale = descale;
+    p.descale_dev = descale_dev;
     const int64_t need = (int64_t)(N - 1) * p.x_rows_per_utt + (int64_t)(Tout - 1) + (int64_t)(Kw - 1) * dil;
     W2L_CHECK_ARG(need <= p.x_max_row, "conv1d_igemm_fp8: padded input too small (need row %lld, have %lld)",
                   (long long)need, (long long)p.x_max_row);
@@ -1010,13 +1014,13 @@ extern "C" int w2l_conv1d_igemm_fp8_tune(const void* xq, int64_t x_bstride, int6
     for (int k = 0; k < kNumF8Cfgs; ++k) {
         if (!f8_feasible(k, Kw, dil, need128)) continue;
         g_force_f8 = k;
-        if (w2l_conv1d_igemm_fp8(xq, x_bstride, x_rows_total, wq, y, y_f32, 1.f, bias, stats_partial, N, Cin, Cout, Tout, Kw, dil,
-                                 stream) != 0)
+        if (w2l_conv1d_igemm_fp8(xq, x_bstride, x_rows_total, wq, y, y_f32, 1.f, nullptr, bias, stats_partial, N, Cin, Cout, Tout, Kw,
+                                 dil, stream) != 0)
             continue;
         (void)hipEventRecord(e0, st);
         for (int r = 0; r < reps; ++r)
-            w2l_conv1d_igemm_fp8(xq, x_bstride, x_rows_total, wq, y, y_f32, 1.f, bias, stats_partial, N, Cin, Cout, Tout, Kw, dil,
-                                 stream);
+            w2l_conv1d_igemm_fp8(xq, x_bstride, x_rows_total, wq, y, y_f32, 1.f, nullptr, bias, stats_partial, N, Cin, Cout, Tout, Kw,
+                                 dil, stream);
         (void)hipEventRecord(e1, st);
         if (hipEventSynchronize(e1) != hipSuccess) continue;
         float ms = 0.f;

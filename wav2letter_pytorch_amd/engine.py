@@ -371,29 +371,33 @@ FP8_ACT_SCALE = {ACT_CLAMP20: 16.0, ACT_RELU: 8.0, ACT_NONE: 8.0}
 FP8_WEIGHT_RESCALE = 256
 
 
-def _fp8_weights(conv: ConvSpec, pk: '_PackedW'):
-    """(e4m3 [Kw, CoutP, CinP] operand, scale) of a conv weight, requantised from the bf16 pack when the weight changed"""
+def _fp8_weights(conv: ConvSpec, pk: '_PackedW', dgrad: bool = False):
+    """(e4m3 operand, scale) of a conv weight, requantised from the bf16 pack when the weight changed: the forward layout
+    [Kw, CoutP, CinP], or (``dgrad``) the flipped-tap layout [Kw, CinP, CoutP] of the data gradient -- one scale for both"""
     w = conv.weight
     st = w.__dict__.get('_w2l_fp8')
-    if st is not None and st['version'] == pk.version and st['q'].device == pk.fwd_hi.device:
-        return st['q'], st['scale']
-    if st is None or st['age'] >= FP8_WEIGHT_RESCALE or st['q'].shape != pk.fwd_hi.shape:
+    if st is None or st['age'] >= FP8_WEIGHT_RESCALE or st['q'].shape != pk.fwd_hi.shape or st['q'].device != pk.fwd_hi.device:
         amax = float(pk.fwd_hi.abs().amax())                     # host sync: first use and every FP8_WEIGHT_RESCALE steps
         scale = 2.0 ** int(torch.floor(torch.log2(torch.tensor(448.0 / max(amax, 1e-30)))))
-        st = {'q': torch.empty(pk.fwd_hi.shape, dtype=torch.uint8, device=pk.fwd_hi.device), 'scale': scale, 'age': 0}
+        dev = pk.fwd_hi.device
+        st = {'q': torch.empty(pk.fwd_hi.shape, dtype=torch.uint8, device=dev),
+              'qd': torch.empty(pk.dgr_hi.shape, dtype=torch.uint8, device=dev), 'scale': scale, 'age': 0, 'version': None,
+              'version_d': None}
         w.__dict__['_w2l_fp8'] = st
-    check(lib.w2l_quantize_e4m3(ptr(pk.fwd_hi), 0, pk.fwd_hi.numel(), st['scale'], ptr(st['q']), stream_ptr()),
-          'w2l_quantize_e4m3')
-    st['version'] = pk.version
-    st['age'] += 1
-    return st['q'], st['scale']
+    key, vkey, src = ('qd', 'version_d', pk.dgr_hi) if dgrad else ('q', 'version', pk.fwd_hi)
+    if st[vkey] != pk.version:
+        check(lib.w2l_quantize_e4m3(ptr(src), 0, src.numel(), st['scale'], ptr(st[key]), stream_ptr()), 'w2l_quantize_e4m3')
+        st[vkey] = pk.version
+        if not dgrad:
+            st['age'] += 1
+    return st[key], st['scale']
 
 
 class StackEngine:
     """Executes a list of UnitSpec.  ``precise`` selects the split-bf16 (near-fp32) mode used
     for parity against the fp32 reference; the default is bf16 operands with fp32 accumulate; ``fp8`` runs the forward
-    convolutions of the units on e4m3 operands (activations and weights quantised per tensor, fp32 accumulate) while
-    the classifier, every gradient and all statistics stay as in bf16 mode."""
+    and data-gradient convolutions of the units on e4m3 operands (activations, dy and weights quantised per tensor, fp32
+    accumulate) while the classifier, the weight gradients and all statistics stay as in bf16 mode."""
 
     def __init__(self, units: Sequence[UnitSpec], head: Optional[ConvSpec], n_labels: int, precise: bool = False,
                  fp8: bool = False):
@@ -635,7 +639,7 @@ class StackEngine:
                                                     cin, cout, Tout, conv.kernel, conv.dilation, TUNE_REPS, st),
                       'w2l_conv1d_igemm_fp8_tune')
         with _timed('conv_igemm_fp8_kernel', flops):
-            check(lib.w2l_conv1d_igemm_fp8(xq, bstride, rows_total, ptr(wq), ptr(y), y_f32, 1.0 / (src.q_scale * w_scale),
+            check(lib.w2l_conv1d_igemm_fp8(xq, bstride, rows_total, ptr(wq), ptr(y), y_f32, 1.0 / (src.q_scale * w_scale), None,
                                            ptr(bias), ptr(stats), N, cin, cout, Tout, conv.kernel, conv.dilation, st),
                   'w2l_conv1d_igemm_fp8')
 
@@ -850,6 +854,7 @@ class StackEngine:
         N = ctx['out'].shape[0]
         dev = ctx['out'].device
         st = stream_ptr
+        amax_pool = torch.zeros(2 * (len(acts) + 1), dtype=torch.float32, device=dev) if self.fp8 else None   # one fill per step
         for uc in reversed(ctx['units']):
             u = uc.unit
             oi = uc.out_index
@@ -895,8 +900,10 @@ class StackEngine:
                 dy2_lo = torch.empty_like(dy2_hi) if precise else None
             if not batch_stats:
                 d = self._desc(uc, N, Tout, coutp, p, uc.lens_out, constant_stats=True)
-            check(lib.w2l_bn_act_bwd_apply(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(sums), ptr(dy_hi),
-                                           ptr(dy_lo), h1, ptr(dy2_hi), ptr(dy2_lo), h2, st()),
+            # fp8 mode: the kernel also leaves max |dy| (|dy2|) in device memory -- the scale of dy's e4m3 copy
+            amax = amax_pool[2 * oi: 2 * oi + 2] if (self.fp8 and coutp % 128 == 0) else None
+            check(lib.w2l_bn_act_bwd_apply_amax(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(sums), ptr(dy_hi),
+                                                ptr(dy_lo), h1, ptr(dy2_hi), ptr(dy2_lo), h2, ptr(amax), st()),
                   'w2l_bn_act_bwd_apply')
             # release the consumed gradient buffers early
             act_grads[oi] = []
@@ -917,12 +924,14 @@ class StackEngine:
                 else:
                     self._set(grads, main.bias, self._dy_colsum(dy_hi, dy_lo, h1, N, Tout, coutp, main.cout))
             if u.dw is not None:
-                dmid = self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src)      # (wrt the depthwise output: no BatchNorm there)
+                dmid = self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src,      # (wrt the depthwise output: no BatchNorm there)
+                                   amax=None if amax is None else amax[0:1])
                 gsrc = self._dw_backward(u.dw, dmid, acts[u.src], uc.mid, need_dx_main, grads)
                 if gsrc is not None:
                     act_grads[u.src].append(gsrc)
             elif need_dx_main:
-                act_grads[u.src].append(self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, self._producer(ctx, u.src)))
+                act_grads[u.src].append(self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, self._producer(ctx, u.src),
+                                                    amax=None if amax is None else amax[0:1]))
             if res is not None:
                 pkr = pack_weights(res, precise)
                 rsrc = acts[u.res_src]
@@ -934,7 +943,8 @@ class StackEngine:
                         self._set(grads, res.bias, self._dy_colsum(dy2_hi, dy2_lo, h2, N, Tout, coutp, res.cout))
                 if self._needs_grad(u.res_src, ctx):
                     act_grads[u.res_src].append(self._dgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc,
-                                                            self._producer(ctx, u.res_src)))
+                                                            self._producer(ctx, u.res_src),
+                                                            amax=None if amax is None else amax[1:2]))
     # ------------------------------------------------------------------ helpers
     def _needs_grad(self, act_index: int, ctx=None) -> bool:
         # the spectrogram needs no gradient in training (base_asr_models.py:78-85); computed only on request
@@ -1134,7 +1144,7 @@ class StackEngine:
             check(lib.w2l_conv1d_dgrad_bnreduce_ws(*args, ptr(ws), ws.numel(), st), 'w2l_conv1d_dgrad_bnreduce_ws')
         return partial
 
-    def _dgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, producer=None):
+    def _dgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, producer=None, amax=None):
         """dXpad (gradient wrt the conv's padded input) through the same implicit-GEMM kernel, run over
         the shared-halo dy buffer as ONE sequence of N*(Tout+halo) rows: tiles never straddle a partially
         filled per-utterance remainder.  Row v of utterance n lands at output row n*(Tout+halo) + v."""
@@ -1163,6 +1173,29 @@ class StackEngine:
         dxp = torch.empty(flat_rows, pk.cinp, dtype=torch.float32 if self.precise else torch.bfloat16, device=dev)
         total = dy_hi.shape[0]
         flops = 2.0 * N * Tout * conv.cout * conv.cin * conv.kernel
+        if self.fp8 and amax is not None and conv.stride == 1 and pk.coutp % 128 == 0 and per >= Tp:
+            # fp8 mode: dy's e4m3 copy (scale from the device-side amax bn_act_bwd_apply left) x the e4m3 flipped-tap weights
+            dyq = torch.empty(dy_hi.shape, dtype=torch.uint8, device=dev)
+            inv = torch.empty(1, dtype=torch.float32, device=dev)
+            check(lib.w2l_quantize_e4m3_dyn(ptr(dy_hi), dy_hi.numel(), ptr(amax), ptr(dyq), ptr(inv), stream_ptr()),
+                  'w2l_quantize_e4m3_dyn')
+            wq, w_scale = _fp8_weights(conv, pk, dgrad=True)
+            row_off = halo - hb
+            xq = C.c_void_p(dyq.data_ptr() + row_off * pk.coutp)
+            rows_total = total - row_off
+            st_ = stream_ptr()
+            if AUTOTUNE:
+                key = ('fp8', 1, pk.coutp, pk.cinp, flat_rows, conv.kernel, conv.dilation, False, dev.index)
+                if key not in _tuned_shapes:
+                    _tuned_shapes.add(key)
+                    check(lib.w2l_conv1d_igemm_fp8_tune(xq, rows_total * pk.coutp, rows_total, ptr(wq), ptr(dxp), 0, None, None, 1,
+                                                        pk.coutp, pk.cinp, flat_rows, conv.kernel, conv.dilation, TUNE_REPS, st_),
+                          'w2l_conv1d_igemm_fp8_tune')
+            with _timed('conv_igemm_fp8_kernel', flops):
+                check(lib.w2l_conv1d_igemm_fp8(xq, rows_total * pk.coutp, rows_total, ptr(wq), ptr(dxp), 0, 1.0 / w_scale, ptr(inv),
+                                               None, None, 1, pk.coutp, pk.cinp, flat_rows, conv.kernel, conv.dilation, st_),
+                      'w2l_conv1d_igemm_fp8')
+            return (dxp, conv.pad_l, conv.pad_r, conv.pad_mode, per)
         if producer is not None and conv.stride == 1 and per >= Tp and src.CP == pk.cinp:
             partial = self._dgrad_fused(conv, pk, dy_hi, halo, hb, per, flat_rows, total, dxp, src, producer, flops)
             return (dxp, conv.pad_l, conv.pad_r, conv.pad_mode, per, partial)
