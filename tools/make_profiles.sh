@@ -1,23 +1,44 @@
 #!/bin/bash
-# Regenerates the artefacts committed under profiles/ (run through gpurun; outputs land in gpurun_out/final/).
+# Regenerates the artefacts committed under profiles/ (run through gpurun; outputs land in gpurun_out/final/ and are then
+# copied into profiles/ with the round prefix by hand: `for f in gpurun_out/final/*; do cp $f profiles/r02_$(basename $f); done`).
+# Stages are independent: a failing one leaves its file empty, the others still run.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/final
-mkdir -p $OUT
-export W2L_TUNE_CACHE=$PWD/$OUT/tune_cache.txt   # first run measures, the profiled runs reuse its choices
-python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench.json
+rm -rf $OUT && mkdir -p $OUT
+export W2L_TUNE_CACHE=$PWD/$OUT/tune_cache.txt   # the first run measures, the profiled runs reuse its choices
+last() { tail -1; }
+# ---- headline (BASELINE config 2): bench line, rocprofv3 kernel statistics (overlapped = default, and serialised), PMC traffic
+python3 bench.py --steps 20 --warmup 5 2>/dev/null | last > $OUT/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_default -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/prof_default.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_serial -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --serial-wgrad > $OUT/prof_serial.log 2>&1
+for d in default serial; do
+  f=$(ls $OUT/prof_$d/*/*kernel_stats.csv | head -1)
+  cp $f $OUT/${d}_kernel_stats.csv
+  python3 tools/prof_summary.py stats $f > $OUT/${d}_kernel_families.txt
+done
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_bench_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
 python3 tools/prof_summary.py pmc $OUT/pmc_bench.json $OUT/pmc_bench_FETCH_SIZE $OUT/pmc_bench_WRITE_SIZE
-rm -rf $OUT/pmc_bench_FETCH_SIZE $OUT/pmc_bench_WRITE_SIZE
-for d in default serial; do python3 tools/prof_summary.py stats $OUT/prof_$d/*/*kernel_stats.csv > $OUT/stats_$d.txt; done
+rm -rf $OUT/pmc_bench_FETCH_SIZE $OUT/pmc_bench_WRITE_SIZE $OUT/prof_default $OUT/prof_serial $OUT/prof_default.log $OUT/prof_serial.log
+# ---- one layer under the SQ / TCC counters (640 -> 640 k21)
 bash tools/pmc_conv.sh 11 > $OUT/pmc_layer11.txt 2>&1
 cp gpurun_out/pmc_11/summary.json $OUT/pmc_layer11.json
-python3 bench.py --model jasper10x5 --batch 16 --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_jasper10x5.json
-python3 bench.py --mid-layers 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_w2l_default_mid1.json
-for n in 8 16; do python3 bench.py --batch $n --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_w2l_n$n.json; done
-python3 tools/bench_features.py 2>/dev/null | tail -1 > $OUT/bench_features.txt
+# ---- per-layer conv kernels, Wav2Letter table shapes at N = 32 (config 2) and N = 16 (the shapes of Jasper 10x5, config 4)
 python3 tools/bench_conv.py --tune > $OUT/conv_layers.txt 2>&1
-cat $OUT/bench.json | cut -c1-1200
+python3 tools/bench_conv.py --tune --n 16 > $OUT/conv_layers_n16.txt 2>&1
+# ---- the other workloads
+python3 bench.py --model jasper10x5 --batch 16 --steps 10 --warmup 4 2>/dev/null | last > $OUT/bench_jasper10x5.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_jasper -- python3 bench.py --model jasper10x5 --batch 16 --steps 8 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+python3 tools/prof_summary.py stats $(ls $OUT/prof_jasper/*/*kernel_stats.csv | head -1) > $OUT/jasper10x5_kernel_families.txt
+rm -rf $OUT/prof_jasper
+python3 bench.py --dtype fp8 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | last > $OUT/bench_fp8.json
+python3 bench.py --model jasper10x5 --batch 16 --dtype fp8 --steps 10 --warmup 4 2>/dev/null | last > $OUT/bench_jasper10x5_fp8.json
+python3 bench.py --model jasper10x5 --batch 16 --frames 16000 --dtype fp8 --steps 3 --warmup 2 2>/dev/null | last > $OUT/bench_jasper10x5_fp8_T16000.json
+python3 bench.py --model jasper10x5 --batch 16 --frames 16000 --steps 3 --warmup 2 2>/dev/null | last > $OUT/bench_jasper10x5_T16000.json
+python3 bench.py --mid-layers 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | last > $OUT/bench_w2l_mid1.json
+for n in 8 16; do python3 bench.py --batch $n --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | last > $OUT/bench_w2l_n$n.json; done
+# one rank, RCCL path forced: what the gradient collectives cost when nothing has to cross a link (plumbing, exposed_comm_ms)
+python3 bench.py --force-dp --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | last > $OUT/bench_force_dp_1rank.json
+python3 tools/bench_features.py 2>/dev/null | last > $OUT/bench_features.txt
+cut -c1-1200 $OUT/bench.json

@@ -369,6 +369,8 @@ def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw
 # quantisations (one host sync per weight then; weights move by lr * grad per step, and the conversion saturates).
 FP8_ACT_SCALE = {ACT_CLAMP20: 16.0, ACT_RELU: 8.0, ACT_NONE: 8.0}
 FP8_WEIGHT_RESCALE = 256
+# W2L_FP8_DGRAD=0: fp8 mode keeps the data gradients in bf16 (forward convolutions only on e4m3 operands)
+FP8_DGRAD = os.environ.get('W2L_FP8_DGRAD', '1') != '0'
 
 
 def _fp8_weights(conv: ConvSpec, pk: '_PackedW', dgrad: bool = False):
@@ -901,7 +903,7 @@ class StackEngine:
             if not batch_stats:
                 d = self._desc(uc, N, Tout, coutp, p, uc.lens_out, constant_stats=True)
             # fp8 mode: the kernel also leaves max |dy| (|dy2|) in device memory -- the scale of dy's e4m3 copy
-            amax = amax_pool[2 * oi: 2 * oi + 2] if (self.fp8 and coutp % 128 == 0) else None
+            amax = amax_pool[2 * oi: 2 * oi + 2] if (self.fp8 and FP8_DGRAD and coutp % 128 == 0) else None
             check(lib.w2l_bn_act_bwd_apply_amax(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(sums), ptr(dy_hi),
                                                 ptr(dy_lo), h1, ptr(dy2_hi), ptr(dy2_lo), h2, ptr(amax), st()),
                   'w2l_bn_act_bwd_apply')
