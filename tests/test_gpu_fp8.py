@@ -109,25 +109,32 @@ def test_fp8_rejects_unsupported_shapes(L):
     assert rc != 0 and b'multiple of 128' in L.lib.w2l_last_error()
 
 
-def _fp8_step(layers, N, T, seed, dropout=False, tie=2.0):
+def _fp8_step(layers, N, T, seed, dropout=False, tie=2.0, dgrad='1'):
     from oracle import w2l_oracle as O
     from gpu_helpers import compare_step
+    from wav2letter_pytorch_amd import engine as E
+    E.FP8_DGRAD = dgrad              # '1': e4m3 data gradients whatever the size ('auto' engages them from 65 536 rows)
     sd = O.init_wav2letter_state(layers, seed=seed)
     model = build_w2l(layers, sd, 'fp8', dropout=dropout).train()
     x, il, tg, tl = O.synthetic_batch(N, T, seed=seed + 1, s_lo=max(2, T // 12), s_hi=max(3, T // 6))
-    errs, stats, out, out_lens, ref = compare_step(model, layers, sd, x, il, tg, tl, 'bf16', drop=dropout, tie=tie, max_frac=0.3)
+    try:
+        errs, stats, out, out_lens, ref = compare_step(model, layers, sd, x, il, tg, tl, 'bf16', drop=dropout, tie=tie,
+                                                       max_frac=0.3)
+    finally:
+        E.FP8_DGRAD = 'auto'
     return model, errs, stats
 
 
-def test_w2l_small_stack_fp8_vs_oracle():
+@pytest.mark.parametrize('dgrad', ['1', '0'])
+def test_w2l_small_stack_fp8_vs_oracle(dgrad):
     """4 layers (stride-2 first layer in bf16: 64 input channels; the others 128/256/384 wide, k11-k29, dilation 2) in
     fp8 mode vs the fp32 oracle: e4m3 operands carry 3 mantissa bits, so one forward layer is good to ~3 % of scale"""
     layers = [(128, 11, 2, 1, 0.0), (256, 13, 1, 1, 0.0), (384, 29, 1, 2, 0.0), (128, 1, 1, 1, 0.0)]
-    model, errs, stats = _fp8_step(layers, N=3, T=300, seed=3)
+    model, errs, stats = _fp8_step(layers, N=3, T=300, seed=3, dgrad=dgrad)
     eng = model.engine()
     assert eng.fp8 and not eng.precise
     worst = max((v, k) for k, v in errs.items() if k not in ('log_probs', 'loss'))
-    print(f'fp8 small stack: log-probs {errs["log_probs"]:.3f} loss {errs["loss"]:.4f} worst grad {worst[0]:.3f} ({worst[1]}) '
+    print(f'fp8 small stack (e4m3 data gradients {dgrad}): log-probs {errs["log_probs"]:.3f} loss {errs["loss"]:.4f} worst grad {worst[0]:.3f} ({worst[1]}) '
           f'stats {max(stats.values()):.3f}')
     assert errs['log_probs'] < 8e-2 and errs['loss'] < 1e-2          # measured 2.8e-2 / 4e-4
     assert worst[0] < 3.5e-1                                          # measured 0.12 with bf16 data gradients
@@ -148,3 +155,46 @@ def test_w2l_full_table_fp8_properties_and_loss():
     assert errs['log_probs'] < 5e-1
     for k, p in model.named_parameters():
         assert torch.isfinite(p.grad).all(), k
+
+
+def test_jasper_fp8_long_utterance_T16000():
+    """BASELINE config 5's combination -- Jasper residual blocks, fp8 MFMA, T = 16 000 frames (T' = 8 000: time-tiled
+    convolutions, streaming CTC) -- on a 3-block dense Jasper (128/256 channels, stride-2 prologue, k29 dilation 2, residual
+    1x1 convs, ragged lengths): lengths bit-equal, loss and log-probs against the fp32 oracle at the fp8 bounds, the e4m3
+    forward and data-gradient kernels actually engaged"""
+    from gpu_helpers import build_jasper, device_step
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd import Jasper, engine as E
+    from wav2letter_pytorch_amd.config import to_cfg
+    blocks = [dict(layer_size=128, kernel_size=11, stride=2, residual=False, separable=False),
+              dict(layer_size=256, kernel_size=13, stride=1, residual=True, separable=False, repeat=2),
+              dict(layer_size=256, kernel_size=29, stride=1, dilation=2, residual=True, separable=False, repeat=2)]
+    labels = O.ENGLISH_LOWERCASE
+    cfg = to_cfg(dict(name='jasper', mid_layers=3, jasper_blocks=blocks, input_size=64, labels=labels, precision='fp8',
+                      audio_conf=dict(window='hamming', window_stride=0.01, window_size=0.02, sample_rate=16000),
+                      decoder=dict(_target_='decoder.GreedyDecoder', labels=labels)))
+    torch.manual_seed(33)
+    sd = {k: v.detach().clone() for k, v in Jasper(cfg).state_dict().items()}
+    model = build_jasper(blocks, sd, 'fp8').train()
+    x, il, tg, tl = O.synthetic_batch(2, 16000, seed=77, s_lo=900, s_hi=1500)
+    il[1] = 12345
+    x[1, :, 12345:] = 0
+    E.KERNEL_TIMER = []
+    E.FP8_DGRAD = '1'
+    try:
+        out, out_lens, loss, _ = device_step(model, x, il, tg, tl)
+        names = [n for n, *_ in E.KERNEL_TIMER]
+    finally:
+        E.KERNEL_TIMER = None
+        E.FP8_DGRAD = 'auto'
+    assert names.count('conv_igemm_fp8_kernel') >= 4 + 4         # forward convs of blocks 1-2 (+ residuals) and their data gradients
+    with torch.no_grad():
+        lp, ol = O.jasper_forward(x, il, {k: v.clone() for k, v in sd.items()}, blocks, training=True)
+        ls = O.ctc_criterion(lp, tg, ol, tl)
+    assert out.shape == (2, 8000, 29) and [int(v) for v in out_lens] == [8000, 6173] and torch.equal(out_lens.cpu(), ol)
+    e_lp = scale_err(out.cpu().numpy(), lp.numpy())
+    e_loss = abs(float(loss) - float(ls)) / abs(float(ls))
+    print(f'fp8 jasper T=16000: log-probs {e_lp:.3f} loss {e_loss:.4f}')
+    assert e_lp < 1.5e-1 and e_loss < 5e-2
+    for k, p in model.named_parameters():
+        assert torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, k

@@ -369,8 +369,13 @@ def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw
 # quantisations (one host sync per weight then; weights move by lr * grad per step, and the conversion saturates).
 FP8_ACT_SCALE = {ACT_CLAMP20: 16.0, ACT_RELU: 8.0, ACT_NONE: 8.0}
 FP8_WEIGHT_RESCALE = 256
-# W2L_FP8_DGRAD=0: fp8 mode keeps the data gradients in bf16 (forward convolutions only on e4m3 operands)
-FP8_DGRAD = os.environ.get('W2L_FP8_DGRAD', '1') != '0'
+# fp8 mode, data gradients: on e4m3 operands too ('1'), in bf16 ('0'), or (default 'auto') e4m3 only from FP8_DGRAD_MIN_ROWS
+# rows of dy per launch.  The e4m3 data gradient needs two more launches per layer on the backward critical path (dy's
+# quantisation, and the BatchNorm-backward reduction its epilogue cannot form) -- measured on one MI355X, ms per step,
+# bf16 / fp8 forward only / fp8 forward + data gradient: Wav2Letter N=32 x T=1000 13.7 / 12.6-12.9 / 13.9, Jasper 10x5 N=16 x
+# T=1000 19.4 / 18.2 / 23.1, Jasper 10x5 N=16 x T=16000 - / 190 / 176: a gain only where the kernels are long.
+FP8_DGRAD = os.environ.get('W2L_FP8_DGRAD', 'auto')
+FP8_DGRAD_MIN_ROWS = 65536
 
 
 def _fp8_weights(conv: ConvSpec, pk: '_PackedW', dgrad: bool = False):
@@ -903,7 +908,9 @@ class StackEngine:
             if not batch_stats:
                 d = self._desc(uc, N, Tout, coutp, p, uc.lens_out, constant_stats=True)
             # fp8 mode: the kernel also leaves max |dy| (|dy2|) in device memory -- the scale of dy's e4m3 copy
-            amax = amax_pool[2 * oi: 2 * oi + 2] if (self.fp8 and FP8_DGRAD and coutp % 128 == 0) else None
+            fp8_dgrad = self.fp8 and coutp % 128 == 0 and (FP8_DGRAD == '1' or (FP8_DGRAD == 'auto' and
+                                                                                  N * Tout >= FP8_DGRAD_MIN_ROWS))
+            amax = amax_pool[2 * oi: 2 * oi + 2] if fp8_dgrad else None
             check(lib.w2l_bn_act_bwd_apply_amax(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(sums), ptr(dy_hi),
                                                 ptr(dy_lo), h1, ptr(dy2_hi), ptr(dy2_lo), h2, ptr(amax), st()),
                   'w2l_bn_act_bwd_apply')
