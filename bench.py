@@ -268,7 +268,13 @@ def main():
     model._overlap_wgrad = not args.serial_wgrad
     if rank == 0:
         agg = {}
+        fused = [0.0, 0.0, 0]
         for name, flops, s, e in E.KERNEL_TIMER:
+            if name.endswith('/dgrad+bnreduce'):          # same kernel family; the launches whose epilogue also forms the
+                name = name.split('/')[0]                 # BatchNorm-backward sums are additionally reported on their own
+                fused[0] += flops
+                fused[1] += s.elapsed_time(e) * 1e-3
+                fused[2] += 1
             a = agg.setdefault(name, [0.0, 0.0, 0])
             a[0] += flops
             a[1] += s.elapsed_time(e) * 1e-3
@@ -281,6 +287,16 @@ def main():
                 'unit': 'TFLOP/s', 'frac': round(ach / BF16_DENSE_PEAK_TFLOPS, 4), 'traffic': None,
                 'launches_per_step': cnt // 3, 'avg_launch_ms': round(tt / cnt * 1e3, 4),
                 'alg_gflop_per_launch': round(fl / cnt / 1e9, 2)}
+        if fused[2]:
+            roof['dgrad_with_fused_bn_reduce'] = {
+                'note': 'data-gradient launches of the same kernel whose epilogue also forms the BatchNorm-backward sums '
+                        '(replaces bn_act_bwd_reduce_kernel); conv FLOPs only are counted',
+                'achieved': round(fused[0] / fused[1] / 1e12, 1), 'launches_per_step': fused[2] // 3,
+                'avg_launch_ms': round(fused[1] / fused[2] * 1e3, 4)}
+            rest = (fl - fused[0], tt - fused[1], cnt - fused[2])
+            if rest[2] > 0:
+                roof['other_launches'] = {'achieved': round(rest[0] / rest[1] / 1e12, 1), 'launches_per_step': rest[2] // 3,
+                                          'avg_launch_ms': round(rest[1] / rest[2] * 1e3, 4)}
         pmc_file = os.path.join(ROOT, 'profiles', 'r02_pmc_bench.json')
         if (args.model == 'wav2letter' and args.mid_layers == 20 and args.batch == 32 and args.dtype == 'bf16'
                 and os.path.exists(pmc_file)):

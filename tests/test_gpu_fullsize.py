@@ -31,9 +31,9 @@ def _w2l_table(dropout):
 
 def _bf16_grad_bound(key, n):
     """bf16 mode, gradient error (max error over tensor scale) against the fp32 oracle on the 21-layer table, as measured on
-    MI355X: 0.09-0.12 at N=32 (classifier 0.01), 0.16-0.27 at N=2 where BatchNorm's statistics rest on 1000 frames --
+    MI355X: 0.08-0.15 at N=32 (classifier 0.01), 0.16-0.27 at N=2 where BatchNorm's statistics rest on 1000 frames --
     the rounding of every backward stage and the clamp gates that fall the other way add up; bounds with ~30 % margin"""
-    return 0.16 if n >= 32 else 0.35
+    return 0.2 if n >= 32 else 0.35
 
 
 def _report(title, errs):

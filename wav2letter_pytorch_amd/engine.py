@@ -1149,7 +1149,7 @@ class StackEngine:
                 _tune_state['dirty'] = True
                 check(lib.w2l_conv1d_dgrad_bnreduce_tune_ws(*args, TUNE_REPS, ptr(ws), ws.numel(), st),
                       'w2l_conv1d_dgrad_bnreduce_tune_ws')
-        with _timed('conv_igemm_kernel', flops):
+        with _timed('conv_igemm_kernel/dgrad+bnreduce', flops):
             check(lib.w2l_conv1d_dgrad_bnreduce_ws(*args, ptr(ws), ws.numel(), st), 'w2l_conv1d_dgrad_bnreduce_ws')
         return partial
 
