@@ -249,6 +249,13 @@ int w2l_bn_bwd_finalize(const float* partial, int nblocks, int C, int ncomp, flo
  * sum(dy) == 0 identically (the reference's value is fp32 rounding noise); it is not computed. */
 int w2l_bn_act_bwd_apply(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2, const float* sums,
                          void* dy_hi, void* dy_lo, int halo, void* dy2_hi, void* dy2_lo, int halo2, void* stream);
+/* w2l_bn_bwd_finalize + w2l_bn_act_bwd_apply(_amax) in ONE launch: every block re-reduces the partial rows of its own 64
+ * channels (fixed order: all blocks of a slab get bit-identical sums), so the finalize launch on the backward critical path
+ * disappears; sums [ncomp][C] (d beta, d gamma, as w2l_bn_bwd_finalize writes them) are published as a by-product.
+ * partial = what w2l_bn_act_bwd_reduce or w2l_conv1d_dgrad_bnreduce_ws produced; amax optional as below. */
+int w2l_bn_act_bwd_apply_fin(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2, const float* partial,
+                             int nblocks, float* sums, void* dy_hi, void* dy_lo, int halo, void* dy2_hi, void* dy2_lo,
+                             int halo2, float* amax, void* stream);
 /* the same, also leaving max |dy| (amax[0]) and max |dy2| (amax[1]) in device memory (integer atomic max on the bit
  * patterns: the caller zeroes amax first) -- the scale of the e4m3 copy of dy that the data gradient reads in fp8 mode */
 int w2l_bn_act_bwd_apply_amax(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2, const float* sums,

@@ -489,7 +489,19 @@ def test_bn_act_fwd_bwd(L, N, T, C, pl, pr, mode, act, f32):
     dy_lo = torch.full_like(dy_hi, float('nan'))
     L.check(L.lib.w2l_bn_act_bwd_apply(C_.byref(d), C_.byref(gs), None, L.ptr(sums), L.ptr(dy_hi), L.ptr(dy_lo), h, None,
                                        None, 0, st))
+    # the same in one launch (finalize folded into the dy kernel, slab form), NaN-prefilled: every row incl. the halos
+    # must be written; sums equal up to fp32 summation order; amax = max |dy| left in device memory
+    sums2 = torch.full((4, C), float('nan'), device='cuda')
+    dy2_hi = torch.full_like(dy_hi, float('nan'))
+    dy2_lo = torch.full_like(dy_hi, float('nan'))
+    amax = torch.zeros(2, device='cuda')
+    L.check(L.lib.w2l_bn_act_bwd_apply_fin(C_.byref(d), C_.byref(gs), None, L.ptr(partial), nb, L.ptr(sums2), L.ptr(dy2_hi),
+                                           L.ptr(dy2_lo), h, None, None, 0, L.ptr(amax), st))
     torch.cuda.synchronize()
+    assert relerr(sums2[:2].cpu(), sums[:2].cpu()) < 1e-5
+    a_, b_ = dy_hi.float() + dy_lo.float(), dy2_hi.float() + dy2_lo.float()
+    assert torch.isfinite(b_).all() and relerr(b_.cpu(), a_.cpu()) < 1e-5
+    assert abs(float(amax[0]) - float(b_.abs().max())) <= 1e-4 * float(amax[0])
     # d beta / d gamma via autograd on the same graph
     gam = gamma.clone().requires_grad_(True)
     bet = beta.clone().requires_grad_(True)

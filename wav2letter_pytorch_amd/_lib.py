@@ -93,6 +93,8 @@ _SIGNATURES = {
                                            c_p, c_i64, c_p]),
     'w2l_conv1d_dgrad_bnreduce_tune_ws': (c_i, [c_p, c_i64, c_p, c_p, c_p, C.POINTER(BnActDesc), c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                                 c_i, c_i, c_p, c_i64, c_p]),
+    'w2l_bn_act_bwd_apply_fin': (c_i, [C.POINTER(BnActDesc), C.POINTER(GradSrc), C.POINTER(GradSrc), c_p, c_i, c_p, c_p, c_p, c_i,
+                                       c_p, c_p, c_i, c_p, c_p]),
     'w2l_log_softmax_fwd': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'w2l_log_softmax_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     'w2l_ctc_workspace_bytes': (c_i64, [c_i, c_i, c_i]),

@@ -431,6 +431,155 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(w2l_bnact_t d, w2
     }
 }
 
+// ---- backward apply with the finalize folded in ("slab" form).  A block owns a 64-channel slab (one 128-byte line per
+// row) of a row range.  Its prologue re-reduces the per-tile partial sums of ITS 64 channels -- nb x ncomp x 64 floats,
+// L2-resident -- in a fixed order, so every block of a slab arrives at bit-identical sums and the separate
+// bn_bwd_finalize launch (13 us of kernel on the backward critical path, 25+ us of queueing behind the weight-gradient
+// blocks) disappears; the blocks of row chunk 0 also publish the sums (d beta, d gamma).  Then each wave walks its rows
+// eight at a time exactly like the reduction kernel above.  Halo rows of the shared-halo dy layout are zero-filled by
+// the same blocks, a share per row chunk.
+__host__ __device__ inline int apply_rows_per_block(int64_t rows, int C) {
+    int64_t r = rows * (C / BWD_SLAB) / 1536;          // ~1536 blocks per launch
+    r = (r + 31) / 32 * 32;
+    return (int)(r < 64 ? 64 : (r > 1024 ? 1024 : r));
+}
+
+template <bool F32, bool GF32, bool HAS2>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_fin_kernel(w2l_bnact_t d, w2l_gradsrc_t g1, w2l_gradsrc_t g2,
+                                                                    int has_g2, const float* partial, int nb, float* sums_out,
+                                                                    bf16_raw* dy_hi, bf16_raw* dy_lo, int h1, bf16_raw* dy2_hi,
+                                                                    bf16_raw* dy2_lo, int h2, float inv_keep, float* amax,
+                                                                    int rpb) {
+    constexpr int ncomp = HAS2 ? 4 : 2;
+    __shared__ float red[4][ncomp][BWD_SLAB];
+    __shared__ float ssum[ncomp][BWD_SLAB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = d.C >> 3;
+    const int nslabs = d.C / BWD_SLAB;
+    const int slab = blockIdx.x % nslabs, chunk = blockIdx.x / nslabs;     // neighbours: adjacent slabs of the same rows
+    const int T = d.T, N = d.N;
+    // ---- prologue: column sums of partial[nb][ncomp][C] over this slab's channels (thread = channel x quarter of the rows)
+    {
+        const int c = slab * BWD_SLAB + (tid & 63);
+        float a[ncomp];
+#pragma unroll
+        for (int k = 0; k < ncomp; ++k) a[k] = 0.f;
+        int j = wave;
+        for (; j + 12 < nb; j += 16) {                 // four rows in flight per component
+            float v[4][ncomp];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < ncomp; ++k) v[u][k] = partial[((int64_t)(j + 4 * u) * ncomp + k) * d.C + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < ncomp; ++k) a[k] += v[u][k];
+        }
+        for (; j < nb; j += 4)
+#pragma unroll
+            for (int k = 0; k < ncomp; ++k) a[k] += partial[((int64_t)j * ncomp + k) * d.C + c];
+#pragma unroll
+        for (int k = 0; k < ncomp; ++k) red[wave][k][tid & 63] = a[k];
+        __syncthreads();
+        if (tid < ncomp * BWD_SLAB) {
+            const int k = tid >> 6, cc = tid & 63;
+            const float t4 = (red[0][k][cc] + red[1][k][cc]) + (red[2][k][cc] + red[3][k][cc]);
+            ssum[k][cc] = t4;
+            if (chunk == 0) sums_out[(int64_t)k * d.C + slab * BWD_SLAB + cc] = t4;
+        }
+        __syncthreads();
+    }
+    const int cgl = lane & 7, rr = lane >> 3;
+    const int cg = slab * (BWD_SLAB / 8) + cgl, c = cg * 8;
+    Chan c1, c2;
+    load_chan(c1, d.scale, d.shift, d.mean, d.invstd, c);
+    if (HAS2) load_chan(c2, d.scale2, d.shift2, d.mean2, d.invstd2, c);
+    float sg[8], sgx[8], sg2[8], sgx2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sg[j] = ssum[0][cgl * 8 + j];
+        sgx[j] = ssum[1][cgl * 8 + j];
+        sg2[j] = HAS2 ? ssum[2][cgl * 8 + j] : 0.f;
+        sgx2[j] = HAS2 ? ssum[3][cgl * 8 + j] : 0.f;
+    }
+    const float invM = 1.f / ((float)N * (float)T);
+    const int64_t rows = (int64_t)N * T;
+    const int rpw = rpb >> 2;                          // rows per wave (multiple of 8)
+    const int64_t row0 = (int64_t)chunk * rpb + (int64_t)wave * rpw;
+    int64_t rend = row0 + rpw;
+    if (rend > rows) rend = rows;
+    float mx1 = 0.f, mx2 = 0.f;
+    if (row0 + rr < rend) {
+        int n = (int)((row0 + rr) / T), t = (int)((row0 + rr) - (int64_t)n * T);
+#pragma unroll 2
+        for (int64_t row = row0 + rr; row < rend; row += 8, t += 8) {
+            while (t >= T) { t -= T; ++n; }
+            BwdRow o;
+            bwd_row<F32, GF32, HAS2>(d, c1, c2, g1, g2, has_g2, n, t, cg, G, inv_keep, o);
+            float o1[8], o2[8];
+            if (d.mean) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o1[j] = c1.sc[j] * (o.g[j] - sg[j] * invM - o.xh1[j] * sgx[j] * invM);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o1[j] = o.g[j] * c1.sc[j];
+            }
+            store8_split(dy_hi, dy_lo, ((int64_t)h1 + (int64_t)n * (T + h1) + t) * d.C + c, o1);
+            if (amax) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mx1 = fmaxf(mx1, fabsf(o1[j]));
+            }
+            if (HAS2 && dy2_hi) {
+                if (d.mean2) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o2[j] = c2.sc[j] * (o.g[j] - sg2[j] * invM - o.xh2[j] * sgx2[j] * invM);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o2[j] = o.g[j] * c2.sc[j];
+                }
+                store8_split(dy2_hi, dy2_lo, ((int64_t)h2 + (int64_t)n * (T + h2) + t) * d.C + c, o2);
+                if (amax) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) mx2 = fmaxf(mx2, fabsf(o2[j]));
+                }
+            }
+        }
+    }
+    // ---- halo rows of the shared-halo layout: (N+1) gaps of h rows each, this block's share (its slab's 128 bytes per row)
+    {
+        const int nchunks = gridDim.x / nslabs;
+        float z[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = 0.f;
+        for (int pass = 0; pass < 2; ++pass) {
+            bf16_raw* hi = pass ? dy2_hi : dy_hi;
+            bf16_raw* lo = pass ? dy2_lo : dy_lo;
+            const int h = pass ? h2 : h1;
+            if (hi == nullptr || h == 0) continue;
+            const int total = h * (N + 1);
+            const int per = (total + nchunks - 1) / nchunks;
+            int e = (chunk + 1) * per;
+            if (e > total) e = total;
+            for (int hr = chunk * per + wave * 8 + rr; hr < e; hr += 32) {
+                const int gap = hr / h, r = hr - gap * h;
+                store8_split(hi, lo, ((int64_t)gap * (T + h) + r) * d.C + c, z);
+            }
+        }
+    }
+    if (amax) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            mx1 = fmaxf(mx1, __shfl_xor(mx1, m, 64));
+            mx2 = fmaxf(mx2, __shfl_xor(mx2, m, 64));
+        }
+        if (lane == 0) {
+            atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx1));
+            if (HAS2 && dy2_hi) atomicMax(reinterpret_cast<unsigned*>(amax) + 1, __float_as_uint(mx2));
+        }
+    }
+}
+
 // e4m3 quantisation with the scale taken from a device-resident amax (no host round trip): scale = the power of two that
 // puts amax at <= 224 (one binade of head-room below e4m3's 448); inv_scale[0] = 1 / scale for the consumer's epilogue
 __global__ __launch_bounds__(256) void quantize_e4m3_dyn_kernel(const bf16_raw* src, int64_t ngroups, const float* amax,
@@ -618,6 +767,31 @@ extern "C" int w2l_bn_act_bwd_apply(const w2l_bnact_t* d, const w2l_gradsrc_t* g
                                     const float* sums, void* dy_hi, void* dy_lo, int halo, void* dy2_hi, void* dy2_lo,
                                     int halo2, void* stream) {
     return w2l_bn_act_bwd_apply_amax(d, g1, g2, sums, dy_hi, dy_lo, halo, dy2_hi, dy2_lo, halo2, nullptr, stream);
+}
+
+extern "C" int w2l_bn_act_bwd_apply_fin(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2,
+                                        const float* partial, int nblocks, float* sums, void* dy_hi, void* dy_lo, int halo,
+                                        void* dy2_hi, void* dy2_lo, int halo2, float* amax, void* stream) {
+    if (int e = check_desc(d, "bn_act_bwd_apply_fin")) return e;
+    W2L_CHECK_ARG(g1 && g1->dxp && dy_hi && partial && sums && nblocks > 0, "bn_act_bwd_apply_fin: null pointer / no partial rows");
+    W2L_CHECK_ARG(d->C % BWD_SLAB == 0, "bn_act_bwd_apply_fin: C=%d must be a multiple of %d", d->C, BWD_SLAB);
+    W2L_CHECK_ARG(!g2 || g2->f32 == g1->f32, "bn_act_bwd_apply_fin: gradient sources must share a dtype");
+    W2L_CHECK_ARG(halo >= 0 && halo2 >= 0, "bn_act_bwd_apply_fin: negative halo");
+    W2L_CHECK_ARG(g1->rows >= g1->pad_l + d->T + g1->pad_r && (!g2 || g2->rows >= g2->pad_l + d->T + g2->pad_r),
+                  "bn_act_bwd_apply_fin: gradient source has too few rows per utterance");
+    const int64_t rows = (int64_t)d->N * d->T;
+    W2L_CHECK_ARG((rows + (int64_t)(halo + halo2) * (d->N + 1)) * (d->C / 8) < (1LL << 31),
+                  "bn_act_bwd_apply_fin: tensor too large for 32-bit indexing");
+    const int rpb = apply_rows_per_block(rows, d->C);
+    const int nchunks = (int)((rows + rpb - 1) / rpb);
+    const int blocks = nchunks * (d->C / BWD_SLAB);
+    const float inv_keep = 1.f / (1.f - d->drop_p);
+    w2l_gradsrc_t g2v = g2 ? *g2 : *g1;
+    W2L_DISPATCH_BWD(bn_act_bwd_apply_fin_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d, *g1, g2v, g2 ? 1 : 0,
+                     partial, nblocks, sums, (bf16_raw*)dy_hi, (bf16_raw*)dy_lo, halo, (bf16_raw*)dy2_hi, (bf16_raw*)dy2_lo,
+                     halo2, inv_keep, amax, rpb);
+    W2L_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int w2l_quantize_e4m3_dyn(const void* src_bf16, int64_t n, const float* amax, void* dst, float* inv_scale,

@@ -315,6 +315,9 @@ DETERMINISTIC_WGRAD = os.environ.get('W2L_DETERMINISTIC', '0') == '1'
 # gradient wrt its output (w2l_conv1d_dgrad_bnreduce_ws): one kernel less per layer on the backward critical path, where it
 # queued behind the weight-gradient blocks of the side stream.  W2L_FUSED_BN_REDUCE=0: separate w2l_bn_act_bwd_reduce pass.
 FUSED_BN_REDUCE = os.environ.get('W2L_FUSED_BN_REDUCE', '1') != '0'
+# the column sums of the BatchNorm-backward partials are re-formed by every block of the dy kernel for its own 64 channels
+# (w2l_bn_act_bwd_apply_fin) instead of by a finalize launch of their own.  W2L_FOLD_BN_FINALIZE=0: separate launch.
+FOLD_BN_FINALIZE = os.environ.get('W2L_FOLD_BN_FINALIZE', '1') != '0'
 
 
 def _wgrad_workspace(dev, cin, cout, kw):
@@ -877,6 +880,7 @@ class StackEngine:
             g1 = self._gsrc(srcs[0])
             g2 = self._gsrc(srcs[1]) if len(srcs) > 1 else None
             sums = None
+            fold = False
             if u.main.has_bn or (u.res is not None and u.res.has_bn):
                 ncomp = 4 if u.res is not None else 2
                 fused = [s_[5] for s_ in srcs if len(s_) > 5 and s_[5] is not None]
@@ -891,7 +895,9 @@ class StackEngine:
                                                     st()), 'w2l_bn_act_bwd_reduce')
                 sums = small_pool[pool_off: pool_off + 4 * coutp].view(4, coutp)
                 pool_off += 4 * coutp
-                check(lib.w2l_bn_bwd_finalize(ptr(partial), nb, coutp, ncomp, ptr(sums), st()), 'w2l_bn_bwd_finalize')
+                fold = FOLD_BN_FINALIZE and batch_stats
+                if not fold:
+                    check(lib.w2l_bn_bwd_finalize(ptr(partial), nb, coutp, ncomp, ptr(sums), st()), 'w2l_bn_bwd_finalize')
                 uc.keep.append((partial, sums))
             main, res = u.main, u.res
             need_dx_main = self._needs_grad(u.src, ctx)
@@ -911,9 +917,14 @@ class StackEngine:
             fp8_dgrad = self.fp8 and coutp % 128 == 0 and (FP8_DGRAD == '1' or (FP8_DGRAD == 'auto' and
                                                                                   N * Tout >= FP8_DGRAD_MIN_ROWS))
             amax = amax_pool[2 * oi: 2 * oi + 2] if fp8_dgrad else None
-            check(lib.w2l_bn_act_bwd_apply_amax(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(sums), ptr(dy_hi),
-                                                ptr(dy_lo), h1, ptr(dy2_hi), ptr(dy2_lo), h2, ptr(amax), st()),
-                  'w2l_bn_act_bwd_apply')
+            if fold:
+                check(lib.w2l_bn_act_bwd_apply_fin(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(partial), nb,
+                                                   ptr(sums), ptr(dy_hi), ptr(dy_lo), h1, ptr(dy2_hi), ptr(dy2_lo), h2, ptr(amax),
+                                                   st()), 'w2l_bn_act_bwd_apply_fin')
+            else:
+                check(lib.w2l_bn_act_bwd_apply_amax(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(sums), ptr(dy_hi),
+                                                    ptr(dy_lo), h1, ptr(dy2_hi), ptr(dy2_lo), h2, ptr(amax), st()),
+                      'w2l_bn_act_bwd_apply')
             # release the consumed gradient buffers early
             act_grads[oi] = []
             # BN parameter gradients: d beta = sum g, d gamma = sum g * xhat
