@@ -401,6 +401,35 @@ def test_deterministic_mode_is_bit_reproducible(monkeypatch):
         assert scale_err(ga.cpu().numpy(), gc.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('fused,fold', [(True, False), (False, True), (True, True)])
+def test_optional_bn_backward_paths(fused, fold, monkeypatch):
+    """the two opt-in forms of the BatchNorm backward -- the reduction formed in the data gradient's epilogue
+    (W2L_FUSED_BN_REDUCE=1, w2l_conv1d_dgrad_bnreduce_ws) and the finalize folded into the dy kernel (W2L_FOLD_BN_FINALIZE=1,
+    w2l_bn_act_bwd_apply_fin) -- give the same step as the default three-launch form: Wav2Letter stack with dropout, reflect
+    padding, stride 2, dilation 2 (fp32 mode falls back to the separate reduction: bf16 here), and the Jasper fixture with
+    residual branches, masks and two gradient sources per block input"""
+    from gpu_helpers import build_jasper, compare_jasper_step
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd import engine as E
+    monkeypatch.setattr(E, 'FUSED_BN_REDUCE', fused)
+    monkeypatch.setattr(E, 'FOLD_BN_FINALIZE', fold)
+    layers = [(128, 11, 2, 1, 0.2), (192, 13, 1, 1, 0.3), (128, 29, 1, 2, 0.2)]
+    sd = O.init_wav2letter_state(layers, seed=81)
+    model = build_w2l(layers, sd, 'bf16', dropout=True).train()
+    x, il, tg, tl = O.synthetic_batch(5, 333, seed=82, s_lo=10, s_hi=40)
+    errs, stats, *_ = compare_step(model, layers, sd, x, il, tg, tl, 'bf16', drop=True)
+    check(errs, stats, 'bf16')
+    z = load('jasper_dense.npz')
+    meta = ast.literal_eval(str(z['meta']))
+    sdj = {k[3:]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith('p0/')}
+    for precision in ('bf16', 'fp32'):
+        mj = build_jasper(meta['blocks'], sdj, precision).train()
+        xj = torch.from_numpy(z['x'])
+        ilj, tgj, tlj = (torch.from_numpy(z[k]) for k in ('in_lens', 'targets', 'target_lens'))
+        errs, stats, out, out_lens = compare_jasper_step(mj, meta['blocks'], sdj, xj, ilj, tgj, tlj, precision)
+        check(errs, stats, precision)
+
+
 @pytest.mark.parametrize('order', [2, 3])
 def test_stream_k_weight_gradients_end_to_end(order):
     """every weight gradient of a step through the stream-K plan of conv_wgrad_kernel (forced; the tuner picks it per

@@ -18,7 +18,8 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 import torch  # noqa: E402,F401  -- must be imported first so the .so binds to torch's bundled HIP runtime
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libw2l_hip.so')
+# W2L_LIB=<path>: load another build of the library (A/B experiments: csrc/Makefile BUILD= EXTRA= OUT=)
+LIB_PATH = os.environ.get('W2L_LIB') or os.path.join(_HERE, 'libw2l_hip.so')
 
 c_p = C.c_void_p
 c_i = C.c_int

@@ -311,13 +311,17 @@ _retired_ws = []                   # outgrown workspaces (grown only while shape
 # W2L_DETERMINISTIC=1: split weight-gradient reductions go through slabs summed in a fixed order instead of fp32 atomics
 # (bit-reproducible gradients, no zero fills) -- measured 6 % slower on the Wav2Letter table (943 vs 1004 TFLOP/s), so opt-in
 DETERMINISTIC_WGRAD = os.environ.get('W2L_DETERMINISTIC', '0') == '1'
-# the BatchNorm-backward reduction of a layer is formed in the epilogue of the data-gradient convolution that produces the
-# gradient wrt its output (w2l_conv1d_dgrad_bnreduce_ws): one kernel less per layer on the backward critical path, where it
-# queued behind the weight-gradient blocks of the side stream.  W2L_FUSED_BN_REDUCE=0: separate w2l_bn_act_bwd_reduce pass.
-FUSED_BN_REDUCE = os.environ.get('W2L_FUSED_BN_REDUCE', '1') != '0'
-# the column sums of the BatchNorm-backward partials are re-formed by every block of the dy kernel for its own 64 channels
-# (w2l_bn_act_bwd_apply_fin) instead of by a finalize launch of their own.  W2L_FOLD_BN_FINALIZE=0: separate launch.
-FOLD_BN_FINALIZE = os.environ.get('W2L_FOLD_BN_FINALIZE', '1') != '0'
+# W2L_FUSED_BN_REDUCE=1: the BatchNorm-backward reduction of a layer is formed in the epilogue of the data-gradient
+# convolution that produces the gradient wrt its output (w2l_conv1d_dgrad_bnreduce_ws) instead of by w2l_bn_act_bwd_reduce:
+# one kernel less per layer on the backward critical path.  OFF by default -- measured on one MI355X, four runs each,
+# Wav2Letter N=32: 13.75-13.85 ms per step with it, 13.71-13.94 without (Jasper 10x5: 20.0 vs 20.1): the epilogue costs the
+# data gradients what the separate pass cost (conv_igemm_kernel 1166 instead of 1246 TFLOP/s), the step is bound by the sum
+# of the kernels' work, not by the number of launches on its critical path.
+FUSED_BN_REDUCE = os.environ.get('W2L_FUSED_BN_REDUCE', '0') == '1'
+# W2L_FOLD_BN_FINALIZE=1: the column sums of the BatchNorm-backward partials are re-formed by every block of the dy kernel
+# for its own 64 channels (w2l_bn_act_bwd_apply_fin) instead of by a finalize launch of their own.  OFF by default: measured
+# neutral to slightly slower (13.75-13.85 vs 13.71-13.80 ms; with the separate reduction pass 14.1 vs 13.7-13.9).
+FOLD_BN_FINALIZE = os.environ.get('W2L_FOLD_BN_FINALIZE', '0') == '1'
 
 
 def _wgrad_workspace(dev, cin, cout, kw):
