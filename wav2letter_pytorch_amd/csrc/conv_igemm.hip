@@ -221,9 +221,6 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
                     for (int ni = 0; ni < NS; ++ni)
                         acc[mi][ni] = mfma_e4m3_k128(a0[mi], a1[mi], b0[ni], b1[ni], acc[mi][ni]);
             } else {
-#ifdef W2L_SETPRIO
-                __builtin_amdgcn_s_setprio(1);
-#endif
     #pragma unroll
                 for (int mi = 0; mi < MS; ++mi)
     #pragma unroll
@@ -234,9 +231,6 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
     #pragma unroll
                     for (int ni = 0; ni < NS; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
-#ifdef W2L_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
                 // schedule: ks0 fragment reads, then ks1 reads slotted one per MFMA into the ks0 MFMAs, then the rest
                 __builtin_amdgcn_sched_group_barrier(0x100, MS + NS, 0);
     #pragma unroll
@@ -265,17 +259,11 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
             for (int ni = 0; ni < NS; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(B + ni * 16 * S * ROWB);
         };
         auto mfma_all = [&](const bf16x8* a, const bf16x8* b) {
-#ifdef W2L_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
     #pragma unroll
             for (int mi = 0; mi < MS; ++mi)
     #pragma unroll
                 for (int ni = 0; ni < NS; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-#ifdef W2L_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
         };
         // schedule of one half step: MS+NS fragment reads slotted one per MFMA into the first MFMAs, then the rest
         auto sched_half = [&]() {

@@ -286,9 +286,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
                 if (have_nn) stage(adst, bdst, n_nn, ts_nn);        // step+2 -> this step's buffers
                 load_b(b[(g + 1) & 1], 0, 0);
             }
-#ifdef W2L_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -297,9 +294,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
                 if (!lastg && ks2 != ks) load_a1(mi, ks2);
                 if (lastg && !LAST) load_a1(mi, 0);
             }
-#ifdef W2L_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
         }
     };
     auto advance = [&](int& n, int& ts) {
