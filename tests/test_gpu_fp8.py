@@ -5,8 +5,6 @@ Kernel level: the device's quantisation is bit-identical to torch's float8_e4m3f
 quantised operands equals the fp32 convolution of the SAME (dequantised) values -- the MFMA path itself is exact up to
 fp32 accumulation order.  Model level: the step in fp8 mode against the fp32 oracle at the documented fp8 bounds (e4m3
 keeps 4 significant bits: a forward layer is good to a few percent, where bf16 mode is good to a few tenths of one)."""
-import ctypes as C_
-
 import numpy as np
 import pytest
 import torch

@@ -18,8 +18,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_helpers import (build_jasper, build_w2l, check_gate_ties, compare_jasper_step, compare_step, device_dropout_masks,
-                         device_gates, device_step, scale_err)
+from gpu_helpers import build_jasper, build_w2l, compare_step, device_dropout_masks, device_gates, device_step, scale_err
 
 pytestmark = pytest.mark.gpu
 
