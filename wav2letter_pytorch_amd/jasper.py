@@ -28,20 +28,19 @@ jasper_activations = {
 
 
 def init_weights(m, mode='xavier_uniform'):
-    """jasper.py:29-50"""
-    if isinstance(m, MaskedConv1d):
-        init_weights(m.conv, mode)
-    if isinstance(m, Conv1d):
-        if mode == 'xavier_uniform':
-            m.reset_parameters('xavier_uniform')
-        else:
+    """Module initialiser for ``nn.Module.apply`` (jasper.py:29-50): convolutions (bare or wrapped in a MaskedConv1d) get
+    xavier-uniform weights (gain 1) -- the only mode there is --, BatchNorm layers go back to their blank state (zero mean,
+    unit variance, gamma 1, beta 0, no batches seen)."""
+    conv = m.conv if isinstance(m, MaskedConv1d) else m
+    if isinstance(conv, Conv1d):
+        if mode != 'xavier_uniform':
             raise ValueError("Unknown Initialization mode: {0}".format(mode))
+        conv.reset_parameters('xavier_uniform')
     elif isinstance(m, BatchNorm1d):
-        m.running_mean.zero_()
-        m.running_var.fill_(1)
-        m.num_batches_tracked.zero_()
-        nn.init.ones_(m.weight)
-        nn.init.zeros_(m.bias)
+        with torch.no_grad():
+            for buf, value in ((m.running_mean, 0.0), (m.running_var, 1.0), (m.weight, 1.0), (m.bias, 0.0)):
+                buf.fill_(value)
+            m.num_batches_tracked.zero_()
 
 
 def compute_new_kernel_size(kernel_size, kernel_width):
@@ -106,7 +105,8 @@ class MaskedConv1d(nn.Module):
 
 
 class GroupShuffle(nn.Module):
-    """jasper.py:135-151 (channel shuffle for grouped convs; not reachable from the config)."""
+    """Channel shuffle between grouped convolutions (jasper.py:135-151): channel g*cpg + j moves to j*groups + g.  Not
+    reachable from the config (``groups`` is never plumbed through ``_build_encoder``); plain torch view ops."""
 
     def __init__(self, groups, channels):
         super(GroupShuffle, self).__init__()
@@ -114,10 +114,9 @@ class GroupShuffle(nn.Module):
         self.channels_per_group = channels // groups
 
     def forward(self, x):
-        sh = x.shape
-        x = x.view(-1, self.groups, self.channels_per_group, sh[-1])
-        x = torch.transpose(x, 1, 2).contiguous()
-        return x.view(-1, self.groups * self.channels_per_group, sh[-1])
+        n, t = x.shape[0], x.shape[-1]
+        grouped = x.reshape(n, self.groups, self.channels_per_group, t)
+        return grouped.permute(0, 2, 1, 3).reshape(n, self.groups * self.channels_per_group, t)
 
 
 class JasperBlock(nn.Module):
