@@ -256,13 +256,16 @@ int w2l_bn_act_bwd_apply(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2
 int w2l_bn_act_bwd_apply_fin(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2, const float* partial,
                              int nblocks, float* sums, void* dy_hi, void* dy_lo, int halo, void* dy2_hi, void* dy2_lo,
                              int halo2, float* amax, void* stream);
-/* the same, also leaving max |dy| (amax[0]) and max |dy2| (amax[1]) in device memory (integer atomic max on the bit
- * patterns: the caller zeroes amax first) -- the scale of the e4m3 copy of dy that the data gradient reads in fp8 mode */
+/* the same, also leaving max |dy| and max |dy2| in device memory -- the scale of the e4m3 copy of dy that the data gradient
+ * reads in fp8 mode.  amax is [2][W2L_AMAX_SLOTS] floats, zeroed by the caller: slot (block index mod W2L_AMAX_SLOTS) of row
+ * 0 (dy) / row 1 (dy2) takes an integer atomic max of the bit patterns; the tensor's amax is the max over a row's slots
+ * (one word per tensor would serialise every wave of the launch on one L2 address). */
+#define W2L_AMAX_SLOTS 64
 int w2l_bn_act_bwd_apply_amax(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2, const float* sums,
                               void* dy_hi, void* dy_lo, int halo, void* dy2_hi, void* dy2_lo, int halo2, float* amax,
                               void* stream);
-/* dst[i] = e4m3(src[i] * s), s = 2^floor(log2(224 / amax[0])) read from DEVICE memory (no host round trip; s = 1 when
- * amax is 0); inv_scale[0] = 1 / s for the consumer (w2l_conv1d_igemm_fp8 descale_dev).  src bf16, n a multiple of 8. */
+/* dst[i] = e4m3(src[i] * s), s = 2^floor(log2(224 / max(amax[0..W2L_AMAX_SLOTS)))) read from DEVICE memory (no host round
+ * trip; s = 1 when amax is 0); inv_scale[0] = 1 / s for the consumer (w2l_conv1d_igemm_fp8 descale_dev).  src bf16, n a multiple of 8. */
 int w2l_quantize_e4m3_dyn(const void* src_bf16, int64_t n, const float* amax, void* dst, float* inv_scale, void* stream);
 
 /* The data gradient of a stride-1 nn.Conv1d FUSED with w2l_bn_act_bwd_reduce of the layer that produced the conv's input

@@ -376,6 +376,7 @@ def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw
 # quantisations (one host sync per weight then; weights move by lr * grad per step, and the conversion saturates).
 FP8_ACT_SCALE = {ACT_CLAMP20: 16.0, ACT_RELU: 8.0, ACT_NONE: 8.0}
 FP8_WEIGHT_RESCALE = 256
+AMAX_SLOTS = 64                    # include/w2l_hip.h W2L_AMAX_SLOTS
 # fp8 mode, data gradients: on e4m3 operands too ('1'), in bf16 ('0'), or (default 'auto') e4m3 only from FP8_DGRAD_MIN_ROWS
 # rows of dy per launch.  The e4m3 data gradient needs two more launches per layer on the backward critical path (dy's
 # quantisation, and the BatchNorm-backward reduction its epilogue cannot form) -- measured on one MI355X, ms per step,
@@ -868,7 +869,8 @@ class StackEngine:
         N = ctx['out'].shape[0]
         dev = ctx['out'].device
         st = stream_ptr
-        amax_pool = torch.zeros(2 * (len(acts) + 1), dtype=torch.float32, device=dev) if self.fp8 else None   # one fill per step
+        amax_pool = (torch.zeros(len(acts) + 1, 2, AMAX_SLOTS, dtype=torch.float32, device=dev)        # one fill per step
+                     if self.fp8 else None)
         for uc in reversed(ctx['units']):
             u = uc.unit
             oi = uc.out_index
@@ -920,7 +922,7 @@ class StackEngine:
             # fp8 mode: the kernel also leaves max |dy| (|dy2|) in device memory -- the scale of dy's e4m3 copy
             fp8_dgrad = self.fp8 and coutp % 128 == 0 and (FP8_DGRAD == '1' or (FP8_DGRAD == 'auto' and
                                                                                   N * Tout >= FP8_DGRAD_MIN_ROWS))
-            amax = amax_pool[2 * oi: 2 * oi + 2] if fp8_dgrad else None
+            amax = amax_pool[oi] if fp8_dgrad else None          # [2][AMAX_SLOTS]: dy, dy2
             if fold:
                 check(lib.w2l_bn_act_bwd_apply_fin(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(partial), nb,
                                                    ptr(sums), ptr(dy_hi), ptr(dy_lo), h1, ptr(dy2_hi), ptr(dy2_lo), h2, ptr(amax),
@@ -949,13 +951,13 @@ class StackEngine:
                     self._set(grads, main.bias, self._dy_colsum(dy_hi, dy_lo, h1, N, Tout, coutp, main.cout))
             if u.dw is not None:
                 dmid = self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src,      # (wrt the depthwise output: no BatchNorm there)
-                                   amax=None if amax is None else amax[0:1])
+                                   amax=None if amax is None else amax[0])
                 gsrc = self._dw_backward(u.dw, dmid, acts[u.src], uc.mid, need_dx_main, grads)
                 if gsrc is not None:
                     act_grads[u.src].append(gsrc)
             elif need_dx_main:
                 act_grads[u.src].append(self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, self._producer(ctx, u.src),
-                                                    amax=None if amax is None else amax[0:1]))
+                                                    amax=None if amax is None else amax[0]))
             if res is not None:
                 pkr = pack_weights(res, precise)
                 rsrc = acts[u.res_src]
@@ -968,7 +970,7 @@ class StackEngine:
                 if self._needs_grad(u.res_src, ctx):
                     act_grads[u.res_src].append(self._dgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc,
                                                             self._producer(ctx, u.res_src),
-                                                            amax=None if amax is None else amax[1:2]))
+                                                            amax=None if amax is None else amax[1]))
     # ------------------------------------------------------------------ helpers
     def _needs_grad(self, act_index: int, ctx=None) -> bool:
         # the spectrogram needs no gradient in training (base_asr_models.py:78-85); computed only on request
