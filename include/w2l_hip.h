@@ -44,10 +44,12 @@ int w2l_pack_weights(const float* w, int64_t s_co, int64_t s_ci, int64_t s_kw, i
  * first_step != 0 initialises the momentum buffer with the (decayed) gradient as torch does.  The bf16
  * outputs are the operands of the next step (no channel padding: Cout, Cin multiples of 64).  zero_grad != 0 writes
  * zeros back into g once it has been read: the buffer can then serve as the next step's dw without a fill launch
- * (split-K weight gradients accumulate with atomics into a zeroed buffer, see w2l_wgrad_needs_zero). */
+ * (split-K weight gradients accumulate with atomics into a zeroed buffer, see w2l_wgrad_needs_zero).  w_fwd_q / w_dgr_q
+ * (optional, fp8 mode): the same two operands once more as e4m3 bytes, value * q_scale, so that the forward and the data
+ * gradient of the next step need no quantisation pass over the weights. */
 int w2l_sgd_pack(float* p, float* g, float* m, int first_step, float lr, float momentum, float weight_decay,
                  int nesterov, int zero_grad, int Cout, int Cin, int Kw, void* w_fwd_hi, void* w_fwd_lo, void* w_dgr_hi,
-                 void* w_dgr_lo, void* stream);
+                 void* w_dgr_lo, void* w_fwd_q, void* w_dgr_q, float q_scale, void* stream);
 
 /* input spectrogram fp32 [N][C][T] -> padded NTC bf16 [N][pad_l+T+pad_r][CP];
  * pad_mode 1 = reflect (nn.ReflectionPad1d, wav2letter.py:28-34,41), 0 = zeros

@@ -199,3 +199,44 @@ def test_jasper_fp8_long_utterance_T16000():
     assert e_lp < 1.5e-1 and e_loss < 5e-2
     for k, p in model.named_parameters():
         assert torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, k
+
+
+@pytest.mark.parametrize('overlap', [False, True])
+def test_fused_sgd_keeps_the_e4m3_operands_current(overlap):
+    """in fp8 mode the fused SGD kernel (w2l_sgd_pack) also emits next step's e4m3 weight operands, forward and flipped-tap
+    layout: after every step they are bit-identical to a fresh quantisation of the updated bf16 operands, the engine finds
+    them current (no requantisation launch), and training moves"""
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd import engine as E
+    from wav2letter_pytorch_amd.optim import FusedSGD
+    layers = [(128, 11, 2, 1, 0.0), (256, 13, 1, 1, 0.0), (128, 5, 1, 2, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=91)
+    model = build_w2l(layers, sd, 'fp8').train()
+    opt = FusedSGD.from_sgd(torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-4))
+    opt.overlap = overlap
+    x, il, tg, tl = O.synthetic_batch(4, 300, seed=92, s_lo=8, s_hi=25)
+    E.FP8_DGRAD = '1'
+    try:
+        losses = []
+        for it in range(4):
+            opt.zero_grad(set_to_none=True)
+            out, ol = model(x.cuda(), il)
+            loss = model.criterion(out.transpose(0, 1), tg, ol, tl)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        opt.join()
+        torch.cuda.synchronize()
+    finally:
+        E.FP8_DGRAD = 'auto'
+    assert losses[-1] < losses[0]
+    for name in ('conv1d_1', 'conv1d_2'):
+        w = getattr(model.conv1ds, name).conv1.weight
+        st, pk = w._w2l_fp8, w._w2l_pack[False]
+        assert st['version'] == pk.version == st['version_d'] and st['age'] >= 3
+        L = __import__('wav2letter_pytorch_amd')._lib
+        for q, src in ((st['q'], pk.fwd_hi), (st['qd'], pk.dgr_hi)):
+            want = torch.empty_like(q)
+            L.check(L.lib.w2l_quantize_e4m3(L.ptr(src), 0, src.numel(), st['scale'], L.ptr(want), L.stream_ptr()))
+            torch.cuda.synchronize()
+            assert torch.equal(q, want), name

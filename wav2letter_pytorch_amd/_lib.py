@@ -52,7 +52,7 @@ _SIGNATURES = {
     'w2l_tune_save': (c_i, [C.c_char_p]),
     'w2l_tune_load': (c_i, [C.c_char_p]),
     'w2l_pack_weights': (c_i, [c_p, c_i64, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
-    'w2l_sgd_pack': (c_i, [c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    'w2l_sgd_pack': (c_i, [c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p]),
     'w2l_novograd_pack': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p,
                                 c_p]),
     'w2l_nct_to_ntc': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),

@@ -51,9 +51,15 @@ __global__ void pack_weights_kernel(const float* w, int64_t s_co, int64_t s_ci, 
 // read p, g, m; write p, m, 2 x bf16 -- instead of torch's multi-pass foreach update plus a separate pack.
 // Update rule = torch.optim.SGD (dampening 0): g += wd*p; m = first ? g : mu*m + g; g = nesterov ? g + mu*m : m;
 // p -= lr*g.
+// one float -> one OCP e4m3 byte (round to nearest even, saturating at +-448)
+__device__ __forceinline__ uint8_t quant1_e4m3(float v) {
+    v = fminf(fmaxf(v, -448.f), 448.f);
+    return (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false) & 0xFF);
+}
+
 __global__ void sgd_pack_kernel(float* p, float* g, float* m, int first, float lr, float mu, float wd,
                                 int nesterov, int zero_grad, int Cout, int Cin, int Kw, bf16_raw* fwd_hi, bf16_raw* fwd_lo,
-                                bf16_raw* dgr_hi, bf16_raw* dgr_lo) {
+                                bf16_raw* dgr_hi, bf16_raw* dgr_lo, uint8_t* fwd_q, uint8_t* dgr_q, float q_scale) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, kw = blockIdx.z;
@@ -72,6 +78,8 @@ __global__ void sgd_pack_kernel(float* p, float* g, float* m, int first, float l
             p[off] = pv;
             v = pv;
             if (fwd_hi) put_split(fwd_hi, fwd_lo, off, pv);
+            // fp8 mode: the e4m3 operand of the next forward, quantised from the bf16-rounded value like w2l_quantize_e4m3
+            if (fwd_q) fwd_q[off] = quant1_e4m3(bf16_bits_to_f32(f32_to_bf16_bits(pv)) * q_scale);
         }
         tile[j][tx] = v;
     }
@@ -79,8 +87,11 @@ __global__ void sgd_pack_kernel(float* p, float* g, float* m, int first, float l
     if (dgr_hi) {
         for (int j = ty; j < 32; j += 8) {
             const int ci = ci0 + j, co = co0 + tx;
-            if (co < Cout && ci < Cin)
-                put_split(dgr_hi, dgr_lo, ((int64_t)(Kw - 1 - kw) * Cin + ci) * Cout + co, tile[tx][j]);
+            if (co < Cout && ci < Cin) {
+                const int64_t o = ((int64_t)(Kw - 1 - kw) * Cin + ci) * Cout + co;
+                put_split(dgr_hi, dgr_lo, o, tile[tx][j]);
+                if (dgr_q) dgr_q[o] = quant1_e4m3(bf16_bits_to_f32(f32_to_bf16_bits(tile[tx][j])) * q_scale);
+            }
         }
     }
 }
@@ -244,14 +255,16 @@ extern "C" int w2l_pack_weights(const float* w, int64_t s_co, int64_t s_ci, int6
 
 extern "C" int w2l_sgd_pack(float* p, float* g, float* m, int first_step, float lr, float momentum,
                             float weight_decay, int nesterov, int zero_grad, int Cout, int Cin, int Kw, void* w_fwd_hi,
-                            void* w_fwd_lo, void* w_dgr_hi, void* w_dgr_lo, void* stream) {
+                            void* w_fwd_lo, void* w_dgr_hi, void* w_dgr_lo, void* w_fwd_q, void* w_dgr_q, float q_scale,
+                            void* stream) {
+    W2L_CHECK_ARG((!w_fwd_q && !w_dgr_q) || (q_scale > 0.f && w_fwd_hi && w_dgr_hi), "sgd_pack: e4m3 operands need a scale");
     W2L_CHECK_ARG(p && g && m, "sgd_pack: null pointer");
     W2L_CHECK_ARG(Cout > 0 && Cin > 0 && Kw > 0, "sgd_pack: bad sizes");
     W2L_CHECK_ARG(!(w_fwd_lo && !w_fwd_hi) && !(w_dgr_lo && !w_dgr_hi), "sgd_pack: lo without hi");
     dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, Kw), block(32, 8);
     hipLaunchKernelGGL(sgd_pack_kernel, grid, block, 0, (hipStream_t)stream, p, g, m, first_step, lr, momentum,
                        weight_decay, nesterov, zero_grad, Cout, Cin, Kw, (bf16_raw*)w_fwd_hi, (bf16_raw*)w_fwd_lo,
-                       (bf16_raw*)w_dgr_hi, (bf16_raw*)w_dgr_lo);
+                       (bf16_raw*)w_dgr_hi, (bf16_raw*)w_dgr_lo, (uint8_t*)w_fwd_q, (uint8_t*)w_dgr_q, q_scale);
     W2L_CHECK_LAUNCH();
     return 0;
 }

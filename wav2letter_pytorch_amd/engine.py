@@ -380,10 +380,10 @@ AMAX_SLOTS = 64                    # include/w2l_hip.h W2L_AMAX_SLOTS
 # fp8 mode, data gradients: on e4m3 operands too ('1'), in bf16 ('0'), or (default 'auto') e4m3 only from FP8_DGRAD_MIN_ROWS
 # rows of dy per launch.  The e4m3 data gradient needs two more launches per layer on the backward critical path (dy's
 # quantisation, and the BatchNorm-backward reduction its epilogue cannot form) -- measured on one MI355X, ms per step,
-# bf16 / fp8 forward only / fp8 forward + data gradient: Wav2Letter N=32 x T=1000 13.7 / 12.6-12.9 / 13.9, Jasper 10x5 N=16 x
-# T=1000 19.4 / 18.2 / 23.1, Jasper 10x5 N=16 x T=16000 - / 190 / 176: a gain only where the kernels are long.
+# bf16 / fp8 forward only / fp8 forward + data gradient: Wav2Letter N=32 x T=1000 13.76 / 12.7-12.9 / 12.3-12.4, Jasper 10x5
+# N=16 x T=1000 19.4 / 18.4 / 18.75, Jasper 10x5 N=16 x T=16000 208 / 190 / 170: a gain from ~12 000 rows per launch.
 FP8_DGRAD = os.environ.get('W2L_FP8_DGRAD', 'auto')
-FP8_DGRAD_MIN_ROWS = 65536
+FP8_DGRAD_MIN_ROWS = 12288
 
 
 def _fp8_weights(conv: ConvSpec, pk: '_PackedW', dgrad: bool = False):

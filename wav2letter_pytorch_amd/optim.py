@@ -146,15 +146,25 @@ class FusedSGD(torch.optim.SGD):
         # the gradient buffer is handed back to the step engine zero-filled (engine._wgrad_now takes it as the next dW when
         # zero_grad(set_to_none=True) has dropped p.grad): no fill launch for the split-K weight gradients of the next step
         recycle = self.recycle_grads and not precise
+        # fp8 mode (engine._fp8_weights left its state on the parameter): emit the e4m3 operands of the next step here too,
+        # with the scale in force -- its periodic re-derivation from amax stays with the engine
+        f8 = p.__dict__.get('_w2l_fp8')
+        if f8 is not None and (precise or f8['q'].shape != fwd_hi.shape or f8['q'].device != dev
+                               or f8['age'] >= E.FP8_WEIGHT_RESCALE):
+            f8 = None
         check(lib.w2l_sgd_pack(ptr(p), ptr(g), ptr(buf), int(first), float(lr), float(mu), float(wd), int(nesterov),
-                               int(recycle), cout, cin, kw, ptr(fwd_hi), ptr(fwd_lo), ptr(dgr_hi), ptr(dgr_lo), stream_ptr()),
-              'w2l_sgd_pack')
+                               int(recycle), cout, cin, kw, ptr(fwd_hi), ptr(fwd_lo), ptr(dgr_hi), ptr(dgr_lo),
+                               ptr(f8['q']) if f8 else None, ptr(f8['qd']) if f8 else None, f8['scale'] if f8 else 1.0,
+                               stream_ptr()), 'w2l_sgd_pack')
         if recycle:
             p._w2l_dw_zeroed = g.permute(2, 0, 1)                    # the dense [Kw, Cout, Cin] storage of g
         torch.autograd.graph.increment_version(p)                    # p changed through its raw pointer
         cache.clear()
         pk = E._PackedW(p._version, fwd_hi, fwd_lo, dgr_hi, dgr_lo, cin, cout, p.data_ptr())
         cache[precise] = pk
+        if f8 is not None:                      # both e4m3 layouts are current for this version
+            f8['version'] = f8['version_d'] = pk.version
+            f8['age'] += 1
         return pk
 
     def _plain(self, params, lr, mu, wd, nesterov, dampening, maximize):
