@@ -589,7 +589,7 @@ int launch_cfg(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream
 }
 
 // e4m3 launches: K-loop structure 0, stride 1, a subset of the block shapes (indices into kCfgs)
-constexpr int kF8Cfgs[] = {2, 5, 12, 14, 16};
+constexpr int kF8Cfgs[] = {2, 5, 12, 14, 16, 1, 3, 8, 9, 11, 13, 18, 19};     // (the first five were round 2's first set)
 constexpr int kNumF8Cfgs = sizeof(kF8Cfgs) / sizeof(kF8Cfgs[0]);
 
 template <int MW, int NW, int MS, int NS>
@@ -984,12 +984,20 @@ extern "C" int w2l_conv1d_igemm_fp8(const void* xq, int64_t x_bstride, int64_t x
     const int tiles_m = (Cout + bm - 1) / bm;
     const size_t lds = 2 * (size_t)bm * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
     hipStream_t st = (hipStream_t)stream;
-    switch (k) {
-        case 0: return launch_f8<2, 2, 4, 4>(p, tiles_m, lds, st);
-        case 1: return launch_f8<4, 2, 4, 4>(p, tiles_m, lds, st);
-        case 2: return launch_f8<2, 4, 4, 4>(p, tiles_m, lds, st);
-        case 3: return launch_f8<2, 4, 6, 4>(p, tiles_m, lds, st);
-        default: return launch_f8<2, 4, 8, 4>(p, tiles_m, lds, st);
+    switch (kF8Cfgs[k]) {                       // block shapes of kCfgs
+        case 2: return launch_f8<2, 2, 4, 4>(p, tiles_m, lds, st);
+        case 5: return launch_f8<4, 2, 4, 4>(p, tiles_m, lds, st);
+        case 12: return launch_f8<2, 4, 4, 4>(p, tiles_m, lds, st);
+        case 14: return launch_f8<2, 4, 6, 4>(p, tiles_m, lds, st);
+        case 16: return launch_f8<2, 4, 8, 4>(p, tiles_m, lds, st);
+        case 1: return launch_f8<2, 2, 3, 4>(p, tiles_m, lds, st);
+        case 3: return launch_f8<2, 2, 5, 4>(p, tiles_m, lds, st);
+        case 8: return launch_f8<2, 3, 4, 3>(p, tiles_m, lds, st);
+        case 9: return launch_f8<2, 3, 5, 3>(p, tiles_m, lds, st);
+        case 11: return launch_f8<2, 4, 3, 4>(p, tiles_m, lds, st);
+        case 13: return launch_f8<2, 4, 5, 4>(p, tiles_m, lds, st);
+        case 18: return launch_f8<2, 3, 5, 6>(p, tiles_m, lds, st);
+        default: return launch_f8<2, 3, 6, 6>(p, tiles_m, lds, st);
     }
 }
 
