@@ -61,6 +61,8 @@ def test_w2l_full_table_fp32(autotune, monkeypatch):
     x, il, tg, tl = O.synthetic_batch(2, 1000, seed=1234)
     errs, stats, out, out_lens, ref = compare_step(model, layers, sd, x, il, tg, tl, 'fp32')
     assert out.shape == (2, 500, 29) and [int(v) for v in out_lens] == [500, 500]
+    print(f'w2l full table fp32 (autotune {autotune}): log-probs {errs["log_probs"]:.2e} loss {errs["loss"]:.2e} '
+          f'worst gradient {_worst(errs)[0]:.2e} ({_worst(errs)[1]}) running stats {max(stats.values()):.2e}')
     assert errs['log_probs'] < 1e-3, errs['log_probs']
     assert errs['loss'] < 1e-4, errs['loss']
     assert _worst(errs)[0] < 1e-3, _worst(errs)

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
 
     // ---- split-K through slabs: publish the partial tile, draw a ticket; only the last arriver goes on.  Agent-scope
     // release before the ticket / acquire after it: correct wherever the tile's blocks ran (they are a whole grid row apart).
-    if (p.slabs != nullptr && p.splits > 1) {
+    if (!SK && p.slabs != nullptr && p.splits > 1) {          // (the stream-K launch has no workspace form)
         constexpr int TILE_F = KWB * BM * BNC;
         float* slab = p.slabs + ((int64_t)tile_id * p.splits + split) * TILE_F;
 #pragma unroll
