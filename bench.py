@@ -269,7 +269,11 @@ def main():
     if rank == 0:
         agg = {}
         fused = [0.0, 0.0, 0]
+        by_shape = {}
         for name, flops, s, e in E.KERNEL_TIMER:
+            b = by_shape.setdefault((name, flops), [0.0, 0])
+            b[0] += s.elapsed_time(e) * 1e-3
+            b[1] += 1
             if name.endswith('/dgrad+bnreduce'):          # same kernel family; the launches whose epilogue also forms the
                 name = name.split('/')[0]                 # BatchNorm-backward sums are additionally reported on their own
                 fused[0] += flops
@@ -329,6 +333,10 @@ def main():
         if args.breakdown:
             for k, (f, t_, c) in agg.items():
                 print(f'{k}: {c // 3} launches/step, {t_ / 3 * 1e3:.3f} ms/step, {f / t_ / 1e12:.1f} TFLOP/s', file=sys.stderr)
+            # per problem size (launches of one kernel family with the same algorithmic FLOPs = the same layer shape)
+            for (k, f), (t_, c) in sorted(by_shape.items(), key=lambda kv: -kv[1][0]):
+                print(f'  {k:34s} {f / 1e9:9.2f} GFLOP x {c // 3:3d}/step: {t_ / c * 1e6:8.1f} us each, {f * c / t_ / 1e12:7.1f} TFLOP/s, '
+                      f'{t_ / 3 * 1e3:6.3f} ms/step', file=sys.stderr)
 
     if rank == 0:
         cpu = None
