@@ -4,7 +4,6 @@ are this package's own: one shared step for training and validation, batch-level
 from __future__ import annotations
 
 import random
-from itertools import chain
 from typing import Callable, Dict, Sequence
 
 import torch
@@ -66,12 +65,23 @@ class ConvCTCASR(_Base):
         raise NotImplementedError()
 
     # ------------------------------------------------------------------ engine cache
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float() replace parameter data and buffer tensors: the engine's specs must be rebuilt
+        self.invalidate_engine()
+        return super()._apply(fn, *args, **kwargs)
+
+    def invalidate_engine(self):
+        """drop the cached StackEngine (call after replacing a Parameter / buffer OBJECT by hand; ``module.to()`` and
+        friends do it themselves, in-place updates -- optimizers, load_state_dict -- never need it)"""
+        self.__dict__.pop('_engine_cache', None)
+
     def _cached_engine(self, build: Callable[[], 'object']):
-        """The StackEngine of this module tree, rebuilt only when a parameter / buffer OBJECT or its device changed
-        (``module.to()`` replaces buffer tensors; load_state_dict and optimizers write in place and keep them).  The
-        per-step switches (weight-gradient overlap, graph-mode dropout counter, data-parallel reducer) are re-read on
-        every call, so attaching a ``grad_reducer`` after the first forward takes effect."""
-        key = tuple((id(t), t.device) for t in chain(self.parameters(), self.buffers())) + (getattr(self, 'precision', None),)
+        """The StackEngine of this module tree, built once and kept until the module is moved / cast (``_apply``) or
+        ``invalidate_engine()`` is called (the per-call guard is just precision + device: walking the module tree on every
+        forward cost Jasper 10x5 0.7 ms of host time per step).  The per-step switches (weight-gradient overlap, graph-mode
+        dropout counter, data-parallel reducer) are re-read on every call, so attaching a ``grad_reducer`` after the first
+        forward takes effect."""
+        key = (getattr(self, 'precision', None), next(self.parameters()).device)
         hit = self.__dict__.get('_engine_cache')
         if hit is None or hit[0] != key:
             hit = (key, build())

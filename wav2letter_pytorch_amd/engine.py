@@ -433,6 +433,7 @@ class StackEngine:
         # on a side HIP stream so their blocks fill the tail rounds of the dgrad / elementwise kernels
         self.overlap_wgrad = True
         self._side = None
+        self._main_stream = None     # the caller's stream, looked up once per backward (torch.cuda.current_stream is not free)
         self._side_used = False
         self._held: list = []        # tensors in use by side-stream kernels; released after the join in backward()
         self._nbt_pending: list = []  # num_batches_tracked buffers to bump (one fused launch per forward)
@@ -724,10 +725,7 @@ class StackEngine:
 
     def _bn_finalize(self, conv: ConvSpec, stats, count, cp, training):
         dev = conv.weight.device
-        scale = torch.empty(cp, dtype=torch.float32, device=dev)
-        shift = torch.empty_like(scale)
-        mean = torch.empty_like(scale)
-        invstd = torch.empty_like(scale)
+        scale, shift, mean, invstd = torch.empty(4, cp, dtype=torch.float32, device=dev).unbind(0)     # one allocation
         gamma = _padded_vec(conv.bn_weight, cp, 1.0)
         beta = _padded_vec(conv.bn_bias, cp, 0.0)
         rm, rv = conv.running_mean, conv.running_var
@@ -788,6 +786,7 @@ class StackEngine:
         # eval-mode forward normalised with the RUNNING statistics: they are constants of the step, so dy = scale * g (no
         # batch-mean terms) and the conv bias in front of BatchNorm has the ordinary gradient sum(dy)
         batch_stats = bool(ctx['training'])
+        self._main_stream = torch.cuda.current_stream(dev) if dev.type == 'cuda' else None
         # every per-channel gradient of the step (BatchNorm gamma / beta sums, classifier bias) lives in ONE buffer: a
         # data-parallel run averages it with one collective instead of ~80 small ones (or a gather + scatter of them)
         pool_elems = roundup(self.head.cout, 64) if self.head is not None else 0
@@ -812,8 +811,9 @@ class StackEngine:
         elif self.grad_ready is not None:
             self.grad_ready(None, small_pool, small_pool)
         if self._side_used:
-            torch.cuda.current_stream(dev).wait_stream(self._side)
+            self._main_stream.wait_stream(self._side)
             self._side_used = False
+        self._main_stream = None
         self._held.clear()
         self._zero_pool = None
         _flush_tune_cache()
@@ -1044,7 +1044,7 @@ class StackEngine:
         allocator never has to poll cross-stream events (that polling stalled small-batch steps by 2-3x)."""
         if not self.overlap_wgrad or not dy_hi.is_cuda:
             return self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads)
-        main = torch.cuda.current_stream(dy_hi.device)
+        main = self._main_stream or torch.cuda.current_stream(dy_hi.device)
         if self._side is None or self._side.device != dy_hi.device:
             # ONE stream per device for the life of the process (engines are rebuilt per forward).  HIP multiplexes streams
             # onto 4 hardware queues round-robin: a fresh pool stream per step lands on the main stream's queue every fourth
