@@ -29,6 +29,21 @@ def load(name):
     return np.load(os.path.join(GOLD, name), allow_pickle=True)
 
 
+def check_fixture_grads(model, z, tol=1e-2):
+    """device gradients against the reference's own (fixture keys g/*), directly: no oracle in between, no gate replay --
+    hence the L2 norm (a ReLU / clamp gate that falls the other way within rounding moves single elements)"""
+    worst = 0.0
+    for k, p in model.named_parameters():
+        ref_g, got_g = z['g/' + k], p.grad.cpu().numpy()
+        n = float(np.linalg.norm(ref_g))
+        if n < 1e-6 * max(float(np.linalg.norm(z['p0/' + k])), 1e-30) or n < 1e-7:
+            continue                    # identically-zero gradients (conv bias under BatchNorm): covered by compare_step
+        rel = float(np.linalg.norm(got_g - ref_g)) / n
+        worst = max(worst, rel)
+        assert rel < tol, (k, rel)
+    return worst
+
+
 def check(errs, stats, precision, grad_tol=None):
     t = dict(TOL[precision])
     if grad_tol is not None:
@@ -66,6 +81,16 @@ def test_w2l_golden(case, precision):
         if k.startswith('p1/') and 'running' in k:
             assert scale_err(sdm[k[3:]].cpu().numpy(), z[k]) < t['stat'], k
     if precision == 'fp32':
+        # the reference's own gradients (fixture keys g/*), compared with the device directly -- no oracle in between, no
+        # gate replay, hence the L2 norm: a clamp gate that falls the other way within rounding moves single elements
+        head = f'conv1ds.conv1d_{len(layers)}.'
+        wscale = {k: float(np.abs(z['g/' + k]).max()) for k, _ in model.named_parameters()}
+        for k, p in model.named_parameters():
+            ref_g, got_g = z['g/' + k], p.grad.cpu().numpy()
+            if k.endswith('conv1.bias') and not k.startswith(head):       # ~0 under BatchNorm (reference: rounding noise)
+                assert np.abs(got_g - ref_g).max() < 1e-3 * wscale[k.replace('bias', 'weight')], k
+            else:
+                assert np.linalg.norm(got_g - ref_g) < 1e-2 * np.linalg.norm(ref_g), (k, np.linalg.norm(got_g - ref_g) / np.linalg.norm(ref_g))
         texts = [str(s) for s in z['texts']]
         m = model.add_string_metrics(out, out_lens, texts, 'train')
         from wav2letter_pytorch_amd.decoder import argmax_indices
@@ -234,6 +259,7 @@ def test_jasper_dense_golden(precision):
     np.testing.assert_array_equal(out_lens.numpy(), z['out_lens'])
     assert scale_err(out.cpu().numpy(), z['log_probs']) < t['lp']
     if precision == 'fp32':
+        check_fixture_grads(model, z)
         model.eval()                 # eval: running stats AND softmax instead of log_softmax (jasper.py:470-473)
         with torch.no_grad():
             oe, _ = model(x.cuda(), il)
@@ -256,6 +282,8 @@ def test_jasper_separable_golden(precision):
     check(errs, stats, precision)
     np.testing.assert_array_equal(out_lens.numpy(), z['out_lens'])
     assert scale_err(out.cpu().numpy(), z['log_probs']) < TOL[precision]['lp']
+    if precision == 'fp32':
+        check_fixture_grads(model, z)
 
 
 def test_trainer_fit_loop_and_checkpoint(tmp_path):
