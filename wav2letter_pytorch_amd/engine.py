@@ -776,12 +776,10 @@ class StackEngine:
     def backward(self, ctx, g_out: torch.Tensor):
         """g_out: gradient wrt the (log_)softmax output [N, T', n_labels].  Returns the list of
         parameter gradients in ``self.parameters()`` order."""
-        precise = self.precise
         acts: List[Act] = ctx['acts']
         out = ctx['out']
         N = out.shape[0]
         dev = out.device
-        st = stream_ptr
         grads = {}
         # eval-mode forward normalised with the RUNNING statistics: they are constants of the step, so dy = scale * g (no
         # batch-mean terms) and the conv bias in front of BatchNorm has the ordinary gradient sum(dy)
