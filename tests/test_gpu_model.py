@@ -208,8 +208,8 @@ def test_headline_shapes_properties_bf16():
             assert float(p.grad.abs().max()) > 0, k
 
 
-@pytest.mark.parametrize('overlap', [False, True])
-def test_fused_sgd_matches_torch_sgd(overlap):
+@pytest.mark.parametrize('overlap,recycle', [(False, False), (True, False), (False, True), (True, True)])
+def test_fused_sgd_matches_torch_sgd(overlap, recycle):
     """FusedSGD (w2l_sgd_pack for conv weights) == torch.optim.SGD(nesterov, momentum, weight decay) over 3 steps,
     and the bf16 operands it emits are the ones the next forward uses (pack cache coherent)."""
     from oracle import w2l_oracle as O
@@ -221,6 +221,7 @@ def test_fused_sgd_matches_torch_sgd(overlap):
     kw = dict(lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-3)
     oa = FusedSGD.from_sgd(torch.optim.SGD(ma.parameters(), **kw))
     oa.overlap = overlap             # True: updates on the optimizer's side stream, ordered by per-layer events
+    oa.recycle_grads = recycle       # True (W2L_RECYCLE_GRADS=1): the kernel zeroes the consumed gradient, the engine reuses it as dW
     ob = torch.optim.SGD(mb.parameters(), **kw)
     x, il, tg, tl = O.synthetic_batch(2, 160, seed=11, s_lo=5, s_hi=15)
     for it in range(3):
