@@ -323,13 +323,23 @@ def main():
                                   'peak': FP8_DENSE_PEAK_TFLOPS, 'frac': round(fl8 / tt8 / 1e12 / FP8_DENSE_PEAK_TFLOPS, 4),
                                   'avg_launch_ms': round(tt8 / cnt8 * 1e3, 4), 'launches_per_step': cnt8 // 3,
                                   'alg_gflop_per_launch': round(fl8 / cnt8 / 1e9, 2)}
+        if args.dtype == 'fp8' and 'fp8_kernel' in roof:
+            # the dominant kernel of an fp8 run is the e4m3 instantiation: it becomes the line's `roofline`, priced against
+            # the fp8 peak; the few bf16 launches of the same family (first layer, classifier) move to `bf16_launches`
+            f8 = roof.pop('fp8_kernel')
+            bf = {k: roof[k] for k in ('achieved', 'frac', 'launches_per_step', 'avg_launch_ms', 'alg_gflop_per_launch')}
+            roof.update(kernel='conv_igemm_kernel<..., F8> (e4m3 operands, v_mfma_scale_f32_16x16x128_f8f6f4)', peak=f8['peak'],
+                        achieved=f8['achieved'], frac=f8['frac'], launches_per_step=f8['launches_per_step'],
+                        avg_launch_ms=f8['avg_launch_ms'], alg_gflop_per_launch=f8['alg_gflop_per_launch'])
+            roof['bf16_launches'] = bf
         if 'conv_wgrad_kernel' in agg:
             fl2, tt2, cnt2 = agg['conv_wgrad_kernel']
             roof['wgrad_kernel'] = {'achieved': round(fl2 / tt2 / 1e12, 1), 'frac': round(fl2 / tt2 / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4),
                                     'avg_launch_ms': round(tt2 / cnt2 * 1e3, 4), 'launches_per_step': cnt2 // 3}
-            conv_ms = (tt + tt2) / 3 * 1e3
-            roof['conv_ms_per_step'] = round(conv_ms, 3)
-            roof['conv_stack_frac_of_peak'] = round((fl + fl2) / (tt + tt2) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)
+            fl8, tt8, _ = agg.get('conv_igemm_fp8_kernel', (0.0, 0.0, 0))
+            roof['conv_ms_per_step'] = round((tt + tt2 + tt8) / 3 * 1e3, 3)
+            # all conv launches of the step (e4m3 ones included) against the bf16 dense peak: the bf16-equivalent rate
+            roof['conv_stack_frac_of_peak'] = round((fl + fl2 + fl8) / (tt + tt2 + tt8) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)
         if args.breakdown:
             for k, (f, t_, c) in agg.items():
                 print(f'{k}: {c // 3} launches/step, {t_ / 3 * 1e3:.3f} ms/step, {f / t_ / 1e12:.1f} TFLOP/s', file=sys.stderr)
