@@ -105,6 +105,9 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay the step as a captured hipGraph (graph.GraphedTrainStep; Wav2Letter)')
     ap.add_argument('--no-sgd-overlap', action='store_true', help='keep the fused SGD updates on the main stream')
     ap.add_argument('--force-dp', action='store_true', help='run the RCCL gradient path even with one rank (plumbing check)')
+    ap.add_argument('--early-collective', action='store_true',
+                    help='with --force-dp: run one collective before the first step, as the parameter broadcast of a multi-rank run '
+                         'does (the communicator and its streams then exist before the engine creates its side streams)')
     ap.add_argument('--serial-wgrad', action='store_true', help='keep weight gradients on the main stream (clean per-kernel durations for profiling)')
     ap.add_argument('--trace-steps', action='store_true', help='per-step host-enqueue vs GPU time (stderr), then exit')
     ap.add_argument('--host-profile', action='store_true', help='cProfile of the host side of the step (stderr), then exit')
@@ -139,6 +142,9 @@ def main():
     else:
         model = Wav2Letter(w2l_cfg(args.mid_layers, precision=args.dtype)).to(dev).train()
     broadcast_parameters(model)
+    if args.early_collective and dist.is_initialized():
+        dist.all_reduce(torch.zeros(1, device=dev))
+        torch.cuda.synchronize()
     if world > 1 or args.force_dp:
         model.grad_reducer = GradReducer(force=args.force_dp)
     if args.serial_wgrad:
@@ -369,6 +375,10 @@ def main():
             'roofline': roof, 'cpu_baseline': cpu,
             'rccl_world': dist.get_world_size() if dist.is_initialized() else 1,
             'backend': dist.get_backend() if dist.is_initialized() else None,
+            'side_streams': [{'role': r, 'candidates_tried': n, 'overlap_fraction_vs_busy_streams': f}
+                             for _, r, n, f in __import__('wav2letter_pytorch_amd.streams', fromlist=['report']).report],
+            'collectives_via': (None if getattr(model, 'grad_reducer', None) is None or not model.grad_reducer.active else
+                                'w2l_rccl_* (C ABI)' if model.grad_reducer._comm is not None else 'torch.distributed'),
             'rank_ms_per_step': [round(v, 3) for v in rank_ms],
             'exposed_comm_ms': None if exposed_comm_ms is None else round(exposed_comm_ms, 3),
             'per_gpu_value': round(value / world, 1),

@@ -341,6 +341,35 @@ int w2l_feature_normalize(const float* logmel, const int32_t* n_samples, int hop
  * the masked_fill of SpecAugment.forward / SpecCutout.forward (data/augmentations.py:56,97); x fp32 [N][C][T]. */
 int w2l_zero_rects(float* x, int N, int C, int T, const int32_t* rects, int R, void* stream);
 
+/* ---- stream concurrency probe -----------------------------------------------------------------------------------------
+ * Launches a chip-filling spin kernel (`rounds` waves of 2 blocks per CU, `spin_us` each) on stream_a, then a one-wave
+ * kernel on stream_b that records when it started.  stamps_dev: 3 x int64, zero before the call (caller synchronises
+ * before and after): [0] start of the fill, [1] end of the fill, [2] start of the stamp kernel, in 100 MHz ticks.
+ * (stamps[2] - stamps[0]) / (stamps[1] - stamps[0]) ~ 0: kernels of the two streams run side by side; ~ 1: they share a
+ * hardware queue / pipe and serialise.  The host uses it to choose the side streams of the step (weight gradients,
+ * optimizer updates, gradient collectives) -- see streams.py; no reference counterpart (stream placement is below torch). */
+int w2l_stream_probe(void* stream_a, void* stream_b, void* stamps_dev, int rounds, int spin_us);
+
+/* ---- RCCL helpers: the exchange step of the data-parallel path ------------------------------------------------------
+ * One process per GPU; every rank holds a full replica and its own utterances, the only exchange is the average of the
+ * parameter gradients (what PL's Trainer(gpus=N) / torch DDP would do for the reference, README.md:40; BatchNorm stays
+ * per rank, wav2letter.py:37).  For hosts without torch.distributed: rank 0 draws an id, the host ships its
+ * W2L_RCCL_ID_BYTES to the other ranks by whatever channel it has (file, socket, env), every rank calls w2l_rccl_init
+ * with its device current (a COLLECTIVE over the ranks), then all-reduces each gradient buffer in place on a stream
+ * of its choice (asynchronous, like every other launch here), and destroys the communicator at the end.
+ * RCCL itself is resolved at run time (the copy already mapped into the process, else librccl.so.1): without it these
+ * entry points -- and only these -- fail with a message.  Errors: 1 = bad argument / RCCL absent, 1000 + ncclResult_t.
+ *   dtype: 0 = fp32, 1 = bf16; average != 0: ncclAvg (sum / world), else ncclSum.
+ *   w2l_rccl_broadcast: raw bytes from `root` (identical replicas at step 0, DDP's construction-time broadcast). */
+#define W2L_RCCL_ID_BYTES 128
+int w2l_rccl_available(void);
+int w2l_rccl_unique_id(void* id_host);
+int w2l_rccl_init(const void* id_host, int rank, int world, void** comm_out);
+int w2l_rccl_world(void* comm, int* world_out);
+int w2l_rccl_all_reduce(void* comm, void* buf, int64_t count, int dtype, int average, void* stream);
+int w2l_rccl_broadcast(void* comm, void* buf, int64_t bytes, int root, void* stream);
+int w2l_rccl_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

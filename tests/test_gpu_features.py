@@ -230,6 +230,42 @@ def test_data_parallel_loaders_shard_the_manifest(tmp_path):
     assert [b[4][0] for b in one] == [t for pair in zip(t0, t1) for t in pair]     # rank r reads items r, r + world, ...
 
 
+def test_stream_probe_and_measured_side_streams():
+    """w2l_stream_probe / streams.concurrent_stream: a stream probed against itself reads as queued (the stamp kernel starts
+    after the fill kernel has ended), the stream handed out for a role runs beside the main stream and beside the roles
+    chosen before it, and a role keeps its stream for the life of the process"""
+    from wav2letter_pytorch_amd import streams as S
+    dev = torch.device('cuda', 0)
+    main = torch.cuda.current_stream(dev)
+    assert S.overlap_fraction(main, main, dev) > 0.9
+    a = S.concurrent_stream(dev, 'test-role-a', main=main)
+    b = S.concurrent_stream(dev, 'test-role-b')
+    assert a is S.concurrent_stream(dev, 'test-role-a') and b is S.concurrent_stream(dev, 'test-role-b')
+    assert a.cuda_stream != b.cuda_stream != main.cuda_stream
+    for x, y in ((main, a), (main, b), (a, b)):
+        assert S.overlap_fraction(x, y, dev) < S.SERIAL_FRAC
+    assert {'test-role-a', 'test-role-b'} <= set(S.chosen(dev))
+    assert any(r[1] == 'test-role-b' and r[3] < S.SERIAL_FRAC for r in S.report)
+
+
+def test_native_rccl_helpers_one_rank():
+    """include/w2l_hip.h's RCCL helpers (w2l_rccl_unique_id / init / world / all_reduce / broadcast / destroy) on a 1-rank
+    communicator, and a training step whose gradients go through them (GradReducer(native=True)) -- see the worker"""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'native_rccl_worker.py')
+    res = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert 'NATIVE_RCCL_OK' in res.stdout
+
+
 def test_train_cli_two_ranks_and_resume(tmp_path):
     """`trainer.gpus=2` (the reference's Lightning flag): the command line starts two ranks itself (gloo rehearsal on one
     GPU), each trains on its shard, only rank 0 writes checkpoints; the checkpoint carries optimizer and scheduler state

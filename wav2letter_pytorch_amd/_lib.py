@@ -105,6 +105,15 @@ _SIGNATURES = {
     'w2l_feature_normalize': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
     'w2l_zero_rects': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
     'w2l_levenshtein_host': (c_i, [c_p, c_i, c_p, c_i]),
+    'w2l_stream_probe': (c_i, [c_p, c_p, c_p, c_i, c_i]),
+    # RCCL helpers (data-parallel exchange for hosts without torch.distributed; distributed.NativeComm)
+    'w2l_rccl_available': (c_i, []),
+    'w2l_rccl_unique_id': (c_i, [c_p]),
+    'w2l_rccl_init': (c_i, [c_p, c_i, c_i, c_p]),
+    'w2l_rccl_world': (c_i, [c_p, c_p]),
+    'w2l_rccl_all_reduce': (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p]),
+    'w2l_rccl_broadcast': (c_i, [c_p, c_p, c_i64, c_i, c_p]),
+    'w2l_rccl_destroy': (c_i, [c_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -86,3 +86,48 @@ extern "C" int w2l_levenshtein_host(const int32_t* a, int na, const int32_t* b, 
     }
     return prev[nb];
 }
+
+// ---- stream concurrency probe ------------------------------------------------------------------------------------
+// Can a kernel launched on `stream_b` START while a large kernel launched earlier on `stream_a` is still being
+// dispatched?  HIP maps a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES) and those onto the command
+// processor's pipes; two streams that share one run their kernels one after the other -- a dispatch that does not fit the
+// chip at once holds its queue until its last workgroup has been placed -- and the step loses the overlap of its side
+// streams (measured: 20.0 instead of 14.0 ms/step when the RCCL communicator happened to be created before the weight-
+// gradient stream).  Which streams collide depends on the creation order of EVERY stream in the process (torch's, RCCL's),
+// so the host picks its side streams by measurement (wav2letter_pytorch_amd/streams.py).
+//   fill:  `rounds` x (2 blocks per CU, held there by 64 KiB of LDS each), every block spins `spin_us`; stamps[0] = the first
+//          block's start, stamps[1] = the last block's end (s_memrealtime ticks, 100 MHz, one counter chip-wide);
+//   stamp: one wave, writes its start time to stamps[2].
+// stamps: 3 x int64 on the device, ZERO and visible before the call (the caller synchronises); the caller synchronises
+// again and reads them: (stamps[2] - stamps[0]) / (stamps[1] - stamps[0]) is ~0 when b runs beside a, ~1 when it queues.
+namespace {
+__global__ __launch_bounds__(256) void probe_fill_kernel(long long ticks, long long* stamps) {
+    extern __shared__ char lds[];
+    if (threadIdx.x == 0) {
+        lds[0] = 0;                                               // keep the allocation
+        const long long t0 = wall_clock64();
+        if (blockIdx.x == 0) stamps[0] = t0;
+        while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);     // time advances: every block leaves
+        atomicMax((unsigned long long*)&stamps[1], (unsigned long long)wall_clock64());
+    }
+}
+__global__ void probe_stamp_kernel(long long* stamps) {
+    if (threadIdx.x == 0) stamps[2] = wall_clock64();
+}
+}  // namespace
+
+extern "C" int w2l_stream_probe(void* stream_a, void* stream_b, void* stamps_dev, int rounds, int spin_us) {
+    W2L_CHECK_ARG(stamps_dev != nullptr, "stream_probe: null pointer");
+    W2L_CHECK_ARG(rounds >= 1 && rounds <= 64 && spin_us >= 1 && spin_us <= 1000, "stream_probe: rounds 1..64, spin 1..1000 us");
+    int dev = 0, cus = 0;
+    W2L_CHECK_HIP(hipGetDevice(&dev));
+    W2L_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    W2L_CHECK_HIP(w2l_allow_big_lds((const void*)probe_fill_kernel));
+    const long long ticks = (long long)spin_us * 100;            // s_memrealtime: 100 MHz
+    hipLaunchKernelGGL(probe_fill_kernel, dim3(cus * 2 * rounds), dim3(256), 64 * 1024, (hipStream_t)stream_a, ticks,
+                       (long long*)stamps_dev);
+    W2L_CHECK_LAUNCH();
+    hipLaunchKernelGGL(probe_stamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_b, (long long*)stamps_dev);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}

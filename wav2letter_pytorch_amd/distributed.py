@@ -46,10 +46,95 @@ def init_process_group_from_env(backend: Optional[str] = None, force: bool = Fal
     return dist.get_rank(), dist.get_world_size()
 
 
+class NativeComm:
+    """An RCCL communicator held through the C ABI (include/w2l_hip.h, ``w2l_rccl_*``): the exchange step as a host
+    without torch.distributed would drive it.  ``GradReducer(native=True)`` / ``W2L_DP_NATIVE=1`` routes the gradient
+    collectives through it (no Work objects, no watchdog thread: a collective is one more asynchronous launch on the
+    reducer's stream); torch.distributed is then only the channel that carries rank 0's unique id to the other ranks."""
+
+    ID_BYTES = 128
+
+    def __init__(self, rank: int, world: int, unique_id: bytes):
+        import ctypes as C
+        from ._lib import check, lib
+        if len(unique_id) != self.ID_BYTES:
+            raise ValueError(f'an RCCL unique id has {self.ID_BYTES} bytes, got {len(unique_id)}')
+        self.rank, self.world = rank, world
+        self._lib, self._check = lib, check
+        comm = C.c_void_p()
+        check(lib.w2l_rccl_init(unique_id, rank, world, C.byref(comm)), 'w2l_rccl_init')   # collective over the ranks
+        self._comm = comm
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from ._lib import check, lib
+        buf = C.create_string_buffer(NativeComm.ID_BYTES)
+        check(lib.w2l_rccl_unique_id(buf), 'w2l_rccl_unique_id')
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, group=None):
+        """rank 0 draws the id; the existing process group (any backend) carries it to the others"""
+        rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(rank, world, box[0])
+
+    def _stream(self, stream):
+        import ctypes as C
+        s = stream if stream is not None else torch.cuda.current_stream()
+        return C.c_void_p(s.cuda_stream)
+
+    def all_reduce(self, t: torch.Tensor, average: bool = True, stream=None):
+        """in place, asynchronous on ``stream`` (default: torch's current stream); fp32 or bf16, dense"""
+        if not (t.is_cuda and t.is_contiguous()):
+            raise ValueError('NativeComm.all_reduce needs a dense device tensor')
+        code = {torch.float32: 0, torch.bfloat16: 1}.get(t.dtype)
+        if code is None:
+            raise TypeError(f'NativeComm.all_reduce: fp32 or bf16, got {t.dtype}')
+        import ctypes as C
+        self._check(self._lib.w2l_rccl_all_reduce(self._comm, C.c_void_p(t.data_ptr()), t.numel(), code, int(average),
+                                                  self._stream(stream)), 'w2l_rccl_all_reduce')
+
+    def broadcast(self, t: torch.Tensor, root: int = 0, stream=None):
+        if not (t.is_cuda and t.is_contiguous()):
+            raise ValueError('NativeComm.broadcast needs a dense device tensor')
+        import ctypes as C
+        self._check(self._lib.w2l_rccl_broadcast(self._comm, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), root,
+                                                 self._stream(stream)), 'w2l_rccl_broadcast')
+
+    def close(self):
+        comm, self._comm = self._comm, None
+        if comm is not None:
+            self._check(self._lib.w2l_rccl_destroy(comm), 'w2l_rccl_destroy')
+
+    def __del__(self):
+        import sys
+        if sys.is_finalizing():    # interpreter shutdown: the HIP runtime may be gone; the driver reclaims the communicator
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _StreamWork:
+    """Work-like handle of a collective launched through NativeComm: wait() = the current stream waits for the event
+    recorded behind the collective on the reducer's stream"""
+
+    def __init__(self, event):
+        self._event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self._event)
+
+
 class GradReducer:
     """Averages gradients across the ranks of ``group`` as they become ready."""
 
-    def __init__(self, group=None, small_bytes: int = SMALL_BYTES, force: bool = False):
+    def __init__(self, group=None, small_bytes: int = SMALL_BYTES, force: bool = False, native: Optional[bool] = None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())
@@ -70,13 +155,29 @@ class GradReducer:
         # step for the full Wav2Letter table) and are widened back in finish(); the average is then accurate to bf16's 8
         # bits, which is NOT what fp32 DDP computes -- an option for link-bound nodes, off by default
         self.bf16 = os.environ.get('W2L_DP_BF16', '0') == '1'
+        # W2L_DP_NATIVE=1 / native=True: the collectives go through the C ABI's RCCL helpers (NativeComm) instead of
+        # torch's ProcessGroupNCCL; same streams, same events, same result (ncclAvg).  Device tensors only.
+        if native is None:
+            native = os.environ.get('W2L_DP_NATIVE', '0') == '1'
+        self._comm: Optional[NativeComm] = None
+        if native and self.active and torch.cuda.is_available():
+            self._comm = NativeComm.from_process_group(group)
 
     def _side_stream(self, device):
         if self._stream is None:
-            self._stream = torch.cuda.Stream(device=device)
+            from .streams import concurrent_stream
+            # with NativeComm the collectives themselves run on this stream; with torch.distributed it only carries the
+            # event waits (ProcessGroupNCCL launches on an internal stream of its own, out of this package's reach)
+            self._stream = concurrent_stream(device, 'collectives')
         return self._stream
 
     def _all_reduce(self, t: torch.Tensor):
+        if self._comm is not None and t.is_cuda:
+            side = torch.cuda.current_stream(t.device)           # (the caller has made the reducer's stream current)
+            self._comm.all_reduce(t, average=True, stream=side)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            return _StreamWork(ev), False
         if self._avg is not None:
             return dist.all_reduce(t, op=self._avg, group=self.group, async_op=True), False
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), True

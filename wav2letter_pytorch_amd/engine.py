@@ -295,13 +295,17 @@ def _splitk_workspace(dev, n, cout, tout):
 _side_streams = {}                 # device index -> the stream weight gradients run on
 
 
-def _side_stream(dev) -> 'torch.cuda.Stream':
+def _side_stream(dev, main=None) -> 'torch.cuda.Stream':
     # a plain default-priority stream.  Measured and rejected: hipStreamCreateWithPriority (lowest or highest: 18.8 / 20.1
     # instead of 14.3 ms per step) and hipExtStreamCreateWithCUMask with 7/8, 6/8 or 5/8 of the CUs (16.6-16.7 instead of
     # 13.7 ms per step, round 2): any special queue makes the weight gradients crawl.
+    # WHICH pool stream: the first one measured to run beside the main stream (streams.py) -- a stream that shares the main
+    # stream's hardware queue / pipe serialises the step (20.0 instead of 14.0 ms), and which one does depends on every
+    # stream created in the process before it (RCCL's included).
     st = _side_streams.get(dev.index)
     if st is None:
-        st = torch.cuda.Stream(device=dev)
+        from .streams import concurrent_stream
+        st = concurrent_stream(dev, 'wgrad', main=main)
         _side_streams[dev.index] = st
     return st
 
@@ -1048,7 +1052,7 @@ class StackEngine:
             # onto 4 hardware queues round-robin: a fresh pool stream per step lands on the main stream's queue every fourth
             # step and that step loses the overlap (14.8 instead of 13.8 ms; Jasper 23.4 instead of 19.7).  Default priority:
             # streams created with hipStreamCreateWithPriority (lowest OR highest) made the whole step 30 % slower.
-            self._side = _side_stream(dy_hi.device)
+            self._side = _side_stream(dy_hi.device, main)
         side = self._side
         self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads, fork=(main, side))
         self._held.extend(t for t in (dy_hi, dy_lo, src.hi, src.lo) if t is not None)

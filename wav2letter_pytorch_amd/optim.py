@@ -104,7 +104,8 @@ class FusedSGD(torch.optim.SGD):
                 continue
             dev = fused[0][0].device
             if st['stream'] is None or st['stream'].device != dev:
-                st['stream'] = torch.cuda.Stream(device=dev)
+                from .streams import concurrent_stream        # measured to run beside the main and weight-gradient streams
+                st['stream'] = concurrent_stream(dev, 'sgd')
             side = st['stream']
             side.wait_stream(torch.cuda.current_stream(dev))     # gradients (wgrad join, all-reduce) are complete there
             with torch.cuda.stream(side):
