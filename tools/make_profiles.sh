@@ -40,5 +40,11 @@ python3 bench.py --mid-layers 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/n
 for n in 8 16; do python3 bench.py --batch $n --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | last > $OUT/bench_w2l_n$n.json; done
 # one rank, RCCL path forced: what the gradient collectives cost when nothing has to cross a link (plumbing, exposed_comm_ms)
 python3 bench.py --force-dp --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | last > $OUT/bench_force_dp_1rank.json
+# the multi-rank creation order rehearsed on one GPU (communicator before the first step), with and without the measured
+# choice of side streams, and the same through the C ABI's RCCL helpers; the probe matrix of a fresh process
+python3 bench.py --force-dp --early-collective --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | last > $OUT/bench_force_dp_comm_first.json
+W2L_STREAM_PROBE=0 python3 bench.py --force-dp --early-collective --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | last > $OUT/bench_force_dp_comm_first_noprobe.json
+W2L_DP_NATIVE=1 python3 bench.py --force-dp --early-collective --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | last > $OUT/bench_force_dp_native_rccl.json
+python3 tools/stream_map.py 12 2>/dev/null > $OUT/stream_map.txt
 python3 tools/bench_features.py 2>/dev/null | last > $OUT/bench_features.txt
 cut -c1-1200 $OUT/bench.json
