@@ -210,13 +210,17 @@ def test_conv_igemm_every_configuration(L, with_stats):
     assert split_ran >= 100, split_ran
 
 
-def test_conv_wgrad_every_plan(L):
-    """split counts x both block orders (the autotuner's search space), odd tap count so the last tap group is partial"""
-    N, Cin, Cout, Kw, s, d, T, pl, pr = 3, 192, 320, 5, 1, 2, 333, 4, 4
+@pytest.mark.parametrize('Kw,s,d', [(5, 1, 2), (6, 1, 1), (7, 1, 2), (8, 1, 1), (11, 2, 1)])
+def test_conv_wgrad_every_plan(L, Kw, s, d):
+    """split counts x both block orders x one or two tap groups per block (the autotuner's search space).  Tap counts
+    4k+1 .. 4k+4: with two tap groups (the 8-wave kernel, order bit 2) the last block then has an idle tap group and a
+    one-tap wave (Kw = 5), an idle tap group (6), a one-tap second group (7), or is full (8); stride 2 takes the other
+    instantiation"""
+    N, Cin, Cout, T, pl, pr = 3, 192, 320, 333, 4, 4
     x, w, b = conv_inputs(N, Cin, Cout, Kw, T, pl, pr, 12)
     xp = to_ntc_padded(x, pl, pr, 1)
     rows = xp.shape[1]
-    Tout = rows - (Kw - 1) * d
+    Tout = (rows - (Kw - 1) * d - 1) // s + 1
     dy = torch.randn(N, Cout, Tout, generator=torch.Generator().manual_seed(13))
     hb = (Kw - 1) * d
     ha = max(hb, (Tout + 63) // 64 * 64 - Tout)
@@ -224,10 +228,10 @@ def test_conv_wgrad_every_plan(L):
     drows = dyp.shape[1]
     dyh, xh = dyp.to(torch.bfloat16).cuda(), xp.to(torch.bfloat16).cuda()
     wr = bf(w).requires_grad_(True)
-    F.conv1d(F.pad(bf(x), (pl, pr), mode='reflect'), wr, None, dilation=d).backward(bf(dy))
+    F.conv1d(F.pad(bf(x), (pl, pr), mode='reflect'), wr, None, stride=s, dilation=d).backward(bf(dy))
     ws = torch.zeros(int(L.lib.w2l_wgrad_workspace_bytes(Cin, Cout, Kw)), dtype=torch.uint8, device='cuda')
     for splits in (1, 2, 3, 5, 18):
-        for order in (0, 1):
+        for order in (0, 1, 4, 5):
             # (a) without a workspace: fp32 atomics into a zero-filled dw
             dw = torch.zeros(Kw, Cout, Cin, device='cuda')
             L.lib.w2l_wgrad_force_plan(splits, order)

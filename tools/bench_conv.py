@@ -38,6 +38,8 @@ def main():
     ap.add_argument('--sweep', action='store_true', help='time every igemm block-shape candidate per layer')
     ap.add_argument('--deterministic', action='store_true', help='weight gradients through slabs + ticket (W2L_DETERMINISTIC=1 path)')
     ap.add_argument('--no-splitk', action='store_true', help='with --tune: measure without the split-K configurations')
+    ap.add_argument('--wgrad-plans', action='store_true',
+                    help='per layer: the best forced split count of every weight-gradient plan class (block order x tap groups, stream-K)')
     ap.add_argument('--tune', action='store_true', help='let the library measure and pick its configurations first')
     args = ap.parse_args()
     N = args.n
@@ -90,6 +92,26 @@ def main():
             L.check(L.lib.w2l_conv1d_wgrad_ws(C.c_void_p(dy.data_ptr() + h * cout * 2), per * cout, L.ptr(x),
                                               rows * cin, N * rows, L.ptr(dw), N, cin, cout, Tout, kw, s, d, 0, *wwsa, st))
 
+        if args.wgrad_plans:
+            res = []
+            for order in (0, 1, 4, 5, 2, 3):
+                best = (float('inf'), 0)
+                for sp in ((1,) if order & 2 else (1, 2, 3, 4, 5, 6, 8, 10, 12, 16)):
+                    L.lib.w2l_wgrad_force_plan(sp, order)
+                    zero = bool(L.lib.w2l_wgrad_needs_zero(N, cin, cout, Tout, kw))
+
+                    def run():
+                        if zero:
+                            dw.zero_()
+                        wgrad()
+                    try:
+                        t_ = timeit(run, args.reps)
+                    except Exception:
+                        continue
+                    best = min(best, (t_, sp))
+                res.append(f'order {order}: {flops / best[0] / 1e9:5.0f} TF (split {best[1]})')
+            L.lib.w2l_wgrad_force_plan(0, -1)
+            print('      ' + ' | '.join(res))
         if args.sweep:
             res = []
             for ci in range(21):

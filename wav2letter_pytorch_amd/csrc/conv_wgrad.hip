@@ -77,12 +77,21 @@ __device__ __forceinline__ bf16x4 tr_read(unsigned lds_byte_addr) {      // 32-b
 // instead of per-step VALU adds (the K loop is issue-bound).
 // SK: the stream-K decomposition (a block walks up to three tile segments); compiled separately so that the classic
 // one-segment kernel keeps its scalar-register budget (the segment loop's extra live scalars cost it 16 v_readlane per step).
-template <int KWB, bool S1, bool SK>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
+// TG: tap groups per block.  TG = 2: ONE 8-wave block per CU instead of two 4-wave blocks; waves 0-3 own taps kw0, kw0+1 and
+// waves 4-7 taps kw0+2, kw0+3 of the same [128 co x 128 ci] tile, all reading ONE dy tile and ONE x window (3*d rows longer).
+// Same waves per CU, same registers and LDS reads per wave, but half the LDS-DMA instructions per MFMA: timing-only builds
+// price the K loop's DMA at 27 % of the kernel (1075 -> 1366 TFLOP/s without it; without the transposing reads 1250;
+// neither 1788) -- a DMA piece costs the issuing SIMD 60-185 cycles beside MFMAs, and each wave issues 8 per 64 MFMAs.
+template <int KWB, bool S1, bool SK, int TG = 1>
+__global__ __launch_bounds__(256 * TG, TG == 1 ? 2 : 1) void conv_wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int NWV = 4 * TG;                    // waves per block
+    constexpr int KWBLK = KWB * TG;                // taps per block
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all & 3;                 // place in the 2 x 2 arrangement over the tile
+    const int tg = wave_all >> 2;                  // tap group of this wave
     const int wm = wave >> 1, wn = wave & 1;
 
     // ---- work decomposition.  The launch's work is the (tile, K step) space, tile-major; a block owns ONE contiguous range
@@ -115,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     }
     int tile_id = 0, kw0 = 0, ntaps = KWB, m0 = 0, c0 = 0, shift = 0;
     const int s = S1 ? 1 : p.stride, d = p.dil;
-    const int xrows = p.xrows_lds;                 // (BT-1)*s + (KWB-1)*d + 1 rounded up to 4
+    const int xrows = p.xrows_lds;                 // (BT-1)*s + (KWBLK-1)*d + 1 rounded up to 4
 
     char* abuf0 = smem;                            // dy tile  [BT][128 co]
     char* abuf1 = smem + BT * ROWB;
@@ -126,18 +135,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     // per-lane offsets are computed once; a step only adds wave-uniform bases (scalar) to them.
     const int srow = lane >> 4;                    // 0..3
     const int schunk = lane & 15;                  // LDS 16-byte chunk
-    unsigned a_voff[BT / 16];                      // byte offset of this lane's 16 B inside the step's dy tile
+    constexpr int AG = BT / 4 / NWV;               // four-row groups of the dy tile per wave
+    unsigned a_voff[AG];                           // byte offset of this lane's 16 B inside the step's dy tile
     const unsigned x_max_row = (unsigned)p.x_max_row;          // rows * Cin * 2 < 2^32 is checked by the launcher
     // the x window likewise (stride 1, <= 20 four-row groups): per-lane offsets inside the window, computed once per tile
-    constexpr int XG = 5;
-    const bool x_fast = S1 && (xrows >> 2) <= 4 * XG;
+    constexpr int XG = TG == 1 ? 5 : 3;
+    const bool x_fast = S1 && (xrows >> 2) <= NWV * XG;
     unsigned x_voff[XG];
     // tile id -> (tap group, co tile, ci tile) and everything that depends on them
     auto set_tile = [&](int tile) {
         tile_id = tile;
         int tm, tn;
         if (p.order) {
-            kw0 = (tile % p.kgroups) * KWB;            // first tap of this block's group
+            kw0 = (tile % p.kgroups) * KWBLK;          // first tap of this block's group
             tile /= p.kgroups;
             tm = tile % p.tiles_m;
             tn = tile / p.tiles_m;
@@ -145,15 +155,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
             tm = tile % p.tiles_m;
             tile /= p.tiles_m;
             tn = tile % p.tiles_n;
-            kw0 = (tile / p.tiles_n) * KWB;
+            kw0 = (tile / p.tiles_n) * KWBLK;
         }
-        ntaps = (p.Kw - kw0) < KWB ? (p.Kw - kw0) : KWB;
+        shift = kw0 * d;                               // the block's x window starts at its first tap
+        kw0 += tg * KWB;                               // from here on: the first tap of THIS WAVE
+        ntaps = p.Kw - kw0;                            // live taps of this wave: 0 (TG > 1 only) .. KWB
+        ntaps = ntaps < 0 ? 0 : (ntaps < KWB ? ntaps : KWB);
         m0 = tm * BM;
         c0 = tn * BNC;
-        shift = kw0 * d;
 #pragma unroll
-        for (int i = 0; i < BT / 16; ++i) {
-            const int r = (wave * (BT / 16) + i) * 4 + srow;
+        for (int i = 0; i < AG; ++i) {
+            const int r = (wave_all * AG + i) * 4 + srow;
             const int g = schunk ^ (row_key(r) << 1);
             int co = m0 + g * 8;
             co = co < p.Cout ? co : p.Cout - 8;
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         }
 #pragma unroll
         for (int i = 0; i < XG; ++i) {
-            const int r = (wave + 4 * i) * 4 + srow;
+            const int r = (wave_all + NWV * i) * 4 + srow;
             const int g = schunk ^ (row_key(r) << 1);
             int ci = c0 + g * 8;
             ci = ci < p.Cin ? ci : p.Cin - 8;
@@ -172,9 +184,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         const int t0 = ts * BT;
         // dy rows t0..t0+63 (rows >= Tout are zero by contract)
         const char* abase = reinterpret_cast<const char*>(p.dy) + ((int64_t)n * p.dy_rows_per_utt + t0) * p.Cout * 2;
-        const unsigned a_lds = __builtin_amdgcn_readfirstlane(lds_addr(adst) + wave * (BT / 16) * 1024);
+        const unsigned a_lds = __builtin_amdgcn_readfirstlane(lds_addr(adst) + wave_all * AG * 1024);
 #pragma unroll
-        for (int i = 0; i < BT / 16; ++i) glds16(abase, a_voff[i], a_lds + i * 1024);
+        for (int i = 0; i < AG; ++i) glds16(abase, a_voff[i], a_lds + i * 1024);
         const unsigned b_lds = __builtin_amdgcn_readfirstlane(lds_addr(bdst));
         const unsigned xrow0 = (unsigned)(n * p.x_rows_per_utt) + (unsigned)(t0 * s + shift);
         const int ngrp = xrows >> 2;
@@ -182,10 +194,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
             const char* xbase = reinterpret_cast<const char*>(p.x) + (uint64_t)xrow0 * (unsigned)p.Cin * 2u;
 #pragma unroll
             for (int i = 0; i < XG; ++i)
-                if (wave + 4 * i < ngrp) glds16(xbase, x_voff[i], b_lds + (wave + 4 * i) * 1024);
+                if (wave_all + NWV * i < ngrp) glds16(xbase, x_voff[i], b_lds + (wave_all + NWV * i) * 1024);
             return;
         }
-        for (int grp = wave; grp < ngrp; grp += 4) {
+        for (int grp = wave_all; grp < ngrp; grp += NWV) {
             const int r = grp * 4 + srow;
             const int g = schunk ^ (row_key(r) << 1);
             unsigned fr = xrow0 + (unsigned)r;
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         for (int tp = 0; tp < KWB; ++tp)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int rb = (lrow + h * 4) * s + tp * d;                   // row at ks = 0
+                const int rb = (lrow + h * 4) * s + (tg * KWB + tp) * d;      // row at ks = 0 (window row 0 = the block's first tap)
                 const int bcol = (wn * 64 + i * 16 + pp * 4) * 2;
                 pb[tp][h][i] = bbase0 + rb * ROWB + (bcol ^ (row_key(rb) << 5));   // ks*32*s rows further: same key (multiple of 16)
             }
@@ -319,6 +331,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         }
         step_body(nt_tag, std::true_type{}, nullptr, nullptr, 0, 0, false);
     };
+    // a wave whose tap group lies beyond Kw (TG > 1, last tap group of an odd tap count): no MFMAs, but its share of the
+    // staging and every barrier of run()
+    auto run_idle = [&]() {
+        if (step_begin >= step_end) return;
+        int n = step_begin / p.tsteps;
+        int ts = step_begin - n * p.tsteps;
+        stage(abuf0, bbuf0, n, ts);
+        advance(n, ts);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (step_begin + 1 < step_end) stage(abuf1, bbuf1, n, ts);
+        for (int step = step_begin; step + 1 < step_end; ++step) {
+            const int par = (step - step_begin) & 1;
+            advance(n, ts);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            toggle();
+            if (step + 2 < step_end) stage(par ? abuf1 : abuf0, par ? bbuf1 : bbuf0, n, ts);
+        }
+    };
     for (;;) {
     {   // ---- one segment: steps [step_begin, step_end) of tile w / S
         const int tile = w / S;
@@ -333,7 +365,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[tp][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (KWB == 1 || ntaps == KWB) run(std::integral_constant<int, KWB>{});
+    if (TG > 1 && ntaps == 0) run_idle();
+    else if (KWB == 1 || ntaps == KWB) run(std::integral_constant<int, KWB>{});
     else run(std::integral_constant<int, 1>{});
     // the read pointers were toggled once per non-last step: bring them back to buffer 0 for a following segment
     if (step_end > step_begin && ((step_end - step_begin - 1) & 1)) toggle();
@@ -344,7 +377,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     // ---- split-K through slabs: publish the partial tile, draw a ticket; only the last arriver goes on.  Agent-scope
     // release before the ticket / acquire after it: correct wherever the tile's blocks ran (they are a whole grid row apart).
     if (!SK && p.slabs != nullptr && p.splits > 1) {          // (the stream-K launch has no workspace form)
-        constexpr int TILE_F = KWB * BM * BNC;
+        constexpr int TILE_F = KWBLK * BM * BNC;
+        const int tid_t = tid & 255;                   // thread inside its tap group
         float* slab = p.slabs + ((int64_t)tile_id * p.splits + split) * TILE_F;
 #pragma unroll
         for (int tp = 0; tp < KWB; ++tp)
@@ -352,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
-                    *reinterpret_cast<f32x4*>(slab + (((tp * 4 + mi) * 4 + ni) * 256 + tid) * 4) = acc[tp][mi][ni];
+                    *reinterpret_cast<f32x4*>(slab + ((((tg * KWB + tp) * 4 + mi) * 4 + ni) * 256 + tid_t) * 4) = acc[tp][mi][ni];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                               // stores complete; the K loop's LDS is dead
         unsigned* flag = reinterpret_cast<unsigned*>(smem);
@@ -384,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni)
-                        acc[tp][mi][ni] += *reinterpret_cast<const f32x4*>(sl + (((tp * 4 + mi) * 4 + ni) * 256 + tid) * 4);
+                        acc[tp][mi][ni] += *reinterpret_cast<const f32x4*>(sl + ((((tg * KWB + tp) * 4 + mi) * 4 + ni) * 256 + tid_t) * 4);
         }
     }
 
@@ -432,8 +466,10 @@ thread_local int g_force_splits = 0;      // per calling thread, like g_force_cf
 thread_local int g_force_order = -1;
 constexpr int kDefaultOrder = 1;
 
-// `order` values: bit 0 = block order, bit 1 = stream-K decomposition (then the split count is not used)
+// `order` values: bit 0 = block order, bit 1 = stream-K decomposition (then the split count is not used), bit 2 = two tap
+// groups per block (the 8-wave kernel, TG = 2; not combined with stream-K)
 constexpr int kStreamK = 2;
+constexpr int kTapGroups2 = 4;
 constexpr int kResidentBlocks = 512;       // 256 CUs x 2 blocks (LDS and registers both allow two)
 
 int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out, int* order_out = nullptr) {
@@ -477,7 +513,7 @@ int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out, int
 // testing / profiling hook: pin the split count (0 = automatic) and the block order (-1 = automatic)
 extern "C" void w2l_wgrad_force_plan(int splits, int order) {
     g_force_splits = splits > 0 ? splits : 0;
-    g_force_order = order >= 0 ? (order & 3) : -1;       // bit 0: block order, bit 1: stream-K
+    g_force_order = order >= 0 ? (order & 7) : -1;       // bit 0: block order, bit 1: stream-K, bit 2: two tap groups per block
 }
 
 extern "C" int w2l_wgrad_needs_zero(int N, int Cin, int Cout, int Tout, int Kw) {
@@ -487,15 +523,21 @@ extern "C" int w2l_wgrad_needs_zero(int N, int Cin, int Cout, int Tout, int Kw) 
 
 constexpr size_t kWgradTicketBytes = 64 * 1024;
 
+// slabs of one launch: tiles x splits x (taps per block) x 128 x 128 floats; the tap count rounds up to the block's tap
+// group, so the 4-tap form can need a little more than the 2-tap form: the need is the larger of the two
 static size_t wgrad_ws_need(int Cin, int Cout, int Kw, int splits) {
-    const int kwb = Kw > 1 ? KWB_DEFAULT : 1;
-    const size_t tiles = (size_t)((Cout + BM - 1) / BM) * ((Cin + BNC - 1) / BNC) * ((Kw + kwb - 1) / kwb);
-    return kWgradTicketBytes + tiles * splits * kwb * BM * BNC * sizeof(float);
+    const size_t tiles_mn = (size_t)((Cout + BM - 1) / BM) * ((Cin + BNC - 1) / BNC);
+    size_t taps = 1;
+    if (Kw > 1) {
+        const size_t t2 = (size_t)((Kw + 1) / 2) * 2, t4 = (size_t)((Kw + 3) / 4) * 4;
+        taps = t2 > t4 ? t2 : t4;
+    }
+    return kWgradTicketBytes + tiles_mn * taps * splits * BM * BNC * sizeof(float);
 }
 
 static bool wgrad_ws_ok(int Cin, int Cout, int Kw, int splits, const void* ws, int64_t ws_bytes) {
     if (ws == nullptr) return false;
-    const int kwb = Kw > 1 ? KWB_DEFAULT : 1;
+    const int kwb = Kw > 1 ? KWB_DEFAULT : 1;          // the 2-tap form has the most tiles (tickets)
     const size_t tiles = (size_t)((Cout + BM - 1) / BM) * ((Cin + BNC - 1) / BNC) * ((Kw + kwb - 1) / kwb);
     return tiles * sizeof(unsigned) <= kWgradTicketBytes && wgrad_ws_need(Cin, Cout, Kw, splits) <= (size_t)ws_bytes;
 }
@@ -538,6 +580,7 @@ extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const voi
     // stream-K is the atomic path's alternative to split-K: with a workspace (deterministic slabs) the classic plan runs
     p.streamk = (order & kStreamK) && ws == nullptr ? 1 : 0;
     if (p.streamk) splits = 1;
+    const bool tg2 = (order & kTapGroups2) && !p.streamk && Kw > 2;
     p.total_steps = N * p.tsteps;
     p.steps_per_split = (p.total_steps + splits - 1) / splits;
     const bool slabs = splits > 1 && wgrad_ws_ok(Cin, Cout, Kw, splits, ws, ws_bytes);
@@ -546,12 +589,14 @@ extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const voi
     p.tickets = slabs ? (unsigned*)ws : nullptr;
     p.slabs = slabs ? (float*)((char*)ws + kWgradTicketBytes) : nullptr;
     p.atomic = splits > 1 && !slabs;
-    const int kwb = Kw > 1 ? KWB_DEFAULT : 1;
-    p.kgroups = (Kw + kwb - 1) / kwb;
-    const int xr = (BT - 1) * stride + (kwb - 1) * dil + 1;
+    const int kwb = Kw > 1 ? KWB_DEFAULT : 1;              // taps per wave
+    const int kwblk = tg2 ? 2 * kwb : kwb;                 // taps per block
+    p.kgroups = (Kw + kwblk - 1) / kwblk;
+    const int xr = (BT - 1) * stride + (kwblk - 1) * dil + 1;
     p.xrows_lds = (xr + 3) & ~3;
     const size_t lds = 2 * BT * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
-    dim3 grid(p.tiles_m * p.tiles_n * p.kgroups, splits), block(256);
+    W2L_CHECK_ARG(lds <= 160 * 1024, "conv1d_wgrad: stride %d / dilation %d need %zu bytes of LDS", stride, dil, lds);
+    dim3 grid(p.tiles_m * p.tiles_n * p.kgroups, splits), block(tg2 ? 512 : 256);
     if (p.streamk) {
         // one block per resident slot, but at least ~16 K steps each (short ranges are all prologue and epilogue)
         const int64_t W = (int64_t)grid.x * p.total_steps;
@@ -566,7 +611,15 @@ extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const voi
         W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<K, S1_, SK_>));                    \
         hipLaunchKernelGGL((conv_wgrad_kernel<K, S1_, SK_>), grid, block, lds, (hipStream_t)stream, p);   \
     } while (0)
-    if (p.streamk) {
+    if (tg2) {
+        if (stride == 1) {
+            W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<2, true, false, 2>));
+            hipLaunchKernelGGL((conv_wgrad_kernel<2, true, false, 2>), grid, block, lds, (hipStream_t)stream, p);
+        } else {
+            W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<2, false, false, 2>));
+            hipLaunchKernelGGL((conv_wgrad_kernel<2, false, false, 2>), grid, block, lds, (hipStream_t)stream, p);
+        }
+    } else if (p.streamk) {
         if (kwb == 2) { if (stride == 1) W2L_WGRAD_LAUNCH(2, true, true); else W2L_WGRAD_LAUNCH(2, false, true); }
         else { if (stride == 1) W2L_WGRAD_LAUNCH(1, true, true); else W2L_WGRAD_LAUNCH(1, false, true); }
     } else {
@@ -607,11 +660,13 @@ extern "C" int w2l_conv1d_wgrad_tune_ws(const void* dy, int64_t dy_bstride, cons
     if (reps < 1) reps = 1;
     const size_t bytes = (size_t)Kw * Cout * Cin * sizeof(float);
     const int ncand = 2 * (int)(sizeof(cands) / sizeof(cands[0]));
-    for (int ci = -2; ci < ncand; ++ci) {
-        // ci = -2, -1: the stream-K decomposition in both block orders (no workspace form: skipped in deterministic mode)
+    for (int tgbit = 0; tgbit <= (Kw > 2 ? kTapGroups2 : 0); tgbit += kTapGroups2)
+    for (int ci = tgbit ? 0 : -2; ci < ncand; ++ci) {
+        // ci = -2, -1: the stream-K decomposition in both block orders (no workspace form: skipped in deterministic mode);
+        // tgbit: the same split counts and block orders once more with two tap groups per block (the 8-wave kernel)
         const bool sk = ci < 0;
         if (sk && ws != nullptr) continue;
-        const int s = sk ? 1 : cands[ci >> 1], order = sk ? (kStreamK | (ci & 1)) : (ci & 1);
+        const int s = sk ? 1 : cands[ci >> 1], order = sk ? (kStreamK | (ci & 1)) : ((ci & 1) | tgbit);
         if (!sk && (s > total || s > 0xffff || (s > 1 && total / s < 4))) break;
         g_force_splits = s;
         g_force_order = order;
@@ -659,7 +714,7 @@ void w2l_wgrad_tune_dump(FILE* f) {
 }
 
 bool w2l_wgrad_tune_put(const int* v) {          // v[0..4] = key, v[5] = split count, v[6] = block order
-    if (v[5] < 1 || v[5] > 0xffff || v[0] < 1 || v[3] < 1 || v[6] < 0 || v[6] > 3) return false;
+    if (v[5] < 1 || v[5] > 0xffff || v[0] < 1 || v[3] < 1 || v[6] < 0 || v[6] > 7 || (v[6] & 6) == 6) return false;
     const int ts = (v[3] + BT - 1) / BT;
     if ((int64_t)v[5] > (int64_t)v[0] * ts) return false;
     std::lock_guard<std::mutex> lock(g_wtuned_mu);
