@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256 * TG, TG == 1 ? 2 : 1) void conv_wgrad_kernel(W
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave_all & 3;                 // place in the 2 x 2 arrangement over the tile
-    const int tg = wave_all >> 2;                  // tap group of this wave
+    const int wave = TG == 1 ? wave_all : wave_all & 3;   // place in the 2 x 2 arrangement over the tile
+    const int tg = TG == 1 ? 0 : wave_all >> 2;           // tap group of this wave (a constant for the 4-wave kernel)
     const int wm = wave >> 1, wn = wave & 1;
 
     // ---- work decomposition.  The launch's work is the (tile, K step) space, tile-major; a block owns ONE contiguous range
