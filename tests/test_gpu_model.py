@@ -430,11 +430,11 @@ def test_deterministic_mode_is_bit_reproducible(monkeypatch):
         assert scale_err(ga.cpu().numpy(), gc.cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize('fused,fold', [(True, False), (False, True), (True, True)])
+@pytest.mark.parametrize('fused,fold', [(True, False), (False, True), (True, True), (False, False)])
 def test_optional_bn_backward_paths(fused, fold, monkeypatch):
-    """the two opt-in forms of the BatchNorm backward -- the reduction formed in the data gradient's epilogue
-    (W2L_FUSED_BN_REDUCE=1, w2l_conv1d_dgrad_bnreduce_ws) and the finalize folded into the dy kernel (W2L_FOLD_BN_FINALIZE=1,
-    w2l_bn_act_bwd_apply_fin) -- give the same step as the default three-launch form: Wav2Letter stack with dropout, reflect
+    """the forms of the BatchNorm backward -- the reduction formed in the data gradient's epilogue (W2L_FUSED_BN_REDUCE:
+    w2l_conv1d_dgrad_bnreduce_ws; 'auto' = on below 12 288 frames, so forced on AND off here) and the finalize folded into the
+    dy kernel (W2L_FOLD_BN_FINALIZE=1, w2l_bn_act_bwd_apply_fin) -- all give the step of the three-launch form: Wav2Letter stack with dropout, reflect
     padding, stride 2, dilation 2 (fp32 mode falls back to the separate reduction: bf16 here), and the Jasper fixture with
     residual branches, masks and two gradient sources per block input"""
     from gpu_helpers import build_jasper, compare_jasper_step

@@ -315,13 +315,16 @@ _retired_ws = []                   # outgrown workspaces (grown only while shape
 # W2L_DETERMINISTIC=1: split weight-gradient reductions go through slabs summed in a fixed order instead of fp32 atomics
 # (bit-reproducible gradients, no zero fills) -- measured 6 % slower on the Wav2Letter table (943 vs 1004 TFLOP/s), so opt-in
 DETERMINISTIC_WGRAD = os.environ.get('W2L_DETERMINISTIC', '0') == '1'
-# W2L_FUSED_BN_REDUCE=1: the BatchNorm-backward reduction of a layer is formed in the epilogue of the data-gradient
-# convolution that produces the gradient wrt its output (w2l_conv1d_dgrad_bnreduce_ws) instead of by w2l_bn_act_bwd_reduce:
-# one kernel less per layer on the backward critical path.  OFF by default -- measured on one MI355X, four runs each,
-# Wav2Letter N=32: 13.75-13.85 ms per step with it, 13.71-13.94 without (Jasper 10x5: 20.0 vs 20.1): the epilogue costs the
-# data gradients what the separate pass cost (conv_igemm_kernel 1166 instead of 1246 TFLOP/s), the step is bound by the sum
-# of the kernels' work, not by the number of launches on its critical path.
-FUSED_BN_REDUCE = os.environ.get('W2L_FUSED_BN_REDUCE', '0') == '1'
+# W2L_FUSED_BN_REDUCE: the BatchNorm-backward reduction of a layer formed in the epilogue of the data-gradient convolution
+# that produces the gradient wrt its output (w2l_conv1d_dgrad_bnreduce_ws) instead of by w2l_bn_act_bwd_reduce: one kernel
+# less per layer on the backward critical path.  '1' always, '0' never, 'auto' (default) for activations of fewer than
+# FUSED_BN_REDUCE_MAX_ROWS frames (N x T').  Measured on one MI355X, same box per pair: Wav2Letter N=32 (16 000 frames)
+# 13.75-13.85 ms per step with it, 13.71-13.94 without, four runs each (later pair 13.47 / 13.56) -- the epilogue costs the data
+# gradients what the separate pass cost (conv_igemm_kernel 1166 instead of 1246 TFLOP/s) and a step of large kernels is
+# bound by the sum of their work, not by the launches on its critical path; where the kernels are short it pays: Jasper 10x5
+# N=16 (8 000 frames, 53 units) 19.39 / 19.78 with vs 19.98 / 20.17 without, Wav2Letter N=16 8.49 vs 8.57.
+FUSED_BN_REDUCE = os.environ.get('W2L_FUSED_BN_REDUCE', 'auto')
+FUSED_BN_REDUCE_MAX_ROWS = 12288
 # W2L_FOLD_BN_FINALIZE=1: the column sums of the BatchNorm-backward partials are re-formed by every block of the dy kernel
 # for its own 64 channels (w2l_bn_act_bwd_apply_fin) instead of by a finalize launch of their own.  OFF by default: measured
 # neutral to slightly slower (13.75-13.85 vs 13.71-13.80 ms; with the separate reduction pass 14.1 vs 13.7-13.9).
@@ -856,11 +859,14 @@ class StackEngine:
     def _producer(self, ctx, act_index: int):
         """the unit context whose BatchNorm-backward sums can be formed by the data gradient wrt activation ``act_index``
         (None: the spectrogram, a unit with a residual branch / without BatchNorm, the fp32 parity mode, or switched off)"""
-        if not FUSED_BN_REDUCE or self.precise or act_index < 1:
+        mode = FUSED_BN_REDUCE
+        if mode in (False, '0') or self.precise or act_index < 1:
             return None
         uc = ctx['units'][act_index - 1]
         u = uc.unit
         if u.res is not None or not u.main.has_bn or uc.y is None or uc.y.dtype != torch.bfloat16:
+            return None
+        if mode == 'auto' and uc.y.shape[0] * uc.y.shape[1] >= FUSED_BN_REDUCE_MAX_ROWS:
             return None
         return (uc, ctx['training'])
 
