@@ -177,3 +177,29 @@ def test_product_mel_filterbank_equals_oracle_restatement():
         assert a.shape == (n_mels, n_fft // 2 + 1)
         assert np.abs(a - b).max() <= 1e-9
         assert (a >= 0).all() and (a.sum(1) > 0).all()
+
+
+def test_mel_filterbank_published_known_answers():
+    """librosa is absent from this image, so the mel matrix cannot be compared with a librosa output; what IS published:
+    (1) the example in the docstring of ``librosa.filters.mel`` -- ``librosa.filters.mel(sr=22050, n_fft=2048)`` (128 bands)
+    prints ``[[0.   , 0.016, ..., 0.   , 0.   ], ...`` -- i.e. M[0, 0] = 0 and M[0, 1] = 0.016 to three decimals;
+    (2) the Slaney scale's defining constants: linear below 1 kHz at 200/3 Hz per mel (1000 Hz = 15 mel), logarithmic above
+    with log(6.4)/27 per mel, so 6400 Hz = 42 mel (Auditory Toolbox, the ``htk=False`` default);
+    (3) Slaney area normalisation: every filter integrates to 1 over frequency (sum * bin width, up to the sampling of the
+    triangle on the FFT grid).  Checked for the oracle's restatement and for the product's."""
+    from oracle import features_oracle as FO
+    from wav2letter_pytorch_amd.data import mel as PM
+    for build in (FO.mel_filterbank, PM.mel_filterbank):
+        M = np.asarray(build(22050, 2048, 128, 0.0, 22050 / 2), dtype=np.float64)
+        assert M.shape == (128, 1025)
+        assert M[0, 0] == 0.0 and abs(M[0, 1] - 0.016) < 5e-4, M[0, :3]
+        assert M[-1, -1] == 0.0 and (M[:, 0] == 0).all()
+        # (3): wide filters (>= 8 bins) integrate to 1 within the triangle's sampling error
+        df = 22050 / 2048
+        for row in M:
+            if (row > 0).sum() >= 8:
+                assert abs(row.sum() * df - 1.0) < 0.02, row.sum() * df
+    for h2m, m2h in ((FO._hz_to_mel_slaney, FO._mel_to_hz_slaney), (PM.hz_to_mel, PM.mel_to_hz)):
+        assert abs(float(h2m(1000.0)) - 15.0) < 1e-9 and abs(float(h2m(6400.0)) - 42.0) < 1e-9
+        assert abs(float(h2m(500.0)) - 7.5) < 1e-9
+        assert abs(float(m2h(42.0)) - 6400.0) < 1e-6 and abs(float(m2h(3.0)) - 200.0) < 1e-9
