@@ -363,6 +363,7 @@ int w2l_stream_probe(void* stream_a, void* stream_b, void* stamps_dev, int round
  *   w2l_rccl_broadcast: raw bytes from `root` (identical replicas at step 0, DDP's construction-time broadcast). */
 #define W2L_RCCL_ID_BYTES 128
 int w2l_rccl_available(void);
+const char* w2l_rccl_library(void);          /* path of the RCCL shared object in use ("" if none) */
 int w2l_rccl_unique_id(void* id_host);
 int w2l_rccl_init(const void* id_host, int rank, int world, void** comm_out);
 int w2l_rccl_world(void* comm, int* world_out);

@@ -19,6 +19,11 @@ def main():
     from wav2letter_pytorch_amd.distributed import GradReducer, NativeComm, init_process_group_from_env
     torch.cuda.set_device(0)
     assert lib.w2l_rccl_available() == 1
+    # one RCCL per process: the helpers must bind the copy torch itself loaded, not open a second instance
+    used = os.path.realpath(lib.w2l_rccl_library().decode())
+    mapped = {os.path.realpath(line.split()[-1]) for line in open('/proc/self/maps') if 'librccl' in line}
+    assert used in mapped and len(mapped) == 1, (used, mapped)
+    assert used.startswith(os.path.realpath(os.path.dirname(torch.__file__))), used
     # ---- the helpers on their own
     uid = NativeComm.unique_id()
     assert len(uid) == 128 and uid != NativeComm.unique_id()

@@ -108,6 +108,7 @@ _SIGNATURES = {
     'w2l_stream_probe': (c_i, [c_p, c_p, c_p, c_i, c_i]),
     # RCCL helpers (data-parallel exchange for hosts without torch.distributed; distributed.NativeComm)
     'w2l_rccl_available': (c_i, []),
+    'w2l_rccl_library': (C.c_char_p, []),
     'w2l_rccl_unique_id': (c_i, [c_p]),
     'w2l_rccl_init': (c_i, [c_p, c_i, c_i, c_p]),
     'w2l_rccl_world': (c_i, [c_p, c_p]),

@@ -73,6 +73,15 @@ static_assert(NCCL_UNIQUE_ID_BYTES == 128, "W2L_RCCL_ID_BYTES in w2l_hip.h must 
 
 extern "C" int w2l_rccl_available(void) { return rccl() != nullptr ? 1 : 0; }
 
+// path of the RCCL shared object whose entry points are in use ("" without RCCL): inside a PyTorch process this must be
+// the copy torch itself links, not a second instance
+extern "C" const char* w2l_rccl_library(void) {
+    const Rccl* r = rccl();
+    Dl_info info;
+    if (r == nullptr || dladdr((const void*)r->AllReduce, &info) == 0 || info.dli_fname == nullptr) return "";
+    return info.dli_fname;
+}
+
 extern "C" int w2l_rccl_unique_id(void* id_host) {
     W2L_CHECK_ARG(id_host != nullptr, "rccl_unique_id: null pointer");
     W2L_RCCL_OR_FAIL(r);
