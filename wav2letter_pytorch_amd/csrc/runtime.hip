@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void probe_fill_kernel(long long ticks, long l
         lds[0] = 0;                                               // keep the allocation
         const long long t0 = wall_clock64();
         if (blockIdx.x == 0) stamps[0] = t0;
-        while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);     // time advances: every block leaves
+        // time advances, so every block leaves; the iteration cap (~2k cycles per s_sleep 32: a few ms) is the exit a
+        // wave reaches even if the counter did not
+        for (int it = 0; it < 4096 && wall_clock64() - t0 < ticks; ++it) __builtin_amdgcn_s_sleep(32);
         atomicMax((unsigned long long*)&stamps[1], (unsigned long long)wall_clock64());
     }
 }
