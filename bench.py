@@ -343,9 +343,15 @@ def main():
             roof['wgrad_kernel'] = {'achieved': round(fl2 / tt2 / 1e12, 1), 'frac': round(fl2 / tt2 / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4),
                                     'avg_launch_ms': round(tt2 / cnt2 * 1e3, 4), 'launches_per_step': cnt2 // 3}
             fl8, tt8, _ = agg.get('conv_igemm_fp8_kernel', (0.0, 0.0, 0))
-            roof['conv_ms_per_step'] = round((tt + tt2 + tt8) / 3 * 1e3, 3)
+            flw8, ttw8, cntw8 = agg.get('conv_wgrad_fp8_kernel', (0.0, 0.0, 0))
+            if cntw8:
+                roof['wgrad_fp8_kernel'] = {'kernel': 'conv_wgrad_fp8_kernel (e4m3 operands, ds_read_b64_tr_b8 fragments)',
+                                            'achieved': round(flw8 / ttw8 / 1e12, 1), 'peak': FP8_DENSE_PEAK_TFLOPS,
+                                            'frac': round(flw8 / ttw8 / 1e12 / FP8_DENSE_PEAK_TFLOPS, 4),
+                                            'avg_launch_ms': round(ttw8 / cntw8 * 1e3, 4), 'launches_per_step': cntw8 // 3}
+            roof['conv_ms_per_step'] = round((tt + tt2 + tt8 + ttw8) / 3 * 1e3, 3)
             # all conv launches of the step (e4m3 ones included) against the bf16 dense peak: the bf16-equivalent rate
-            roof['conv_stack_frac_of_peak'] = round((fl + fl2 + fl8) / (tt + tt2 + tt8) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)
+            roof['conv_stack_frac_of_peak'] = round((fl + fl2 + fl8 + flw8) / (tt + tt2 + tt8 + ttw8) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)
         if args.breakdown:
             for k, (f, t_, c) in agg.items():
                 print(f'{k}: {c // 3} launches/step, {t_ / 3 * 1e3:.3f} ms/step, {f / t_ / 1e12:.1f} TFLOP/s', file=sys.stderr)

@@ -166,6 +166,19 @@ int w2l_conv1d_wgrad_tune(const void* dy, int64_t dy_bstride, const void* xp, in
                           float* dw_scratch, int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int reps,
                           void* stream);
 
+/* fp8 mode (BASELINE config 5): the weight gradient on OCP e4m3 operands, v_mfma_scale_f32_16x16x128_f8f6f4 with
+ * ds_read_b64_tr_b8 fragment reads (stride 1; conv_wgrad_fp8.hip).  dyq / xq: the one-byte copies of dy and of the padded
+ * input that the fp8 step already holds (w2l_quantize_e4m3_dyn / w2l_bn_act_fwd_q), same row layouts as the bf16 entry
+ * point (batch strides in elements = bytes); dw = descale * (*descale_dev, if given) * sum dyq * xq, fp32, tap-major.
+ * Split-K partial tiles are added atomically: w2l_wgrad_fp8_needs_zero tells whether dw must be zero-filled.
+ * Replaces aten::convolution_backward's weight half (wav2letter.py:35-36,42 / jasper.py:96-105,127) in that mode. */
+int w2l_wgrad_fp8_needs_zero(int N, int Cin, int Cout, int Tout, int Kw);
+int w2l_conv1d_wgrad_fp8(const void* dyq, int64_t dy_bstride, const void* xq, int64_t x_bstride, int64_t x_rows_total,
+                         float* dw, int N, int Cin, int Cout, int Tout, int Kw, int dil, float descale,
+                         const float* descale_dev, int accumulate, void* stream);
+int w2l_conv1d_wgrad_fp8_tune(const void* dyq, int64_t dy_bstride, const void* xq, int64_t x_bstride, int64_t x_rows_total,
+                              float* dw_scratch, int N, int Cin, int Cout, int Tout, int Kw, int dil, int reps, void* stream);
+
 /* Persistence of the measured choices of w2l_conv1d_igemm_tune / w2l_conv1d_wgrad_tune (a small text file; the
  * analogue of a vendor library's find-db).  save: 0 on success.  load: number of entries taken, -1 on error; lines
  * that do not describe a feasible launch of THIS build are skipped. */

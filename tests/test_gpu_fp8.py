@@ -110,11 +110,65 @@ def test_fp8_rejects_unsupported_shapes(L):
     assert rc != 0 and b'multiple of 128' in L.lib.w2l_last_error()
 
 
-def _fp8_step(layers, N, T, seed, dropout=False, tie=2.0, dgrad='1'):
+@pytest.mark.parametrize('N,T,cin,cout,kw,dil', [(3, 333, 128, 256, 5, 2), (2, 500, 256, 128, 1, 1), (2, 200, 192, 320, 4, 1),
+                                                  (4, 500, 384, 256, 11, 1), (1, 75, 128, 128, 29, 2), (2, 130, 128, 128, 3, 17)])
+def test_conv1d_wgrad_fp8_matches_dequantised_reference(L, N, T, cin, cout, kw, dil):
+    """w2l_conv1d_wgrad_fp8 (v_mfma_scale_f32_16x16x128_f8f6f4 fed by ds_read_b64_tr_b8) against the fp64 weight gradient of
+    the SAME e4m3 values: the kernel is exact up to fp32 accumulation order.  Shapes: odd / even tap counts (a one-tap last
+    block), dilation, channel counts that leave half-filled 128-wide tiles (192, 320), utterances shorter than one 128-frame
+    step and not a multiple of it, a dilation that makes the staged window 145 rows; every split count the tuner tries, both
+    block orders, the device-side descale factor, accumulate on top of a previous result"""
+    import ctypes as C
+    g = torch.Generator().manual_seed(kw * 131 + cin)
+    rows = T + (kw - 1) * dil
+    x = torch.randn(N, rows, cin, generator=g)
+    dy = torch.randn(N, T, cout, generator=g) * 0.3
+    sx, sdy = 16.0, 64.0
+    xq = (x * sx).clamp(-448, 448).to(torch.float8_e4m3fn)
+    dyq = (dy * sdy).clamp(-448, 448).to(torch.float8_e4m3fn)
+    # reference: d/dw of sum(conv1d(xq, w) * dyq) in fp64
+    w = torch.zeros(cout, cin, kw, dtype=torch.float64, requires_grad=True)
+    y = F.conv1d(xq.double().transpose(1, 2), w, None, dilation=dil)
+    (y * dyq.double().transpose(1, 2)).sum().backward()
+    want = (w.grad / (sx * sdy)).permute(2, 0, 1).float()                 # [kw][cout][cin]
+    # device layouts: x [N][rows][cin] bytes; dy in the shared-halo layout, zero rows up to the next multiple of 128 frames
+    hb = (kw - 1) * dil
+    h = max(hb, (T + 127) // 128 * 128 - T)
+    per = T + h
+    dyb = torch.zeros(h + N * per, cout, dtype=torch.uint8)
+    dyb[h:].view(N, per, cout)[:, :T] = dyq.view(torch.uint8)
+    xb, dyb = xq.view(torch.uint8).contiguous().cuda(), dyb.cuda()
+    inv = torch.tensor([1.0 / sdy], device='cuda')
+    scale = float(want.abs().max())
+
+    def launch(dw, acc):
+        L.check(L.lib.w2l_conv1d_wgrad_fp8(C.c_void_p(dyb.data_ptr() + h * cout), per * cout, L.ptr(xb), rows * cin, N * rows,
+                                           L.ptr(dw), N, cin, cout, T, kw, dil, 1.0 / sx, L.ptr(inv), acc, L.stream_ptr()))
+
+    # default plan (cost model), then the tuner's choice
+    for tuned in (False, True):
+        if tuned:
+            scratch = torch.empty(kw, cout, cin, device='cuda')
+            L.check(L.lib.w2l_conv1d_wgrad_fp8_tune(C.c_void_p(dyb.data_ptr() + h * cout), per * cout, L.ptr(xb), rows * cin,
+                                                    N * rows, L.ptr(scratch), N, cin, cout, T, kw, dil, 2, L.stream_ptr()))
+        zero = bool(L.lib.w2l_wgrad_fp8_needs_zero(N, cin, cout, T, kw))
+        dw = torch.zeros(kw, cout, cin, device='cuda') if zero else torch.full((kw, cout, cin), float('nan'), device='cuda')
+        launch(dw, 0)
+        torch.cuda.synchronize()
+        got = dw.cpu()
+        assert torch.isfinite(got).all()
+        assert float((got - want).abs().max()) < 2e-5 * max(scale, 1e-6) * (N * T) ** 0.5, (tuned, zero)
+        launch(dw, 1)                                                       # accumulate: twice the gradient
+        torch.cuda.synchronize()
+        assert float((dw.cpu() - 2 * want).abs().max()) < 4e-5 * max(scale, 1e-6) * (N * T) ** 0.5
+
+
+def _fp8_step(layers, N, T, seed, dropout=False, tie=2.0, dgrad='1', wgrad='0'):
     from oracle import w2l_oracle as O
     from gpu_helpers import compare_step
     from wav2letter_pytorch_amd import engine as E
-    E.FP8_DGRAD = dgrad              # '1': e4m3 data gradients whatever the size ('auto' engages them from 65 536 rows)
+    E.FP8_DGRAD = dgrad              # '1': e4m3 data gradients whatever the size ('auto' engages them from 12 288 rows)
+    E.FP8_WGRAD = wgrad              # likewise the weight gradients
     sd = O.init_wav2letter_state(layers, seed=seed)
     model = build_w2l(layers, sd, 'fp8', dropout=dropout).train()
     x, il, tg, tl = O.synthetic_batch(N, T, seed=seed + 1, s_lo=max(2, T // 12), s_hi=max(3, T // 6))
@@ -123,7 +177,29 @@ def _fp8_step(layers, N, T, seed, dropout=False, tie=2.0, dgrad='1'):
                                                        max_frac=0.3)
     finally:
         E.FP8_DGRAD = 'auto'
+        E.FP8_WGRAD = 'auto'
     return model, errs, stats
+
+
+def test_w2l_small_stack_fp8_weight_gradients_vs_oracle():
+    """the same stack with the weight gradients on e4m3 operands too (w2l_conv1d_wgrad_fp8: dy's e4m3 copy x the e4m3 copy
+    of the input the forward convolution consumed): both operands carry 3 mantissa bits, the sum over N x T frames averages
+    their rounding, so a weight gradient is good to a few percent of its scale"""
+    from wav2letter_pytorch_amd import engine as E
+    layers = [(128, 11, 2, 1, 0.0), (256, 13, 1, 1, 0.0), (384, 29, 1, 2, 0.0), (128, 1, 1, 1, 0.0)]
+    E.KERNEL_TIMER = []
+    try:
+        model, errs, stats = _fp8_step(layers, N=3, T=300, seed=3, dgrad='1', wgrad='1')
+        names = [n for n, *_ in E.KERNEL_TIMER]
+    finally:
+        E.KERNEL_TIMER = None
+    assert names.count('conv_wgrad_fp8_kernel') == 3            # layers 1-3 (layer 0 reads the 64-channel spectrogram: bf16)
+    worst = max((v, k) for k, v in errs.items() if k not in ('log_probs', 'loss'))
+    print(f'fp8 small stack, e4m3 weight gradients: worst grad {worst[0]:.3f} ({worst[1]}) loss {errs["loss"]:.4f}')
+    assert errs['log_probs'] < 8e-2 and errs['loss'] < 1e-2
+    assert worst[0] < 3.5e-1
+    for k, p in model.named_parameters():
+        assert torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0 or 'conv1.bias' in k, k
 
 
 @pytest.mark.parametrize('dgrad', ['1', '0'])

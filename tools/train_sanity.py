@@ -6,6 +6,8 @@ from wav2letter_pytorch_amd.defaults import wav2letter_model, synthetic_batch
 torch.manual_seed(0)
 cfg = wav2letter_model(20)
 cfg.optimizer.lr = float(sys.argv[1]) if len(sys.argv) > 1 else 3e-4
+if len(sys.argv) > 2:
+    cfg.precision = sys.argv[2]          # bf16 | fp32 | fp8 (W2L_FP8_DGRAD / W2L_FP8_WGRAD = 1 force the e4m3 gradients)
 model = Wav2Letter(cfg).cuda().train()
 opt = model.configure_optimizers()[0][0]
 opt.overlap = True

@@ -105,6 +105,9 @@ _SIGNATURES = {
     'w2l_feature_normalize': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
     'w2l_zero_rects': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
     'w2l_levenshtein_host': (c_i, [c_p, c_i, c_p, c_i]),
+    'w2l_wgrad_fp8_needs_zero': (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    'w2l_conv1d_wgrad_fp8': (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
+    'w2l_conv1d_wgrad_fp8_tune': (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'w2l_stream_probe': (c_i, [c_p, c_p, c_p, c_i, c_i]),
     # RCCL helpers (data-parallel exchange for hosts without torch.distributed; distributed.NativeComm)
     'w2l_rccl_available': (c_i, []),

@@ -391,6 +391,10 @@ AMAX_SLOTS = 64                    # include/w2l_hip.h W2L_AMAX_SLOTS
 # N=16 x T=1000 19.4 / 18.4 / 18.75, Jasper 10x5 N=16 x T=16000 208 / 190 / 170: a gain from ~12 000 rows per launch.
 FP8_DGRAD = os.environ.get('W2L_FP8_DGRAD', 'auto')
 FP8_DGRAD_MIN_ROWS = 12288
+# fp8 mode, weight gradients: '1' = on e4m3 operands too (w2l_conv1d_wgrad_fp8: dy's e4m3 copy x the e4m3 copy of the input
+# the forward convolution already consumed), '0' = bf16, 'auto' (default) = e4m3 from FP8_DGRAD_MIN_ROWS rows, like the data
+# gradients (dy's quantisation pass is then shared by the two)
+FP8_WGRAD = os.environ.get('W2L_FP8_WGRAD', 'auto')
 
 
 def _fp8_weights(conv: ConvSpec, pk: '_PackedW', dgrad: bool = False):
@@ -443,6 +447,7 @@ class StackEngine:
         self._main_stream = None     # the caller's stream, looked up once per backward (torch.cuda.current_stream is not free)
         self._side_used = False
         self._held: list = []        # tensors in use by side-stream kernels; released after the join in backward()
+        self._dyq: dict = {}         # fp8 mode: id(dy) -> (e4m3 copy, 1/scale) shared by a unit's weight and data gradient
         self._nbt_pending: list = []  # num_batches_tracked buffers to bump (one fused launch per forward)
         self._zero_pool = None       # (buffer, offset): the identically-zero conv-bias gradients of one backward
         # graph mode (graph.GraphedTrainStep): a uint64 step counter in device memory; dropout offsets become
@@ -820,6 +825,7 @@ class StackEngine:
             self._side_used = False
         self._main_stream = None
         self._held.clear()
+        self._dyq.clear()
         self._zero_pool = None
         _flush_tune_cache()
         if self.backward_done is not None:
@@ -915,7 +921,8 @@ class StackEngine:
                 uc.keep.append((partial, sums))
             main, res = u.main, u.res
             need_dx_main = self._needs_grad(u.src, ctx)
-            tail = roundup(Tout, 64) - Tout              # wgrad walks each utterance in 64-row steps over zero rows
+            # wgrad walks each utterance in 64-row steps (the e4m3 kernel: 128-row steps) over zero rows
+            tail = roundup(Tout, 128 if self.fp8 else 64) - Tout
             h1 = max((main.kernel - 1) * main.dilation, tail)
             dy_hi = torch.empty(h1 + N * (Tout + h1), coutp, dtype=torch.bfloat16, device=dev)
             dy_lo = torch.empty_like(dy_hi) if precise else None
@@ -930,7 +937,11 @@ class StackEngine:
             # fp8 mode: the kernel also leaves max |dy| (|dy2|) in device memory -- the scale of dy's e4m3 copy
             fp8_dgrad = self.fp8 and coutp % 128 == 0 and (FP8_DGRAD == '1' or (FP8_DGRAD == 'auto' and
                                                                                   N * Tout >= FP8_DGRAD_MIN_ROWS))
-            amax = amax_pool[oi] if fp8_dgrad else None          # [2][AMAX_SLOTS]: dy, dy2
+            fp8_wgrad = self.fp8 and coutp % 128 == 0 and (FP8_WGRAD == '1' or (FP8_WGRAD == 'auto' and
+                                                                                  N * Tout >= FP8_DGRAD_MIN_ROWS))
+            amax = amax_pool[oi] if fp8_dgrad or fp8_wgrad else None          # [2][AMAX_SLOTS]: dy, dy2
+            amax_w = amax if fp8_wgrad else None
+            amax_d = amax if fp8_dgrad else None
             if fold:
                 check(lib.w2l_bn_act_bwd_apply_fin(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(partial), nb,
                                                    ptr(sums), ptr(dy_hi), ptr(dy_lo), h1, ptr(dy2_hi), ptr(dy2_lo), h2, ptr(amax),
@@ -951,7 +962,7 @@ class StackEngine:
             # main branch
             pkm = pack_weights(main, precise)
             src = acts[u.src] if u.dw is None else uc.mid
-            self._wgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, grads)
+            self._wgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, grads, amax=None if amax_w is None else amax_w[0])
             if main.bias is not None:
                 if main.has_bn and batch_stats:      # sum(dy) == 0 identically under batch-statistics BatchNorm
                     grads[id(main.bias)] = self._zeros(main.cout, dev)      # zero on every rank: nothing to average
@@ -959,17 +970,17 @@ class StackEngine:
                     self._set(grads, main.bias, self._dy_colsum(dy_hi, dy_lo, h1, N, Tout, coutp, main.cout))
             if u.dw is not None:
                 dmid = self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src,      # (wrt the depthwise output: no BatchNorm there)
-                                   amax=None if amax is None else amax[0])
+                                   amax=None if amax_d is None else amax_d[0])
                 gsrc = self._dw_backward(u.dw, dmid, acts[u.src], uc.mid, need_dx_main, grads)
                 if gsrc is not None:
                     act_grads[u.src].append(gsrc)
             elif need_dx_main:
                 act_grads[u.src].append(self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, self._producer(ctx, u.src),
-                                                    amax=None if amax is None else amax[0]))
+                                                    amax=None if amax_d is None else amax_d[0]))
             if res is not None:
                 pkr = pack_weights(res, precise)
                 rsrc = acts[u.res_src]
-                self._wgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc, grads)
+                self._wgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc, grads, amax=None if amax_w is None else amax_w[1])
                 if res.bias is not None:
                     if res.has_bn and batch_stats:
                         grads[id(res.bias)] = self._zeros(res.cout, dev)
@@ -978,7 +989,7 @@ class StackEngine:
                 if self._needs_grad(u.res_src, ctx):
                     act_grads[u.res_src].append(self._dgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc,
                                                             self._producer(ctx, u.res_src),
-                                                            amax=None if amax is None else amax[1]))
+                                                            amax=None if amax_d is None else amax_d[1]))
     # ------------------------------------------------------------------ helpers
     def _needs_grad(self, act_index: int, ctx=None) -> bool:
         # the spectrogram needs no gradient in training (base_asr_models.py:78-85); computed only on request
@@ -1044,14 +1055,30 @@ class StackEngine:
         g.pad_l, g.pad_r, g.pad_mode, g.rows = pl, pr, mode, rows
         return g
 
-    def _wgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, grads):
+    def _dy_e4m3(self, dy_hi, amax):
+        """dy's e4m3 copy and the device-side 1/scale (from the amax bn_act_bwd_apply left), made once per dy on the
+        current stream and shared by the unit's weight and data gradients"""
+        hit = self._dyq.get(id(dy_hi))
+        if hit is None:
+            dyq = torch.empty(dy_hi.shape, dtype=torch.uint8, device=dy_hi.device)
+            inv = torch.empty(1, dtype=torch.float32, device=dy_hi.device)
+            check(lib.w2l_quantize_e4m3_dyn(ptr(dy_hi), dy_hi.numel(), ptr(amax), ptr(dyq), ptr(inv), stream_ptr()),
+                  'w2l_quantize_e4m3_dyn')
+            hit = self._dyq[id(dy_hi)] = (dyq, inv, dy_hi)          # (dy_hi kept: its id must not be reused meanwhile)
+        return hit[0], hit[1]
+
+    def _wgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, grads, amax=None):
         """dW, optionally on the side stream (ordered after everything enqueued so far on the current stream).
 
         No record_stream: dW is allocated (and zero-filled) on the main stream before the fork, and every tensor the
         side-stream kernel touches is kept alive in self._held until backward() joins the streams, so the caching
         allocator never has to poll cross-stream events (that polling stalled small-batch steps by 2-3x)."""
+        f8 = None
+        if (self.fp8 and amax is not None and src.q is not None and conv.stride == 1 and pk.coutp % 128 == 0
+                and src.CP == pk.cinp and pk.cinp % 128 == 0 and (min(conv.kernel, 2) - 1) * conv.dilation <= 32):
+            f8 = self._dy_e4m3(dy_hi, amax)          # on the current (main) stream, before the fork
         if not self.overlap_wgrad or not dy_hi.is_cuda:
-            return self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads)
+            return self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads, f8=f8)
         main = self._main_stream or torch.cuda.current_stream(dy_hi.device)
         if self._side is None or self._side.device != dy_hi.device:
             # ONE stream per device for the life of the process (engines are rebuilt per forward).  HIP multiplexes streams
@@ -1060,11 +1087,11 @@ class StackEngine:
             # streams created with hipStreamCreateWithPriority (lowest OR highest) made the whole step 30 % slower.
             self._side = _side_stream(dy_hi.device, main)
         side = self._side
-        self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads, fork=(main, side))
-        self._held.extend(t for t in (dy_hi, dy_lo, src.hi, src.lo) if t is not None)
+        self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads, fork=(main, side), f8=f8)
+        self._held.extend(t for t in (dy_hi, dy_lo, src.hi, src.lo) + ((src.q,) + f8 if f8 else ()) if t is not None)
         self._side_used = True
 
-    def _wgrad_now(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, grads, fork=None):
+    def _wgrad_now(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, grads, fork=None, f8=None):
         """dW through w2l_conv1d_wgrad, written in the parameter's own physical layout when possible.
         fork=(main, side): allocate on main, launch on side after an event recorded on main."""
         w = conv.weight
@@ -1076,9 +1103,20 @@ class StackEngine:
         x_bstride = src.rows * src.CP
         x_rows_total = N * src.rows - row_off
         dy_bstride = (Tout + halo) * pk.coutp          # shared-halo layout: utterance n starts at row halo + n*(Tout+halo)
-        ws = _wgrad_workspace(dev, pk.cinp, pk.coutp, kw) if DETERMINISTIC_WGRAD else None
+        ws = _wgrad_workspace(dev, pk.cinp, pk.coutp, kw) if DETERMINISTIC_WGRAD and f8 is None else None
         ws_bytes = ws.numel() if ws is not None else 0
-        if AUTOTUNE and not self.precise:
+        if f8 is not None:
+            self._f8 = f8                      # picked up by _wgrad_launch (same call chain)
+            if AUTOTUNE:
+                key = ('wgrad_fp8', N, pk.cinp, pk.coutp, Tout, kw, conv.dilation, dev.index)
+                if key not in _tuned_shapes:
+                    _tuned_shapes.add(key)
+                    scratch = torch.empty(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
+                    check(lib.w2l_conv1d_wgrad_fp8_tune(C.c_void_p(f8[0].data_ptr() + halo * pk.coutp), dy_bstride,
+                                                        C.c_void_p(src.q.data_ptr() + row_off * src.CP), x_bstride, x_rows_total,
+                                                        ptr(scratch), N, pk.cinp, pk.coutp, Tout, kw, conv.dilation, TUNE_REPS,
+                                                        stream_ptr()), 'w2l_conv1d_wgrad_fp8_tune')
+        elif AUTOTUNE and not self.precise:
             key = ('wgrad', N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, dev.index)
             if key not in _tuned_shapes:       # once per shape and device, during the first (warm-up) step
                 _tuned_shapes.add(key)
@@ -1091,7 +1129,10 @@ class StackEngine:
                                                    ptr(scratch), N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, TUNE_REPS,
                                                    ptr(ws), ws_bytes, stream_ptr()), 'w2l_conv1d_wgrad_tune_ws')
         # with a workspace, split reductions end in plain stores by the last block of a tile: no zero fill, no atomics
-        need_zero = bool(lib.w2l_wgrad_needs_zero_ws(N, pk.cinp, pk.coutp, Tout, kw, ws_bytes)) or self.precise
+        if f8 is not None:
+            need_zero = bool(lib.w2l_wgrad_fp8_needs_zero(N, pk.cinp, pk.coutp, Tout, kw))
+        else:
+            need_zero = bool(lib.w2l_wgrad_needs_zero_ws(N, pk.cinp, pk.coutp, Tout, kw, ws_bytes)) or self.precise
         # optim.FusedSGD leaves last step's gradient buffer zero-filled on the parameter: take it as this step's dW (only
         # when zero_grad(set_to_none=True) dropped p.grad -- otherwise autograd is about to ADD into that very tensor)
         recycled = w.__dict__.pop('_w2l_dw_zeroed', None)
@@ -1138,7 +1179,15 @@ class StackEngine:
                                           ptr(dw), N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, acc, ptr(ws),
                                           ws.numel() if ws is not None else 0, st), 'w2l_conv1d_wgrad_ws')
 
-        if not self.precise:
+        f8 = self.__dict__.pop('_f8', None)
+        if f8 is not None:
+            # fp8 mode: dy's e4m3 copy x the input's e4m3 copy (the operand of the forward convolution), fp32 result
+            with _timed('conv_wgrad_fp8_kernel', 2.0 * N * Tout * cout * cin * kw):
+                check(lib.w2l_conv1d_wgrad_fp8(C.c_void_p(f8[0].data_ptr() + halo * pk.coutp), dy_bstride,
+                                               C.c_void_p(src.q.data_ptr() + row_off * src.CP), x_bstride, x_rows_total, ptr(dw), N,
+                                               pk.cinp, pk.coutp, Tout, kw, conv.dilation, 1.0 / src.q_scale, ptr(f8[1]), 0, st),
+                      'w2l_conv1d_wgrad_fp8')
+        elif not self.precise:
             with _timed('conv_wgrad_kernel', 2.0 * N * Tout * cout * cin * kw):
                 run(dy_hi, src.hi, 0)
         else:
@@ -1209,10 +1258,7 @@ class StackEngine:
         flops = 2.0 * N * Tout * conv.cout * conv.cin * conv.kernel
         if self.fp8 and amax is not None and conv.stride == 1 and pk.coutp % 128 == 0 and per >= Tp:
             # fp8 mode: dy's e4m3 copy (scale from the device-side amax bn_act_bwd_apply left) x the e4m3 flipped-tap weights
-            dyq = torch.empty(dy_hi.shape, dtype=torch.uint8, device=dev)
-            inv = torch.empty(1, dtype=torch.float32, device=dev)
-            check(lib.w2l_quantize_e4m3_dyn(ptr(dy_hi), dy_hi.numel(), ptr(amax), ptr(dyq), ptr(inv), stream_ptr()),
-                  'w2l_quantize_e4m3_dyn')
+            dyq, inv = self._dy_e4m3(dy_hi, amax)
             wq, w_scale = _fp8_weights(conv, pk, dgrad=True)
             row_off = halo - hb
             xq = C.c_void_p(dyq.data_ptr() + row_off * pk.coutp)
