@@ -40,6 +40,7 @@ def main():
     ap.add_argument('--no-splitk', action='store_true', help='with --tune: measure without the split-K configurations')
     ap.add_argument('--wgrad-plans', action='store_true',
                     help='per layer: the best forced split count of every weight-gradient plan class (block order x tap groups, stream-K)')
+    ap.add_argument('--fp8', action='store_true', help='also time the e4m3 weight-gradient kernel (w2l_conv1d_wgrad_fp8) on each layer')
     ap.add_argument('--tune', action='store_true', help='let the library measure and pick its configurations first')
     args = ap.parse_args()
     N = args.n
@@ -138,6 +139,25 @@ def main():
             L.check(L.lib.w2l_conv1d_wgrad_tune_ws(C.c_void_p(dy.data_ptr() + h * cout * 2), per * cout, L.ptr(x), rows * cin,
                                                    N * rows, L.ptr(dw), N, cin, cout, Tout, kw, s, d, 3, *wwsa, st))
             dw.zero_()
+        tw8 = float('nan')
+        if args.fp8 and s == 1 and cin % 128 == 0 and cout % 128 == 0:
+            # e4m3 copies in the layouts of the bf16 operands; the halo of dy must cover the 128-frame steps
+            h8 = max(hb, (Tout + 127) // 128 * 128 - Tout)
+            per8 = Tout + h8
+            dyq = torch.zeros(h8 + N * per8, cout, dtype=torch.uint8, device='cuda')
+            dyq[h8:].view(N, per8, cout)[:, :Tout] = (torch.randn(N, Tout, cout, device='cuda') * 16).to(torch.float8_e4m3fn).view(torch.uint8)
+            xq = (x.float() * 16).to(torch.float8_e4m3fn).view(torch.uint8)
+
+            def wgrad8():
+                L.check(L.lib.w2l_conv1d_wgrad_fp8(C.c_void_p(dyq.data_ptr() + h8 * cout), per8 * cout, L.ptr(xq), rows * cin,
+                                                   N * rows, L.ptr(dw), N, cin, cout, Tout, kw, d, 1.0, None, 0, st))
+            if args.tune:
+                L.check(L.lib.w2l_conv1d_wgrad_fp8_tune(C.c_void_p(dyq.data_ptr() + h8 * cout), per8 * cout, L.ptr(xq), rows * cin,
+                                                        N * rows, L.ptr(dw), N, cin, cout, Tout, kw, d, 3, st))
+            tw8 = timeit(wgrad8, args.reps)
+            tot.setdefault('wgrad_fp8', [0, 0])
+            tot['wgrad_fp8'][0] += mult[(cin, cout, kw, s, d)] * tw8
+            tot['wgrad_fp8'][1] += mult[(cin, cout, kw, s, d)] * flops
         tf = timeit(fwd, args.reps)
         td = timeit(dgrad, args.reps) if s == 1 else float('nan')
         tw = timeit(wgrad, args.reps)
@@ -147,7 +167,7 @@ def main():
                 tot[k][0] += m * t
                 tot[k][1] += m * flops
         print(f'{cin:5d} {cout:5d} {kw:3d} {s} {d} | {tf:8.3f} {flops / tf / 1e9:6.0f} | {td:8.3f} {flops / td / 1e9:6.0f} | '
-              f'{tw:8.3f} {flops / tw / 1e9:6.0f}   x{m}')
+              f'{tw:8.3f} {flops / tw / 1e9:6.0f}   x{m}' + (f' | wgrad e4m3 {tw8:8.3f} {flops / tw8 / 1e9:6.0f}' if tw8 == tw8 else ''))
     for k, (t, f) in tot.items():
         if t:
             print(f'{k}: {t:.3f} ms/step-equivalent, {f / t / 1e9:.0f} TFLOP/s')

@@ -25,7 +25,7 @@ rm -rf $OUT/pmc_bench_FETCH_SIZE $OUT/pmc_bench_WRITE_SIZE $OUT/prof_default $OU
 bash tools/pmc_conv.sh 11 > $OUT/pmc_layer11.txt 2>&1
 cp gpurun_out/pmc_11/summary.json $OUT/pmc_layer11.json
 # ---- per-layer conv kernels, Wav2Letter table shapes at N = 32 (config 2) and N = 16 (the shapes of Jasper 10x5, config 4)
-python3 tools/bench_conv.py --tune > $OUT/conv_layers.txt 2>&1
+python3 tools/bench_conv.py --tune --fp8 > $OUT/conv_layers.txt 2>&1
 python3 tools/bench_conv.py --tune --n 16 > $OUT/conv_layers_n16.txt 2>&1
 # ---- the other workloads
 python3 bench.py --model jasper10x5 --batch 16 --steps 10 --warmup 4 2>/dev/null | last > $OUT/bench_jasper10x5.json
