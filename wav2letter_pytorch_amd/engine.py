@@ -1106,7 +1106,6 @@ class StackEngine:
         ws = _wgrad_workspace(dev, pk.cinp, pk.coutp, kw) if DETERMINISTIC_WGRAD and f8 is None else None
         ws_bytes = ws.numel() if ws is not None else 0
         if f8 is not None:
-            self._f8 = f8                      # picked up by _wgrad_launch (same call chain)
             if AUTOTUNE:
                 key = ('wgrad_fp8', N, pk.cinp, pk.coutp, Tout, kw, conv.dilation, dev.index)
                 if key not in _tuned_shapes:
@@ -1145,9 +1144,9 @@ class StackEngine:
                 self._held.append(recycled)
                 with torch.cuda.stream(fork[1]):
                     return self._wgrad_launch(conv, pk, recycled, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride,
-                                              x_rows_total, dy_bstride, row_off, direct, ws)
+                                              x_rows_total, dy_bstride, row_off, direct, ws, f8)
             return self._wgrad_launch(conv, pk, recycled, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total,
-                                      dy_bstride, row_off, direct, ws)
+                                      dy_bstride, row_off, direct, ws, f8)
         if fork is not None:
             # allocated on the main stream (the caching allocator then owns it there), zero-filled on the side stream:
             # the fill of a split-K gradient is as far off the critical path as the kernel that accumulates into it
@@ -1160,14 +1159,14 @@ class StackEngine:
                 if need_zero:
                     dw.zero_()
                 return self._wgrad_launch(conv, pk, dw, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total,
-                                          dy_bstride, row_off, direct, ws)
+                                          dy_bstride, row_off, direct, ws, f8)
         alloc = torch.zeros if need_zero else torch.empty
         dw = alloc(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
         return self._wgrad_launch(conv, pk, dw, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total, dy_bstride,
-                                  row_off, direct, ws)
+                                  row_off, direct, ws, f8)
 
     def _wgrad_launch(self, conv, pk, dw, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total, dy_bstride, row_off,
-                      direct, ws):
+                      direct, ws, f8=None):
         w = conv.weight
         cout, cin, kw = w.shape
         N = src.N
@@ -1179,7 +1178,6 @@ class StackEngine:
                                           ptr(dw), N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, acc, ptr(ws),
                                           ws.numel() if ws is not None else 0, st), 'w2l_conv1d_wgrad_ws')
 
-        f8 = self.__dict__.pop('_f8', None)
         if f8 is not None:
             # fp8 mode: dy's e4m3 copy x the input's e4m3 copy (the operand of the forward convolution), fp32 result
             with _timed('conv_wgrad_fp8_kernel', 2.0 * N * Tout * cout * cin * kw):
