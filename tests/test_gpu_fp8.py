@@ -167,7 +167,7 @@ def _fp8_step(layers, N, T, seed, dropout=False, tie=2.0, dgrad='1', wgrad='0'):
     from oracle import w2l_oracle as O
     from gpu_helpers import compare_step
     from wav2letter_pytorch_amd import engine as E
-    E.FP8_DGRAD = dgrad              # '1': e4m3 data gradients whatever the size ('auto' engages them from 12 288 rows)
+    E.FP8_DGRAD = dgrad              # '1': e4m3 data gradients whatever the size ('auto' engages them from 3 072 rows)
     E.FP8_WGRAD = wgrad              # likewise the weight gradients
     sd = O.init_wav2letter_state(layers, seed=seed)
     model = build_w2l(layers, sd, 'fp8', dropout=dropout).train()

@@ -389,8 +389,12 @@ AMAX_SLOTS = 64                    # include/w2l_hip.h W2L_AMAX_SLOTS
 # quantisation, and the BatchNorm-backward reduction its epilogue cannot form) -- measured on one MI355X, ms per step,
 # bf16 / fp8 forward only / fp8 forward + data gradient: Wav2Letter N=32 x T=1000 13.76 / 12.7-12.9 / 12.3-12.4, Jasper 10x5
 # N=16 x T=1000 19.4 / 18.4 / 18.75, Jasper 10x5 N=16 x T=16000 208 / 190 / 170: a gain from ~12 000 rows per launch.
+# With the weight gradients on e4m3 operands as well (one quantisation pass of dy serves both, and the main and the side
+# stream get shorter together -- either alone leaves the step on the other stream's timeline: Jasper 10x5 N=16 x T=1000 17.96
+# with neither, 17.83 data gradients only, 17.48 weight gradients only, 15.18 with both) the gain starts far lower: Wav2Letter
+# N=16 8.01 -> 6.61, N=8 (4 000 rows) 5.56 -> 5.34.
 FP8_DGRAD = os.environ.get('W2L_FP8_DGRAD', 'auto')
-FP8_DGRAD_MIN_ROWS = 12288
+FP8_DGRAD_MIN_ROWS = 3072
 # fp8 mode, weight gradients: '1' = on e4m3 operands too (w2l_conv1d_wgrad_fp8: dy's e4m3 copy x the e4m3 copy of the input
 # the forward convolution already consumed), '0' = bf16, 'auto' (default) = e4m3 from FP8_DGRAD_MIN_ROWS rows, like the data
 # gradients (dy's quantisation pass is then shared by the two)
