@@ -399,6 +399,7 @@ FP8_DGRAD_MIN_ROWS = 3072
 # the forward convolution already consumed), '0' = bf16, 'auto' (default) = e4m3 from FP8_DGRAD_MIN_ROWS rows, like the data
 # gradients (dy's quantisation pass is then shared by the two)
 FP8_WGRAD = os.environ.get('W2L_FP8_WGRAD', 'auto')
+JOIN_EVENTS = None                 # a list: backward() appends (event on the main stream, event on the weight-gradient stream) at its join
 
 
 def _fp8_weights(conv: ConvSpec, pk: '_PackedW', dgrad: bool = False):
@@ -825,6 +826,11 @@ class StackEngine:
         elif self.grad_ready is not None:
             self.grad_ready(None, small_pool, small_pool)
         if self._side_used:
+            if JOIN_EVENTS is not None:        # tools/stream_lag.py: which stream does the backward pass end on?
+                em, es = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                em.record(self._main_stream)
+                es.record(self._side)
+                JOIN_EVENTS.append((em, es))
             self._main_stream.wait_stream(self._side)
             self._side_used = False
         self._main_stream = None
