@@ -326,8 +326,7 @@ extern "C" int w2l_conv1d_wgrad_fp8(const void* dyq, int64_t dy_bstride, const v
     W2L_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && Cin > 0 && Cout > 0,
                   "conv1d_wgrad_fp8: channels (%d,%d) must be positive multiples of 64", Cin, Cout);
     W2L_CHECK_ARG(dy_bstride % Cout == 0 && x_bstride % Cin == 0, "conv1d_wgrad_fp8: batch strides must be whole rows");
-    W2L_CHECK_ARG(x_rows_total * (int64_t)Cin < (1LL << 32) && (int64_t)(BT + 8) * Cout < (1LL << 32),
-                  "conv1d_wgrad_fp8: activation buffer exceeds 32-bit byte offsets");
+    W2L_CHECK_ARG(x_rows_total * (int64_t)Cin < (1LL << 32), "conv1d_wgrad_fp8: activation buffer exceeds 32-bit byte offsets");
     const int kwb = Kw > 1 ? 2 : 1;
     W2L_CHECK_ARG((kwb - 1) * dil <= 32, "conv1d_wgrad_fp8: dilation %d exceeds the staged window", dil);
     WgradF8Params p;
@@ -412,4 +411,23 @@ extern "C" int w2l_conv1d_wgrad_fp8_tune(const void* dyq, int64_t dy_bstride, co
     std::lock_guard<std::mutex> lock(g_f8_mu);
     g_f8_tuned[key] = best;
     return 0;
+}
+
+// Tuning-cache (de)serialisation used by w2l_tune_save / w2l_tune_load (runtime.hip).
+void w2l_wgrad_fp8_tune_dump(FILE* f) {
+    std::lock_guard<std::mutex> lock(g_f8_mu);
+    for (const auto& kv : g_f8_tuned) {
+        const F8ShapeKey& k = kv.first;
+        fprintf(f, "wgradf8 %d %d %d %d %d %d %d\n", std::get<0>(k), std::get<1>(k), std::get<2>(k), std::get<3>(k),
+                std::get<4>(k), kv.second & 0xffff, kv.second >> 16);
+    }
+}
+
+bool w2l_wgrad_fp8_tune_put(const int* v) {      // v[0..4] = key, v[5] = split count, v[6] = block order
+    if (v[5] < 1 || v[5] > 0xffff || v[0] < 1 || v[3] < 1 || v[6] < 0 || v[6] > 1) return false;
+    const int ts = (v[3] + BT - 1) / BT;
+    if ((int64_t)v[5] > (int64_t)v[0] * ts) return false;
+    std::lock_guard<std::mutex> lock(g_f8_mu);
+    g_f8_tuned[F8ShapeKey(v[0], v[1], v[2], v[3], v[4])] = v[5] | (v[6] << 16);
+    return true;
 }

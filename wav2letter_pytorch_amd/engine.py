@@ -1120,6 +1120,7 @@ class StackEngine:
                 key = ('wgrad_fp8', N, pk.cinp, pk.coutp, Tout, kw, conv.dilation, dev.index)
                 if key not in _tuned_shapes:
                     _tuned_shapes.add(key)
+                    _tune_state['dirty'] = True
                     scratch = torch.empty(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
                     check(lib.w2l_conv1d_wgrad_fp8_tune(C.c_void_p(f8[0].data_ptr() + halo * pk.coutp), dy_bstride,
                                                         C.c_void_p(src.q.data_ptr() + row_off * src.CP), x_bstride, x_rows_total,
