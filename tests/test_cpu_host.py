@@ -270,14 +270,16 @@ def test_tune_cache_roundtrip(tmp_path):
                    'wgrad 1 64 64 10 3 999 0\n'               # more splits than (n,t) steps: skipped
                    'wgradf8 7 640 768 1000 21 5 1\n'          # the e4m3 weight-gradient kernel's choices
                    'wgradf8 7 640 768 1000 21 5 4\n'          # no such block order: skipped
+                   'igemmf8 7 640 768 1000 21 1 1 1 3\n'      # the e4m3 implicit-GEMM kernel's block shape
+                   'igemmf8 7 640 768 1000 21 1 1 1 77\n'     # no such shape: skipped
                    'garbage\n')
-    assert L.lib.w2l_tune_load(str(src).encode()) == 3
+    assert L.lib.w2l_tune_load(str(src).encode()) == 4
     out = tmp_path / 'out.txt'
     assert L.lib.w2l_tune_save(str(out).encode()) == 0
     lines = out.read_text().splitlines()
     assert lines[0] == 'w2l-tune v1 gfx950'
     assert 'igemm 7 640 768 1000 21 1 1 1 15' in lines and 'wgrad 7 640 768 1000 21 3 1' in lines
-    assert 'wgradf8 7 640 768 1000 21 5 1' in lines
+    assert 'wgradf8 7 640 768 1000 21 5 1' in lines and 'igemmf8 7 640 768 1000 21 1 1 1 3' in lines
     assert not any(' 99' in ln or ' 999' in ln for ln in lines)
     assert L.lib.w2l_tune_load(str(tmp_path / 'missing').encode()) == -1
     assert b'cannot open' in L.lib.w2l_last_error()

@@ -1054,6 +1054,23 @@ void w2l_igemm_tune_dump(FILE* f) {
     }
 }
 
+// the e4m3 kernel's choices: same key (stride always 1), value = index into kF8Cfgs
+void w2l_igemm_fp8_tune_dump(FILE* f) {
+    std::lock_guard<std::mutex> lock(g_tuned_mu);
+    for (const auto& kv : g_tuned_f8) {
+        const ShapeKey& k = kv.first;
+        fprintf(f, "igemmf8 %d %d %d %d %d %d %d %d %d\n", std::get<0>(k), std::get<1>(k), std::get<2>(k), std::get<3>(k),
+                std::get<4>(k), std::get<5>(k), std::get<6>(k), std::get<7>(k), kv.second);
+    }
+}
+
+bool w2l_igemm_fp8_tune_put(const int* v) {      // v[0..7] = key, v[8] = index into kF8Cfgs
+    if (v[5] != 1 || v[0] < 1 || v[3] < 1 || !f8_feasible(v[8], v[4], v[6], v[7] != 0)) return false;
+    std::lock_guard<std::mutex> lock(g_tuned_mu);
+    g_tuned_f8[ShapeKey(v[0], v[1], v[2], v[3], v[4], 1, v[6], v[7] != 0 ? 1 : 0)] = v[8];
+    return true;
+}
+
 bool w2l_igemm_tune_put(const int* v) {          // v[0..7] = key, v[8] = block-shape index
     if (!cfg_feasible(v[8], v[4], v[5], v[6], v[7] != 0)) return false;
     std::lock_guard<std::mutex> lock(g_tuned_mu);

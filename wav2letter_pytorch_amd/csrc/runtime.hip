@@ -34,6 +34,8 @@ bool w2l_igemm_tune_put(const int* v);
 void w2l_wgrad_tune_dump(FILE* f);
 bool w2l_wgrad_tune_put(const int* v);
 void w2l_wgrad_fp8_tune_dump(FILE* f);
+void w2l_igemm_fp8_tune_dump(FILE* f);
+bool w2l_igemm_fp8_tune_put(const int* v);
 bool w2l_wgrad_fp8_tune_put(const int* v);
 static const char kTuneHeader[] = "w2l-tune v1 gfx950";
 
@@ -45,6 +47,7 @@ extern "C" int w2l_tune_save(const char* path) {
     w2l_igemm_tune_dump(f);
     w2l_wgrad_tune_dump(f);
     w2l_wgrad_fp8_tune_dump(f);
+    w2l_igemm_fp8_tune_dump(f);
     const bool ok = fclose(f) == 0;
     W2L_CHECK_ARG(ok, "tune_save: write to %s failed", path);
     return 0;
@@ -69,6 +72,8 @@ extern "C" int w2l_tune_load(const char* path) {
             taken += w2l_igemm_tune_put(v) ? 1 : 0;
         else if (sscanf(line, "wgrad %d %d %d %d %d %d %d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6) == 7)
             taken += w2l_wgrad_tune_put(v) ? 1 : 0;
+        else if (sscanf(line, "igemmf8 %d %d %d %d %d %d %d %d %d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8) == 9)
+            taken += w2l_igemm_fp8_tune_put(v) ? 1 : 0;
         else if (sscanf(line, "wgradf8 %d %d %d %d %d %d %d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6) == 7)
             taken += w2l_wgrad_fp8_tune_put(v) ? 1 : 0;
     }

@@ -668,6 +668,7 @@ class StackEngine:
             key = ('fp8', N, cin, cout, Tout, conv.kernel, conv.dilation, stats is not None, src.q.device.index)
             if key not in _tuned_shapes:
                 _tuned_shapes.add(key)
+                _tune_state['dirty'] = True
                 check(lib.w2l_conv1d_igemm_fp8_tune(xq, bstride, rows_total, ptr(wq), ptr(y), y_f32, ptr(bias), ptr(stats), N,
                                                     cin, cout, Tout, conv.kernel, conv.dilation, TUNE_REPS, st),
                       'w2l_conv1d_igemm_fp8_tune')
@@ -1277,6 +1278,7 @@ class StackEngine:
                 key = ('fp8', 1, pk.coutp, pk.cinp, flat_rows, conv.kernel, conv.dilation, False, dev.index)
                 if key not in _tuned_shapes:
                     _tuned_shapes.add(key)
+                    _tune_state['dirty'] = True
                     check(lib.w2l_conv1d_igemm_fp8_tune(xq, rows_total * pk.coutp, rows_total, ptr(wq), ptr(dxp), 0, None, None, 1,
                                                         pk.coutp, pk.cinp, flat_rows, conv.kernel, conv.dilation, TUNE_REPS, st_),
                           'w2l_conv1d_igemm_fp8_tune')
