@@ -99,7 +99,7 @@ def main():
     ap.add_argument('--model', default='wav2letter', choices=['wav2letter', 'jasper10x5'],
                     help='wav2letter = the headline workload; jasper10x5 = BASELINE config 4 (secondary)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp8'],
-                    help='fp8 = forward convolutions on e4m3 operands (BASELINE config 5); gradients stay bf16')
+                    help='fp8 = forward, data-gradient and weight-gradient convolutions on e4m3 operands (BASELINE config 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the step as a captured hipGraph (graph.GraphedTrainStep; Wav2Letter)')
