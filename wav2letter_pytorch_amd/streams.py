@@ -93,6 +93,12 @@ def concurrent_stream(dev: torch.device, role: str, main: Optional['torch.cuda.S
             break
     reg[role] = best[1]
     report.append((idx, role, tried, round(best[0], 3)))
+    if best[0] >= SERIAL_FRAC:
+        import warnings
+        warnings.warn(f'wav2letter_pytorch_amd.streams: none of {tried} candidate streams for role {role!r} on cuda:{idx} runs '
+                      f'beside the {len(against)} busy stream(s) (best overlap fraction {best[0]:.2f}): kernels of that role '
+                      f'will queue behind another stream and the step loses that overlap (more busy streams than the command '
+                      f'processor runs side by side? see tools/stream_map.py)')
     return best[1]
 
 
