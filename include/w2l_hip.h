@@ -129,6 +129,9 @@ int w2l_conv1d_igemm_fp8_tune(const void* xq, int64_t x_bstride, int64_t x_rows_
  * idx = block shape (0..20) + 21 * K-loop structure (0: barrier at the top of a step, 1: barrier mid-step);
  * a call whose problem the forced configuration cannot run returns an error. */
 void w2l_conv_force_tile_config(int idx);
+/* likewise for the e4m3 kernel: idx = index into its list of 13 block shapes; an infeasible one (statistics need 128-row
+ * tiles, LDS) makes w2l_conv1d_igemm_fp8 fail with a message */
+void w2l_conv_force_fp8_config(int idx);
 
 /* Conv1d weight gradient (autograd of the same call sites):
  * dw[kw][co][ci] (+)= sum_{n,t} dy[n][t][co] * xp[n][t*stride + kw*dil][ci]

@@ -76,6 +76,27 @@ def test_conv1d_igemm_fp8_matches_dequantised_fp32_conv(L, N, T, cin, cout, kw, 
     # and the quantisation error itself against the unquantised operands: a few percent of the output scale
     full = F.conv1d(x.float().transpose(1, 2), w.permute(1, 2, 0), bias, dilation=dil).transpose(1, 2)
     assert scale_err(got.float().numpy(), full.numpy()) < 6e-2
+    # every block shape the tuner can pick; infeasible ones (statistics need 128-row tiles, LDS) must refuse
+    ran = 0
+    try:
+        for k in range(13):
+            L.lib.w2l_conv_force_fp8_config(k)
+            y.fill_(float('nan'))
+            if st is not None:
+                st.zero_()
+            rc = L.lib.w2l_conv1d_igemm_fp8(L.ptr(xq), rows * cin, N * rows, L.ptr(wq), L.ptr(y), 1, 1.0 / sw, L.ptr(inv_d),
+                                            L.ptr(b_d), L.ptr(st), N, cin, cout, T, kw, dil, L.stream_ptr())
+            if rc != 0:
+                continue
+            ran += 1
+            torch.cuda.synchronize()
+            assert scale_err(y.cpu().double().numpy(), ref.numpy()) < 2e-5, k
+            if stats:
+                s = st.cpu().double().sum(0)
+                assert scale_err(s[0].numpy(), ref.sum((0, 1)).numpy()) < 1e-4, k
+    finally:
+        L.lib.w2l_conv_force_fp8_config(-1)
+    assert ran >= 5, ran
 
 
 def test_dynamic_quantisation_from_device_amax(L):

@@ -915,6 +915,8 @@ extern "C" int w2l_conv1d_igemm_tune(const void* xp, int64_t x_bstride, int64_t 
 // measured choices of the e4m3 kernel: shape -> index into kF8Cfgs
 static std::map<ShapeKey, int> g_tuned_f8;
 static thread_local int g_force_f8 = -1;
+// testing / profiling hook (per calling thread): pin the e4m3 kernel's block shape (index into kF8Cfgs), -1 = automatic
+extern "C" void w2l_conv_force_fp8_config(int idx) { g_force_f8 = idx; }
 
 static bool f8_feasible(int k, int Kw, int dil, bool need_bn128) {
     if (k < 0 || k >= kNumF8Cfgs) return false;
