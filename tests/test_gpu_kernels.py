@@ -400,7 +400,7 @@ def test_ctc_golden_cases(L):
     assert np.all(g[1, 33:] == 0) and np.all(g[3] == 0) and np.all(g[5] == 0)
 
 
-@pytest.mark.parametrize('N,T,S', [(4, 250, 100), (2, 500, 160), (3, 64, 5)])
+@pytest.mark.parametrize('N,T,S', [(4, 250, 100), (2, 500, 160), (3, 64, 5), (2, 600, 250), (3, 700, 300), (2, 40, 1)])
 def test_ctc_vs_oracle_random(L, N, T, S):
     from wav2letter_pytorch_amd.ctc_loss import CTCLoss
     g = torch.Generator().manual_seed(N * 1000 + T)
