@@ -82,6 +82,26 @@ def main():
         ref = grads[0][k]
         for other in grads[1:]:
             assert np.linalg.norm(other[k] - ref) <= 1e-5 * max(np.linalg.norm(ref), 1e-12), k
+    # ---- bf16 transport (W2L_DP_BF16=1) through the native communicator: the averaged gradient is the bf16 rounding
+    model = build_w2l(layers, sd, 'fp32').train()
+    red = GradReducer(force=True, native=True, small_bytes=1 << 12)
+    red.bf16 = True
+    model.grad_reducer = red
+    out, ol = model(x.cuda(), il)
+    model.criterion(out.transpose(0, 1), tg, ol, tl).backward()
+    torch.cuda.synchronize()
+    rounded = 0
+    for k, v in model.named_parameters():
+        ref = torch.from_numpy(grads[0][k])
+        got = v.grad.detach().cpu()
+        # conv weights travel alone, the per-channel gradients as one pooled message: either way a message of >= small_bytes
+        # went as bf16, so a gradient is the fp32 value or its bf16 rounding (2^-9 relative)
+        assert float((got - ref).norm()) <= 4e-3 * max(float(ref.norm()), 1e-12), k
+        if ref.numel() * 4 >= (1 << 12):
+            want = ref.to(torch.bfloat16).float()
+            assert float((got - want).norm()) <= 1e-3 * max(float(want.norm()), 1e-12), k
+            rounded += int(not torch.equal(got, ref))
+    assert rounded >= 3
     dist.destroy_process_group()
     print('NATIVE_RCCL_OK')
 

@@ -252,6 +252,22 @@ def test_stream_probe_and_measured_side_streams(monkeypatch):
     assert any(r[1] == 'test-role-b' and r[3] < S.SERIAL_FRAC for r in S.report)
 
 
+def test_stream_probe_warns_when_nothing_runs_beside(monkeypatch):
+    """if every candidate reads as queued behind a busy stream (more busy streams than the command processor runs side by
+    side), the role still gets a stream -- the best seen -- and the user is told that the overlap is lost"""
+    from wav2letter_pytorch_amd import streams as S
+    dev = torch.device('cuda', 0)
+    monkeypatch.setitem(S._chosen, 0, {})
+    monkeypatch.setitem(S._main, 0, torch.cuda.current_stream(dev))
+    monkeypatch.setattr(S, 'TRIES', 3)
+    seen = iter([0.9, 0.6, 0.8])
+    monkeypatch.setattr(S, 'serialise', lambda a, b, d, reps=2: next(seen))
+    with pytest.warns(UserWarning, match='none of 3 candidate streams'):
+        st = S.concurrent_stream(dev, 'test-role-crowded')
+    assert isinstance(st, torch.cuda.Stream)
+    assert S.report[-1][1:] == ('test-role-crowded', 3, 0.6)
+
+
 def test_native_rccl_helpers_one_rank():
     """include/w2l_hip.h's RCCL helpers (w2l_rccl_unique_id / init / world / all_reduce / broadcast / destroy) on a 1-rank
     communicator, and a training step whose gradients go through them (GradReducer(native=True)) -- see the worker"""
