@@ -78,6 +78,43 @@ def csrc_fingerprint():
     return h.hexdigest()[:16]
 
 
+def share_tune_plans(E, dist, rank, world, fwd_bwd):
+    """One set of kernel plans for all ranks.  Rank 0 runs ONE forward + backward alone (no collectives, no optimizer step:
+    the engine measures and picks block shapes / split-K / block orders for every layer shape), writes the choices to a
+    file, the other ranks wait at a barrier and load it.  Without this each of the N ranks would tune for itself (N x the
+    measuring launches) and could pick different plans, i.e. different ms/step for no reason the line explains.  Returns
+    (path, entries loaded or None, sha16 of this rank's plan table)."""
+    import hashlib
+    import tempfile
+    path = os.environ.get('W2L_TUNE_CACHE') or os.path.join(
+        tempfile.gettempdir(), 'w2l_tune_%s_%d.txt' % (os.environ.get('MASTER_PORT', '0'), os.getuid()))
+    loaded = None
+    if world > 1:
+        dist.barrier()            # the process group's communicator (and its streams) exists on EVERY rank before any rank's
+                                  # engine probes its side streams: all ranks create their streams in the same order
+    if rank == 0:
+        fwd_bwd()
+        torch.cuda.synchronize()
+        E.save_tune_cache(path)
+    if world > 1:
+        dist.barrier()
+        if rank != 0:
+            loaded = E.load_tune_cache(path)
+    own = '%s.rank%d' % (path, rank)
+    E.save_tune_cache(own)
+    sha = hashlib.sha256(open(own, 'rb').read()).hexdigest()[:16]
+    os.remove(own)
+    return path, loaded, sha
+
+
+def gather_objects(dist, world, obj):
+    if world <= 1:
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def _launcher():
     """wav2letter_pytorch_amd/launch.py loaded by path: importing the package would load libw2l_hip.so (and the HIP
     runtime) into the parent, which only spawns the ranks"""
@@ -108,6 +145,9 @@ def main():
     ap.add_argument('--early-collective', action='store_true',
                     help='with --force-dp: run one collective before the first step, as the parameter broadcast of a multi-rank run '
                          'does (the communicator and its streams then exist before the engine creates its side streams)')
+    ap.add_argument('--no-collective-ab', action='store_true',
+                    help='data-parallel runs: skip the in-run A/B of the two collective paths (torch.distributed vs the C ABI\'s '
+                         'RCCL helpers) and keep torch.distributed (or what W2L_DP_NATIVE says)')
     ap.add_argument('--serial-wgrad', action='store_true', help='keep weight gradients on the main stream (clean per-kernel durations for profiling)')
     ap.add_argument('--trace-steps', action='store_true', help='per-step host-enqueue vs GPU time (stderr), then exit')
     ap.add_argument('--host-profile', action='store_true', help='cProfile of the host side of the step (stderr), then exit')
@@ -116,15 +156,17 @@ def main():
 
     L = _launcher()
     if args.gpus > 1 and not L.under_launcher():
-        # parent of a self-launched run: no HIP call has been made here (device_count() does not initialise the runtime)
-        if os.environ.get('W2L_DIST_BACKEND') != 'gloo' and torch.cuda.device_count() < args.gpus:
-            raise SystemExit(f'bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible')
+        # parent of a self-launched run: no HIP / HSA call may happen here (the children are started from this process), so
+        # the devices are counted from sysfs / the *_VISIBLE_DEVICES variables, never through torch.cuda
+        seen = L.visible_gpu_count()
+        if os.environ.get('W2L_DIST_BACKEND') != 'gloo' and seen is not None and seen < args.gpus:
+            raise SystemExit(f'bench.py --gpus {args.gpus}: only {seen} GPU(s) visible')
         sys.exit(L.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     if L.under_launcher() and int(os.environ['WORLD_SIZE']) != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} inside a {os.environ['WORLD_SIZE']}-rank launch: the two must agree")
 
     from wav2letter_pytorch_amd import Jasper, Wav2Letter, engine as E
-    from wav2letter_pytorch_amd.distributed import GradReducer, broadcast_parameters, init_process_group_from_env
+    from wav2letter_pytorch_amd.distributed import GradReducer, NativeComm, broadcast_parameters, init_process_group_from_env
     import torch.distributed as dist
     from wav2letter_pytorch_amd.defaults import synthetic_batch      # the GPU leg never touches oracle/
 
@@ -141,11 +183,29 @@ def main():
         model.check_nan = False              # the reference's per-step NaN assert is a host sync
     else:
         model = Wav2Letter(w2l_cfg(args.mid_layers, precision=args.dtype)).to(dev).train()
-    broadcast_parameters(model)
+    N, T = args.batch, args.frames
+    x, il, tg, tl = synthetic_batch(N, T, seed=1234 + rank)
+    x = x.to(dev)
+    tg_d, tl_d = tg.to(dev), tl.to(dev)
+    ol = model.compute_output_lengths(il).to(dev)
+    lens_arg = il if args.model == 'jasper10x5' else None        # host lengths, as _collator hands them over
+
+    def fwd_bwd():
+        model.zero_grad(set_to_none=True)
+        out, _ = model(x, lens_arg)
+        loss = model.criterion(out.transpose(0, 1), tg_d, ol, tl_d)
+        loss.backward()
+        return loss
+
+    dp = world > 1 or args.force_dp
+    tune_path = tune_loaded = tune_sha = None
+    if dp and E.AUTOTUNE:
+        tune_path, tune_loaded, tune_sha = share_tune_plans(E, dist, rank, world, fwd_bwd)
+    broadcast_parameters(model)          # (also undoes what rank 0's tuning pass did to its BatchNorm running statistics)
     if args.early_collective and dist.is_initialized():
         dist.all_reduce(torch.zeros(1, device=dev))
         torch.cuda.synchronize()
-    if world > 1 or args.force_dp:
+    if dp:
         model.grad_reducer = GradReducer(force=args.force_dp)
     if args.serial_wgrad:
         model._overlap_wgrad = False
@@ -153,16 +213,10 @@ def main():
     opt = opt[0]
     if hasattr(opt, 'overlap') and not args.no_sgd_overlap:
         opt.overlap = True            # conv-weight updates run on a side stream under the next step's forward (optim.FusedSGD)
-    N, T = args.batch, args.frames
-    x, il, tg, tl = synthetic_batch(N, T, seed=1234 + rank)
-    x = x.to(dev)
-    tg_d, tl_d = tg.to(dev), tl.to(dev)
-    ol = model.compute_output_lengths(il).to(dev)
-
 
     def step():
         opt.zero_grad(set_to_none=True)
-        out, _ = model(x, il if args.model == 'jasper10x5' else None)       # host lengths, as _collator hands them over
+        out, _ = model(x, lens_arg)
         loss = model.criterion(out.transpose(0, 1), tg_d, ol, tl_d)
         loss.backward()
         if not args.no_optimizer:
@@ -181,14 +235,70 @@ def main():
         eager_step = step
 
     def fence():
+        if hasattr(opt, 'join'):
+            opt.join()                    # updates still streaming on the optimizer's side stream belong to the step just run
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_ms(k):
+        """k steps between two fences, ms per step, the slowest rank's"""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        return dt / k * 1e3
+
     for _ in range(args.warmup):
         step()
     fence()
+
+    # ---- which collective path?  Measured here, in this run, on this node: nobody is there to flip a switch on the first
+    # 8-GPU run.  k steps with the gradient collectives through torch.distributed (ProcessGroupNCCL: its own internal stream,
+    # the one stream of the step streams.py cannot probe), k steps through the C ABI's RCCL helpers (NativeComm: the collective
+    # is a launch on the reducer's probed stream); the faster one (slowest rank's time) serves the timed region.  The two
+    # communicators never have work in flight together: every switch sits between two fences (device sync + barrier).
+    collective_paths = None
+    reducer0 = getattr(model, 'grad_reducer', None)
+    forced_native = os.environ.get('W2L_DP_NATIVE')
+    if (reducer0 is not None and reducer0.active and not args.no_collective_ab and not args.graph and forced_native is None):
+        k_ab = 5
+        collective_paths = {'torch.distributed': round(timed_ms(k_ab), 3), 'w2l_rccl_* (C ABI)': None}
+        comm, why = None, None
+        try:
+            comm = NativeComm.from_process_group()
+        except Exception as e:            # noqa: BLE001 -- reported in the line; the run goes on with torch.distributed
+            why = repr(e)
+        ok = torch.tensor([1.0 if comm is not None else 0.0], device=dev)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)            # all ranks or none
+        if float(ok) == 1.0:
+            fence()
+            reducer0.set_native(comm)
+            step()
+            step()                        # the communicator's first collectives (channel set-up) stay out of the timing
+            collective_paths['w2l_rccl_* (C ABI)'] = round(timed_ms(k_ab), 3)
+            if comm.rehearsal:
+                collective_paths['note'] = ('one-GPU rehearsal (W2L_DIST_BACKEND=gloo): the native path ran on one-rank '
+                                            'communicators, averaging nothing')
+            if collective_paths['w2l_rccl_* (C ABI)'] >= collective_paths['torch.distributed']:
+                reducer0.set_native(None)
+            collective_paths['kept'] = 'w2l_rccl_* (C ABI)' if reducer0._comm is not None else 'torch.distributed'
+            fence()
+            broadcast_parameters(model)   # replicas that stepped through a rehearsal communicator have drifted apart
+        else:
+            collective_paths['kept'] = 'torch.distributed'
+            collective_paths['native_unavailable'] = why or 'another rank could not create its communicator'
+            if comm is not None:
+                comm.close()
+        fence()
     if args.trace_steps:
         # per-step host enqueue time vs GPU time (event to event): tells a host-bound box from a slow-clock box
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -240,8 +350,8 @@ def main():
     ms = elapsed / args.steps * 1e3
     value = world * N * T / (elapsed / args.steps)
 
-    # ---- exposed communication: the same step with the gradient reducer detached (no collectives), same run ----
-    exposed_comm_ms = None
+    # ---- exposed communication: the same step with the gradient reducer detached (no collectives), same run, per rank ----
+    exposed_comm_ms = exposed_by_rank = None
     reducer = getattr(model, 'grad_reducer', None)
     if reducer is not None and not args.graph:
         model.grad_reducer = None
@@ -253,13 +363,12 @@ def main():
             step()
         fence()
         solo = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([solo], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            solo = float(t)
-        exposed_comm_ms = ms - solo / k2 * 1e3
+        own = rank_ms[rank] - solo / k2 * 1e3                 # this rank's step with the collectives minus its step without
+        exposed_by_rank = [round(v, 3) for v in gather_objects(dist, world, own)]
+        exposed_comm_ms = max(exposed_by_rank)
         model.grad_reducer = reducer
         broadcast_parameters(model)                          # the replicas drifted apart while stepping alone
+    tune_shas = gather_objects(dist, world, tune_sha) if tune_sha is not None else None
 
     # ---- instrumented pass: HIP events around every conv kernel launch (same stream) ----
     roof = None
@@ -307,20 +416,22 @@ def main():
             if rest[2] > 0:
                 roof['other_launches'] = {'achieved': round(rest[0] / rest[1] / 1e12, 1), 'launches_per_step': rest[2] // 3,
                                           'avg_launch_ms': round(rest[1] / rest[2] * 1e3, 4)}
-        pmc_file = os.path.join(ROOT, 'profiles', 'r02_pmc_bench.json')
-        if (args.model == 'wav2letter' and args.mid_layers == 20 and args.batch == 32 and args.dtype == 'bf16'
-                and os.path.exists(pmc_file)):
+        if args.model == 'wav2letter' and args.mid_layers == 20 and args.batch == 32 and args.dtype == 'bf16':
             # HBM-side bytes per launch from the committed PMC passes of this same command (tools/make_profiles.sh):
-            # FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 FETCH correction applied (tools/prof_summary.py).  The file
-            # carries the fingerprint of the kernel sources it was measured on: a different build reports traffic = null.
-            pmc = json.load(open(pmc_file))
-            k = pmc['kernels'].get(name, {})
-            if pmc.get('csrc_sha') == csrc_fingerprint() and 'traffic_bytes_per_launch' in k:
-                roof['traffic'] = round(k['traffic_bytes_per_launch'])
-                roof['traffic_source'] = ('profiles/r02_pmc_bench.json (rocprofv3 --pmc, mean over the step\'s launches; '
-                                          'kernel sources ' + pmc['csrc_sha'] + ')')
-            else:
-                roof['traffic_source'] = 'none: profiles/r02_pmc_bench.json was measured on other kernel sources'
+            # FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 FETCH correction applied (tools/prof_summary.py).  Each file
+            # carries the fingerprint of the kernel sources it was measured on: only a file measured on THIS build is quoted
+            # (newest round first); otherwise traffic = null.
+            import glob
+            sha = csrc_fingerprint()
+            roof['traffic_source'] = 'none: no profiles/r*_pmc_bench.json was measured on these kernel sources (' + sha + ')'
+            for pmc_file in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_bench.json')), reverse=True):
+                pmc = json.load(open(pmc_file))
+                k = pmc.get('kernels', {}).get(name, {})
+                if pmc.get('csrc_sha') == sha and 'traffic_bytes_per_launch' in k:
+                    roof['traffic'] = round(k['traffic_bytes_per_launch'])
+                    roof['traffic_source'] = ('profiles/' + os.path.basename(pmc_file) + ' (rocprofv3 --pmc, mean over the '
+                                              'step\'s launches; kernel sources ' + sha + ')')
+                    break
         if 'conv_igemm_fp8_kernel' in agg:
             # fp8 mode: the forward convolutions of the units ran on e4m3 operands; they are priced against the fp8 peak, the
             # bf16 launches left in `roof` (first layer, classifier, data gradients) against the bf16 peak
@@ -350,8 +461,12 @@ def main():
                                             'frac': round(flw8 / ttw8 / 1e12 / FP8_DENSE_PEAK_TFLOPS, 4),
                                             'avg_launch_ms': round(ttw8 / cntw8 * 1e3, 4), 'launches_per_step': cntw8 // 3}
             roof['conv_ms_per_step'] = round((tt + tt2 + tt8 + ttw8) / 3 * 1e3, 3)
-            # all conv launches of the step (e4m3 ones included) against the bf16 dense peak: the bf16-equivalent rate
-            roof['conv_stack_frac_of_peak'] = round((fl + fl2 + fl8 + flw8) / (tt + tt2 + tt8 + ttw8) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)
+            # all conv launches of the step, each priced against the dense peak of ITS operand type (bf16 2.5 PF, e4m3 5 PF):
+            # the time the launches would take at their peaks over the time they took -- a fraction, never above 1
+            ideal_s = (fl + fl2) / (BF16_DENSE_PEAK_TFLOPS * 1e12) + (fl8 + flw8) / (FP8_DENSE_PEAK_TFLOPS * 1e12)
+            roof['conv_stack_frac_of_peak'] = round(ideal_s / (tt + tt2 + tt8 + ttw8), 4)
+            if fl8 + flw8 > 0:
+                roof['conv_stack_bf16_equivalent_tflops'] = round((fl + fl2 + fl8 + flw8) / (tt + tt2 + tt8 + ttw8) / 1e12, 1)
         if args.breakdown:
             for k, (f, t_, c) in agg.items():
                 print(f'{k}: {c // 3} launches/step, {t_ / 3 * 1e3:.3f} ms/step, {f / t_ / 1e12:.1f} TFLOP/s', file=sys.stderr)
@@ -385,8 +500,12 @@ def main():
                              for _, r, n, f in __import__('wav2letter_pytorch_amd.streams', fromlist=['report']).report],
             'collectives_via': (None if getattr(model, 'grad_reducer', None) is None or not model.grad_reducer.active else
                                 'w2l_rccl_* (C ABI)' if model.grad_reducer._comm is not None else 'torch.distributed'),
+            'collective_paths_ms': collective_paths,
             'rank_ms_per_step': [round(v, 3) for v in rank_ms],
             'exposed_comm_ms': None if exposed_comm_ms is None else round(exposed_comm_ms, 3),
+            'exposed_comm_ms_by_rank': exposed_by_rank,
+            'tune_plans': (None if tune_shas is None else
+                           {'shared_from_rank0': tune_path, 'sha16_by_rank': tune_shas, 'identical': len(set(tune_shas)) == 1}),
             'per_gpu_value': round(value / world, 1),
         }
         print(json.dumps(line))

@@ -11,6 +11,14 @@ def scale_err(got, ref):
     return float(np.abs(np.asarray(got, dtype=np.float64) - ref).max() / max(np.abs(ref).max(), 1e-12))
 
 
+def l2_cos(got, ref):
+    """(relative L2 error, cosine) of two tensors, in float64"""
+    g = np.asarray(got, dtype=np.float64).ravel()
+    r = np.asarray(ref, dtype=np.float64).ravel()
+    ng, nr = np.linalg.norm(g), np.linalg.norm(r)
+    return float(np.linalg.norm(g - r) / max(nr, 1e-30)), float(np.dot(g, r) / max(ng * nr, 1e-30))
+
+
 def build_w2l(layers, sd, precision, labels=None, dropout=False):
     from wav2letter_pytorch_amd import Wav2Letter
     from wav2letter_pytorch_amd.config import to_cfg
@@ -93,9 +101,11 @@ def compare_step(model, layers, sd, x, il, tg, tl, precision, drop=False, tie=No
     errs = {'log_probs': scale_err(out.cpu().numpy(), ref['log_probs'].numpy()),
             'loss': abs(float(loss) - float(ref['loss'])) / max(1.0, abs(float(ref['loss'])))}
     head = f'conv1ds.conv1d_{len(layers)}.'
+    compare_step.norms = {}                 # per parameter: (relative L2 error, cosine) of the gradient, beside the max-norm in errs
     for k, p in model.named_parameters():
         assert p.grad is not None and p.grad.shape == p.shape, k
         r = ref['grads'][k].numpy()
+        compare_step.norms[k] = l2_cos(p.grad.cpu().numpy(), r)
         if k.endswith('conv1.bias') and not k.startswith(head):
             # conv bias under BatchNorm: the true gradient is 0; the reference holds fp32 rounding noise
             wscale = np.abs(ref['grads'][k.replace('bias', 'weight')].numpy()).max()

@@ -386,3 +386,39 @@ def test_init_weights_xavier_and_batchnorm_reset():
     x, lens = m.create_example_input_array()                 # base_asr_models.py:27-31
     assert x.shape == (4, 64, 200) and float(x.min()) >= 0 and float(x.max()) < 1
     assert lens.shape == (4,) and int(lens.min()) >= 100 and int(lens.max()) < 200
+
+
+def test_launch_parents_never_map_the_hip_library(tmp_path):
+    """`python -m wav2letter_pytorch_amd.train ... trainer.gpus=N` and `python bench.py --gpus N` first run in a parent that
+    only spawns the ranks (launch.py): that process must not have loaded libw2l_hip.so (nor torch), so that no HIP / HSA
+    call can have happened before the children start.  Checked in a fresh interpreter up to the point where the parent
+    would call spawn_ranks."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys\n"
+        "import wav2letter_pytorch_amd.train as t\n"
+        "cfg = t.build_config(['data.train_manifest=a.csv', 'data.val_manifest=b.csv', 'trainer.gpus=2', 'model=jasper'])\n"
+        "assert t._requested_gpus(cfg) == 2 and cfg.model.name == 'jasper' and not t.under_launcher()\n"
+        "bad = [m for m in sys.modules if m.endswith('._lib') or m == 'torch']\n"
+        "assert not bad, bad\n"
+        "import wav2letter_pytorch_amd as W\n"
+        "assert W.Wav2Letter.__name__ == 'Wav2Letter' and any(m.endswith('._lib') for m in sys.modules)\n"
+        "print('clean')\n")
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE')}
+    out = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0 and 'clean' in out.stdout, out.stderr[-2000:]
+
+
+def test_visible_gpu_count_needs_no_hip(monkeypatch):
+    """the launch parent counts devices from the *_VISIBLE_DEVICES variables / sysfs, never through the runtime"""
+    from wav2letter_pytorch_amd import launch
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,1,2')
+    assert launch.visible_gpu_count() == 3
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '')
+    assert launch.visible_gpu_count() == 0
+    for var in ('HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES'):
+        monkeypatch.delenv(var, raising=False)
+    n = launch.visible_gpu_count()
+    assert n is None or n >= 0

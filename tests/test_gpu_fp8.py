@@ -216,7 +216,12 @@ def test_w2l_small_stack_fp8_weight_gradients_vs_oracle():
         E.KERNEL_TIMER = None
     assert names.count('conv_wgrad_fp8_kernel') == 3            # layers 1-3 (layer 0 reads the 64-channel spectrogram: bf16)
     worst = max((v, k) for k, v in errs.items() if k not in ('log_probs', 'loss'))
-    print(f'fp8 small stack, e4m3 weight gradients: worst grad {worst[0]:.3f} ({worst[1]}) loss {errs["loss"]:.4f}')
+    from gpu_helpers import compare_step
+    wn = {k: v for k, v in compare_step.norms.items() if k.endswith('conv1.weight')}
+    print(f'fp8 small stack, e4m3 weight gradients: worst grad {worst[0]:.3f} ({worst[1]}) loss {errs["loss"]:.4f}; L2 / cosine '
+          + ' '.join(f'{l2:.3f}/{c:.4f}' for l2, c in wn.values()))
+    for k, (l2, c) in wn.items():
+        assert l2 <= FP8_GRAD_L2 and c >= FP8_GRAD_COS, (k, l2, c)
     assert errs['log_probs'] < 8e-2 and errs['loss'] < 1e-2
     assert worst[0] < 3.5e-1
     for k, p in model.named_parameters():
@@ -242,17 +247,101 @@ def test_w2l_small_stack_fp8_vs_oracle(dgrad):
     assert st['q'].dtype == torch.uint8 and st['scale'] >= 1 and float(w.detach().abs().max()) * st['scale'] <= 448
 
 
-def test_w2l_full_table_fp8_properties_and_loss():
-    """the 21-layer table in fp8 mode at N=4 x T=1000, dropout on: finite / normalised outputs, every gradient finite and
-    non-zero, and the loss close to the oracle's with the device's masks and gates replayed"""
+def _fp8_grad_bounds(layer: int):
+    """(max relative L2 error, min cosine) of an fp8-mode weight gradient against the fp32 oracle (masks and gates replayed)
+    on the 21-layer table at N=4: e4m3 keeps 3 mantissa bits, so every quantised operand carries ~3-4 % rms relative error;
+    a gradient picks up that of its own two operands plus what the e4m3 data gradients of the layers above it left in dy.
+    Calibrated on MI355X (the per-layer figures are printed by the test), with ~30 % margin."""
+    return FP8_GRAD_L2, FP8_GRAD_COS
+
+
+FP8_GRAD_L2, FP8_GRAD_COS = 0.15, 0.98
+
+
+def test_w2l_full_table_fp8_gradients_vs_oracle():
+    """the 21-layer table in fp8 mode at N=4 x T=1000, dropout on, device masks and gates replayed through the fp32 oracle:
+    finite / normalised outputs, loss within 5e-2, and a bound on the TRAINING SIGNAL -- every conv weight gradient within
+    FP8_GRAD_L2 of the oracle's in the L2 norm and with cosine >= FP8_GRAD_COS; BatchNorm gamma / beta gradients likewise."""
+    from gpu_helpers import compare_step
     from oracle import w2l_oracle as O
     layers = list(O.W2L_LAYERS)
-    model, errs, stats = _fp8_step(layers, N=4, T=1000, seed=0, dropout=True, tie='skip')
-    print(f'fp8 full table: log-probs {errs["log_probs"]:.3f} loss {errs["loss"]:.4f}')
-    assert errs['loss'] < 1e-1
-    assert errs['log_probs'] < 5e-1
+    model, errs, stats = _fp8_step(layers, N=4, T=1000, seed=0, dropout=True, tie='skip', dgrad='1', wgrad='1')
+    norms = compare_step.norms
+    rows = []
+    for i in range(len(layers) + 1):
+        l2, cos = norms[f'conv1ds.conv1d_{i}.conv1.weight']
+        rows.append(f'{i}:{l2:.3f}/{cos:.4f}')
+    print(f'fp8 full table N=4: log-probs {errs["log_probs"]:.3f} loss {errs["loss"]:.4f}; weight gradient L2 / cosine by layer: '
+          + ' '.join(rows))
+    assert errs['loss'] < 5e-2
+    assert errs['log_probs'] < 3e-1
     for k, p in model.named_parameters():
         assert torch.isfinite(p.grad).all(), k
+        if k.endswith('conv1.bias') and not k.startswith(f'conv1ds.conv1d_{len(layers)}.'):
+            continue                                   # identically zero under batch-statistics BatchNorm
+        l2, cos = norms[k]
+        layer = int(k.split('conv1d_')[1].split('.')[0])
+        max_l2, min_cos = _fp8_grad_bounds(layer)
+        assert l2 <= max_l2 and cos >= min_cos, (k, l2, cos)
+
+
+def _jasper10x5_fp8():
+    from wav2letter_pytorch_amd import Jasper
+    from wav2letter_pytorch_amd.defaults import jasper10x5_model
+    cfg = jasper10x5_model(precision='fp8')
+    blocks = [dict(b) for b in cfg.jasper_blocks]
+    torch.manual_seed(7)
+    sd = {k: v.detach().clone() for k, v in Jasper(cfg).state_dict().items()}
+    return cfg, blocks, sd
+
+
+def test_jasper10x5_fp8_T16000():
+    """BASELINE config 5's own single-GPU workload: Jasper 10x5 (defaults.jasper10x5_model: the 13-block table through the
+    reference's jasper_blocks keys, jasper.py:439-451; 322 M parameters) in ``precision: fp8`` on T = 16 000-frame utterances
+    (N=2, one ragged).  Lengths bit-equal to the oracle's, loss against the oracle's fp32 forward, normalised log-probs, every
+    gradient finite and non-zero, and the e4m3 kernels engaged on every convolution that qualifies: forward and data gradient
+    of each stride-1 conv with a multiple of 128 input channels (conv_igemm_kernel<F8>), its weight gradient
+    (conv_wgrad_fp8_kernel); the 64-mel stride-2 prologue and the 29-label classifier stay bf16."""
+    from gpu_helpers import build_jasper, device_step
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd import engine as E
+    cfg, blocks, sd = _jasper10x5_fp8()
+    assert len(blocks) == 13 and cfg.precision == 'fp8'
+    model = build_jasper(blocks, sd, 'fp8').train()
+    eng = model.engine()
+    assert eng.fp8 and len(eng.units) == 53
+    x, il, tg, tl = O.synthetic_batch(2, 16000, seed=77, s_lo=900, s_hi=1500)
+    il[1] = 12345
+    x[1, :, 12345:] = 0
+    E.KERNEL_TIMER = []
+    try:
+        out, out_lens, loss, ectx = device_step(model, x, il, tg, tl)
+        names = [n for n, *_ in E.KERNEL_TIMER]
+    finally:
+        E.KERNEL_TIMER = None
+    del ectx
+    # which convolutions qualify for e4m3 operands (engine._conv_forward / _dgrad / _wgrad): stride 1, 128 | C_in, 128 | C_out
+    q = 0
+    for u in eng.units:
+        for c in (u.main, u.res):
+            if c is not None and c.stride == 1 and c.cin % 128 == 0 and c.cout % 128 == 0:
+                q += 1
+    assert q == 62                                  # 10 blocks x (5 repeats + 1 residual 1x1) + the dilated and the 1x1 block
+    assert names.count('conv_igemm_fp8_kernel') == 2 * q, names.count('conv_igemm_fp8_kernel')       # forward + data gradient
+    assert names.count('conv_wgrad_fp8_kernel') == q, names.count('conv_wgrad_fp8_kernel')
+    assert names.count('conv_wgrad_kernel') == 2                                            # prologue and classifier
+    assert out.shape == (2, 8000, 29) and torch.isfinite(out).all()
+    assert float((out.exp().sum(-1) - 1).abs().max()) < 1e-4
+    for k, p in model.named_parameters():
+        assert torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, k
+    with torch.no_grad():
+        lp, ol = O.jasper_forward(x, il, {k: v.clone() for k, v in sd.items()}, blocks, training=True)
+        ls = O.ctc_criterion(lp, tg, ol, tl)
+    assert [int(v) for v in out_lens] == [8000, 6173] and torch.equal(out_lens.cpu(), ol.cpu())
+    e_loss = abs(float(loss) - float(ls)) / abs(float(ls))
+    print(f'jasper10x5 fp8 T=16000: loss {float(loss):.4f} vs oracle {float(ls):.4f} ({e_loss:.4f}), '
+          f'log-probs {scale_err(out.cpu().numpy(), lp.numpy()):.3f} of scale')
+    assert e_loss < 5e-2
 
 
 def test_jasper_fp8_long_utterance_T16000():

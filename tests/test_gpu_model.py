@@ -613,6 +613,18 @@ def test_bench_self_launch_two_ranks(tmp_path):
     assert d['n_gpus'] == 2 and d['rccl_world'] == 2 and d['backend'] == 'gloo' and d['config']['global_batch'] == 4
     assert len(d['rank_ms_per_step']) == 2 and all(v > 0 for v in d['rank_ms_per_step'])
     assert d['exposed_comm_ms'] is not None and abs(d['per_gpu_value'] * 2 - d['value']) < 1.0
+    assert len(d['exposed_comm_ms_by_rank']) == 2 and d['exposed_comm_ms'] == max(d['exposed_comm_ms_by_rank'])
+    # the in-run A/B of the two collective paths: both ran (the native one on one-rank rehearsal communicators here -- RCCL
+    # refuses two ranks of one communicator on one device), the line carries both timings and names the path it kept, and
+    # the timed region ran on that path
+    ab = d['collective_paths_ms']
+    native, via_torch = 'w2l_rccl_* (C ABI)', 'torch.distributed'
+    assert ab[via_torch] > 0 and ab[native] is not None and ab[native] > 0, ab
+    assert ab['kept'] == (native if ab[native] < ab[via_torch] else via_torch) and 'rehearsal' in ab['note']
+    assert d['collectives_via'] == ab['kept']
+    # rank 0 tuned, rank 1 loaded its plans: one plan table on both ranks
+    tp = d['tune_plans']
+    assert tp['identical'] and len(tp['sha16_by_rank']) == 2 and len(set(tp['sha16_by_rank'])) == 1
     bad = subprocess.run(cmd, env=dict(env, RANK='0', WORLD_SIZE='3', MASTER_ADDR='127.0.0.1', MASTER_PORT='1'), cwd=root,
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and 'must agree' in bad.stderr

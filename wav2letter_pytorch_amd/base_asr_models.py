@@ -35,6 +35,30 @@ except ImportError:  # pragma: no cover - exercised in this image
 EXAMPLE_BATCH, EXAMPLE_FRAMES = 4, (100, 200)         # base_asr_models.py:27-31
 
 
+def _nothing():
+    return None
+
+
+class EngineSlot(tuple):
+    """(key, StackEngine) as cached in a module's ``__dict__``.  An engine holds HIP streams and raw-pointer specs of THIS
+    module's tensors: a copy of the module (``copy.deepcopy``, ``torch.save`` of the whole module, pickling for a worker)
+    gets an empty slot instead and rebuilds its own engine on first use."""
+
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (_nothing, ())
+
+
+def feature_size(cfg, audio_conf) -> int:
+    """rows of the input spectrogram: ``cfg.input_size`` when the config names one, else the one-sided STFT bins of the
+    analysis window, 1 + n_fft / 2 with n_fft = sample_rate * window_size (wav2letter.py:53-57, jasper.py:426-430)"""
+    if cfg.input_size:
+        return cfg.input_size
+    return int(1 + audio_conf['sample_rate'] * audio_conf['window_size'] / 2)
+
+
 class ConvCTCASR(_Base):
     def __init__(self, cfg):
         super().__init__()
@@ -45,6 +69,8 @@ class ConvCTCASR(_Base):
         self.criterion = CTCLoss(blank=0, reduction='mean', zero_infinity=True)      # base_asr_models.py:23
         self.print_decoded_prob = cfg.get('print_decoded_prob', 0)
         self.example_input_array = self.create_example_input_array()
+        # load_state_dict(assign=True) swaps Parameter OBJECTS under the engine's specs: rebuild after any load
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_engine())
 
     def create_example_input_array(self):
         """(spectrograms [4, input_size, 200] ~ U[0,1), lengths [4] ~ U{100..199}) -- Lightning's model summary input;
@@ -84,7 +110,7 @@ class ConvCTCASR(_Base):
         key = (getattr(self, 'precision', None), next(self.parameters()).device)
         hit = self.__dict__.get('_engine_cache')
         if hit is None or hit[0] != key:
-            hit = (key, build())
+            hit = EngineSlot((key, build()))
             self.__dict__['_engine_cache'] = hit
         eng = hit[1]
         eng.overlap_wgrad = getattr(self, '_overlap_wgrad', True)

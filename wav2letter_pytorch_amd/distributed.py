@@ -60,6 +60,7 @@ class NativeComm:
         if len(unique_id) != self.ID_BYTES:
             raise ValueError(f'an RCCL unique id has {self.ID_BYTES} bytes, got {len(unique_id)}')
         self.rank, self.world = rank, world
+        self.rehearsal = False
         self._lib, self._check = lib, check
         comm = C.c_void_p()
         check(lib.w2l_rccl_init(unique_id, rank, world, C.byref(comm)), 'w2l_rccl_init')   # collective over the ranks
@@ -75,12 +76,28 @@ class NativeComm:
 
     @classmethod
     def from_process_group(cls, group=None):
-        """rank 0 draws the id; the existing process group (any backend) carries it to the others"""
+        """rank 0 draws the id; the existing process group (any backend) carries it to the others.
+
+        Collective and fail-together: if rank 0 cannot draw an id every rank raises (nobody is left waiting in the
+        broadcast).  One-GPU rehearsal (``W2L_DIST_BACKEND=gloo``: all ranks share cuda:0, and RCCL refuses two ranks of one
+        communicator on one device): every process gets a ONE-rank communicator of its own -- the launch path (C ABI call
+        on the reducer's stream, events) is the production one, but nothing is averaged across the ranks (``rehearsal``)."""
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
-        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1 and os.environ.get('W2L_DIST_BACKEND') == 'gloo':
+            comm = cls(0, 1, cls.unique_id())
+            comm.rehearsal = True
+            return comm
+        box = [None]
+        if rank == 0:
+            try:
+                box = [cls.unique_id()]
+            except Exception as e:          # noqa: BLE001 -- carried to the other ranks below, raised on all of them
+                box = [e]
         if world > 1:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        return cls(rank, world, box[0])
+        if not isinstance(box[0], (bytes, bytearray)):
+            raise RuntimeError(f'rank 0 could not draw an RCCL unique id: {box[0]!r}')
+        return cls(rank, world, bytes(box[0]))
 
     def _stream(self, stream):
         import ctypes as C
@@ -162,6 +179,13 @@ class GradReducer:
         self._comm: Optional[NativeComm] = None
         if native and self.active and torch.cuda.is_available():
             self._comm = NativeComm.from_process_group(group)
+
+    def set_native(self, comm: Optional[NativeComm]):
+        """route the gradient collectives through ``comm`` (the C ABI's RCCL helpers) from the next step on, or back through
+        torch.distributed (None).  Call between steps, with nothing in flight (after ``finish()`` and a stream sync)."""
+        if self._works or self._small:
+            raise RuntimeError('GradReducer.set_native with collectives in flight')
+        self._comm = comm
 
     def _side_stream(self, device):
         if self._stream is None:
@@ -261,6 +285,11 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):
     """identical replicas at step 0 (DDP broadcasts rank 0's state at construction)."""
     if not dist.is_initialized() or dist.get_world_size(group) <= 1:
         return
+    if torch.cuda.is_available():
+        # nothing of this package may still be running when torch's communicator starts: optimizer updates stream on a side
+        # stream, and a second (native) RCCL communicator may have collectives queued -- RCCL promises no progress for two
+        # communicators with work in flight at once
+        torch.cuda.synchronize()
     from .engine import invalidate_packed
     invalidate_packed(module)              # .data writes below do not bump Parameter._version: repack on the next forward
     for t in list(module.parameters()) + list(module.buffers()):

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import atexit
 import ctypes as C
+import math
 import os
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence
@@ -380,9 +381,10 @@ def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw
 # fp8 mode (BASELINE config 5): per-tensor scales of the e4m3 operands.  Activations: clamp(0, 20) outputs times 16 stay
 # below e4m3's 448; ReLU / linear outputs (BatchNorm-normalised, a few units wide) times 8, saturating beyond 56.  Weights:
 # the largest power of two that keeps |w| * scale <= 448, re-derived from the tensor's amax every FP8_WEIGHT_RESCALE
-# quantisations (one host sync per weight then; weights move by lr * grad per step, and the conversion saturates).
+# weight versions without a host sync (_fp8_weights: device-side amax, asynchronous copy, adopted FP8_RESCALE_LAG versions later).
 FP8_ACT_SCALE = {ACT_CLAMP20: 16.0, ACT_RELU: 8.0, ACT_NONE: 8.0}
 FP8_WEIGHT_RESCALE = 256
+FP8_RESCALE_LAG = 2
 AMAX_SLOTS = 64                    # include/w2l_hip.h W2L_AMAX_SLOTS
 # fp8 mode, data gradients: on e4m3 operands too ('1'), in bf16 ('0'), or (default 'auto') e4m3 only from FP8_DGRAD_MIN_ROWS
 # rows of dy per launch.  The e4m3 data gradient needs two more launches per layer on the backward critical path (dy's
@@ -402,19 +404,48 @@ FP8_WGRAD = os.environ.get('W2L_FP8_WGRAD', 'auto')
 JOIN_EVENTS = None                 # a list: backward() appends (event on the main stream, event on the weight-gradient stream) at its join
 
 
+def _pow2_scale(amax: float) -> float:
+    """the largest power of two s with amax * s <= 448 (e4m3's largest finite value)"""
+    return 2.0 ** math.floor(math.log2(448.0 / max(float(amax), 1e-30)))
+
+
 def _fp8_weights(conv: ConvSpec, pk: '_PackedW', dgrad: bool = False):
     """(e4m3 operand, scale) of a conv weight, requantised from the bf16 pack when the weight changed: the forward layout
-    [Kw, CoutP, CinP], or (``dgrad``) the flipped-tap layout [Kw, CinP, CoutP] of the data gradient -- one scale for both"""
+    [Kw, CoutP, CinP], or (``dgrad``) the flipped-tap layout [Kw, CinP, CoutP] of the data gradient -- one scale for both.
+
+    The scale is a host float (the kernels take it by value).  It is derived from the tensor's amax with a host sync ONCE,
+    at first use; afterwards every FP8_WEIGHT_RESCALE weight versions the amax is re-taken on the device and copied to pinned
+    host memory asynchronously, and the scale it yields is adopted FP8_RESCALE_LAG versions later (by then the copy has long
+    landed: no pipeline drain, and every rank of a data-parallel run adopts it at the same step).  Weights move by lr * grad
+    per step and the conversion saturates, so a scale that lags by a few steps is harmless.  Under stream capture
+    (graph.GraphedTrainStep) the scale in force when the graph was captured stays."""
     w = conv.weight
     st = w.__dict__.get('_w2l_fp8')
-    if st is None or st['age'] >= FP8_WEIGHT_RESCALE or st['q'].shape != pk.fwd_hi.shape or st['q'].device != pk.fwd_hi.device:
-        amax = float(pk.fwd_hi.abs().amax())                     # host sync: first use and every FP8_WEIGHT_RESCALE steps
-        scale = 2.0 ** int(torch.floor(torch.log2(torch.tensor(448.0 / max(amax, 1e-30)))))
+    if st is None or st['q'].shape != pk.fwd_hi.shape or st['q'].device != pk.fwd_hi.device:
+        mn, mx = torch.aminmax(pk.fwd_hi)
+        scale = _pow2_scale(max(-float(mn), float(mx)))          # host sync: first use only
         dev = pk.fwd_hi.device
         st = {'q': torch.empty(pk.fwd_hi.shape, dtype=torch.uint8, device=dev),
               'qd': torch.empty(pk.dgr_hi.shape, dtype=torch.uint8, device=dev), 'scale': scale, 'age': 0, 'version': None,
-              'version_d': None}
+              'version_d': None, 'req': None}
         w.__dict__['_w2l_fp8'] = st
+    elif not dgrad and not torch.cuda.is_current_stream_capturing():
+        req = st.get('req')
+        if req is not None and st['age'] >= FP8_RESCALE_LAG:
+            ev, host = req
+            ev.synchronize()                                         # FP8_RESCALE_LAG steps old: returns at once
+            st['req'] = None
+            scale = _pow2_scale(max(-float(host[0]), float(host[1])))
+            if scale != st['scale']:
+                st['scale'] = scale
+                st['version'] = st['version_d'] = None               # both layouts are requantised below / by the data gradient
+        elif req is None and st['age'] >= FP8_WEIGHT_RESCALE:
+            host = torch.empty(2, dtype=torch.float32, pin_memory=True)
+            host.copy_(torch.stack(torch.aminmax(pk.fwd_hi)).float(), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            st['req'] = (ev, host)
+            st['age'] = 0
     key, vkey, src = ('qd', 'version_d', pk.dgr_hi) if dgrad else ('q', 'version', pk.fwd_hi)
     if st[vkey] != pk.version:
         check(lib.w2l_quantize_e4m3(ptr(src), 0, src.numel(), st['scale'], ptr(st[key]), stream_ptr()), 'w2l_quantize_e4m3')
@@ -1085,7 +1116,9 @@ class StackEngine:
         side-stream kernel touches is kept alive in self._held until backward() joins the streams, so the caching
         allocator never has to poll cross-stream events (that polling stalled small-batch steps by 2-3x)."""
         f8 = None
-        if (self.fp8 and amax is not None and src.q is not None and conv.stride == 1 and pk.coutp % 128 == 0
+        # (W2L_DETERMINISTIC=1: the e4m3 kernel sums its splits with fp32 atomics -- the bit-reproducible slab path is the
+        # bf16 kernel's, so a deterministic run takes that one for the weight gradients in fp8 mode too)
+        if (self.fp8 and not DETERMINISTIC_WGRAD and amax is not None and src.q is not None and conv.stride == 1 and pk.coutp % 128 == 0
                 and src.CP == pk.cinp and pk.cinp % 128 == 0 and (min(conv.kernel, 2) - 1) * conv.dilation <= 32):
             f8 = self._dy_e4m3(dy_hi, amax)          # on the current (main) stream, before the fork
         if not self.overlap_wgrad or not dy_hi.is_cuda:

@@ -12,11 +12,12 @@ from __future__ import annotations
 
 from typing import List
 
-import numpy as np
+import math
+
 import torch
 import torch.nn as nn
 
-from .base_asr_models import ConvCTCASR
+from .base_asr_models import ConvCTCASR, feature_size
 from .engine import ACT_NONE, ACT_RELU, PAD_ZERO, StackEngine, UnitSpec
 from .layers import BatchNorm1d, Conv1d, conv_spec, default_precision, run_stack, solo_engine
 
@@ -44,18 +45,28 @@ def init_weights(m, mode='xavier_uniform'):
 
 
 def compute_new_kernel_size(kernel_size, kernel_width):
-    new_kernel_size = max(int(kernel_size * kernel_width), 1)
-    if new_kernel_size % 2 == 0:          # even kernels are rounded up to odd
-        new_kernel_size += 1
-    return new_kernel_size
+    """kernel taps after scaling by ``kernel_width``, forced odd so that 'same' padding is symmetric (jasper.py:53-58):
+    32 -> 33, 38 -> 39, ... ; never below one tap"""
+    return max(int(kernel_size * kernel_width), 1) | 1
 
 
 def get_same_padding(kernel_size, stride, dilation):
-    if stride > 1 and dilation > 1:
+    """zeros on each side of the time axis (jasper.py:61-66): half the kernel, or half the dilated span minus one"""
+    if min(stride, dilation) > 1:
         raise ValueError("Only stride OR dilation may be greater than 1")
-    if dilation > 1:
-        return (dilation * kernel_size) // 2 - 1
-    return kernel_size // 2
+    return (kernel_size * dilation) // 2 - int(dilation > 1)
+
+
+# per-block keys of cfg.jasper_blocks -> JasperBlock keyword, with the value used when the key is absent
+# (jasper.py:440-449); ``layer_size``, ``kernel_size`` and ``residual`` are mandatory
+_BLOCK_KEYS = (('layer_size', 'planes', None), ('kernel_size', 'kernel_size', None), ('residual', 'residual', None),
+               ('stride', 'stride', 1), ('dilation', 'dilation', 1), ('repeat', 'repeat', 1),
+               ('conv_mask', 'conv_mask', True), ('separable', 'separable', True), ('dropout', 'dropout', 0))
+
+
+def block_kwargs(row) -> dict:
+    """one row of ``cfg.jasper_blocks`` as JasperBlock constructor keywords"""
+    return {kw: (row[key] if default is None else row.get(key, default)) for key, kw, default in _BLOCK_KEYS}
 
 
 class _NoParams(nn.Module):
@@ -243,38 +254,34 @@ class Jasper(ConvCTCASR):
     def __init__(self, cfg):
         super(Jasper, self).__init__(cfg)
         self.mid_layers = cfg.mid_layers
-        if not cfg.input_size:
-            nfft = (self.audio_conf['sample_rate'] * self.audio_conf['window_size'])
-            self.input_size = int(1 + (nfft / 2))
-        else:
-            self.input_size = cfg.input_size
+        self.input_size = feature_size(cfg, self.audio_conf)
         self.precision = default_precision(cfg)
         self.check_nan = True                    # jasper.py:474 asserts on every forward (host sync)
-        self._build_encoder(cfg)
-        last_layer_input_size = self.jasper_encoder[-1].mconv[-1].num_features
-        self.final_layer = nn.Sequential(Conv1d(last_layer_input_size, len(self.labels), kernel_size=1, stride=1,
-                                                init='xavier_uniform'))
+        width = self._build_encoder(cfg)
+        # classifier: a plain (unmasked) 1x1 Conv1d WITH bias, inside a Sequential (key ``final_layer.0``), jasper.py:432-434
+        self.final_layer = nn.Sequential(Conv1d(width, len(self.labels), kernel_size=1, stride=1, init='xavier_uniform'))
         self.final_layer.apply(init_weights)
 
-    def _build_encoder(self, cfg):
-        layer_size = self.input_size
-        encoder_layers = []
-        for l in cfg.jasper_blocks[:cfg.mid_layers]:
-            layer = JasperBlock(inplanes=layer_size, planes=l.layer_size, kernel_size=l.kernel_size,
-                                stride=l.get('stride', 1), dilation=l.get('dilation', 1), residual=l.residual,
-                                repeat=l.get('repeat', 1), conv_mask=l.get('conv_mask', True),
-                                separable=l.get('separable', True), activation=torch.nn.ReLU(),
-                                dropout=l.get('dropout', 0))
-            encoder_layers.append(layer)
-            layer_size = l.layer_size
-        self.jasper_encoder = nn.Sequential(*encoder_layers)
+    def _build_encoder(self, cfg) -> int:
+        """the first ``mid_layers`` rows of cfg.jasper_blocks as a Sequential of JasperBlock (jasper.py:436-453); every block
+        gets its own ReLU instance request (the engine fuses the activation anyway); returns the encoder's output width"""
+        widths = [self.input_size]
+        blocks = []
+        for row in cfg.jasper_blocks[: cfg.mid_layers]:
+            kw = block_kwargs(row)
+            blocks.append(JasperBlock(inplanes=widths[-1], activation=nn.ReLU(), **kw))
+            widths.append(kw['planes'])
+        self.jasper_encoder = nn.Sequential(*blocks)
         self.jasper_encoder.apply(init_weights)
+        return widths[-1]
 
     @property
     def scaling_factor(self):
-        if not hasattr(self, '_scaling_factor'):
-            self._scaling_factor = int(np.prod([block.mconv[0].conv.stride[0] for block in self.jasper_encoder]))
-        return self._scaling_factor
+        """input frames per output frame: the stride of each block's FIRST conv, multiplied (jasper.py:455-459); once"""
+        cached = self.__dict__.get('_scaling_factor')
+        if cached is None:
+            cached = self.__dict__['_scaling_factor'] = math.prod(b.mconv[0].conv.stride[0] for b in self.jasper_encoder)
+        return cached
 
     def _build_engine(self) -> StackEngine:
         units: List[UnitSpec] = []

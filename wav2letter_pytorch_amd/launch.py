@@ -29,6 +29,32 @@ def free_port() -> int:
     return port
 
 
+def visible_gpu_count() -> Optional[int]:
+    """GPUs this process's children can open, WITHOUT any HIP / HSA call (a launch parent must not initialise the runtime:
+    torch.cuda.device_count() falls back to hipGetDeviceCount -- which opens KFD -- whenever amdsmi discovery fails).
+    Counted from the KFD topology in sysfs (nodes with a gfx target and SIMDs are GPUs; CPUs report 0), narrowed by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one is set.  None = unknown (no sysfs here): the
+    caller then lets each rank find out for itself after set_device."""
+    for var in ('HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(',') if x.strip() != ''])
+    root = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        nodes = os.listdir(root)
+    except OSError:
+        return None
+    n = 0
+    for node in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(root, node, 'properties')) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get('simd_count', '0')) > 0 and int(props.get('gfx_target_version', '0')) > 0:
+            n += 1
+    return n
+
+
 def rank_env(rank: int, world: int, port: int, base: Optional[dict] = None) -> dict:
     env = dict(os.environ if base is None else base)
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),

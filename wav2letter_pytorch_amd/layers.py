@@ -156,6 +156,7 @@ def solo_engine(owner: nn.Module, units_fn: Callable[[], list]) -> StackEngine:
     key = tuple((id(t), t.device) for t in chain(owner.parameters(), owner.buffers())) + (prec,)
     hit = owner.__dict__.get('_solo_engine')
     if hit is None or hit[0] != key:
-        hit = (key, StackEngine(units_fn(), None, 0, precise=prec == 'fp32', fp8=prec == 'fp8'))
+        from .base_asr_models import EngineSlot        # a copy / pickle of the module gets an empty slot, not this engine
+        hit = EngineSlot((key, StackEngine(units_fn(), None, 0, precise=prec == 'fp32', fp8=prec == 'fp8')))
         owner.__dict__['_solo_engine'] = hit
     return hit[1]

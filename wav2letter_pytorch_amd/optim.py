@@ -148,10 +148,10 @@ class FusedSGD(torch.optim.SGD):
         # zero_grad(set_to_none=True) has dropped p.grad): no fill launch for the split-K weight gradients of the next step
         recycle = self.recycle_grads and not precise
         # fp8 mode (engine._fp8_weights left its state on the parameter): emit the e4m3 operands of the next step here too,
-        # with the scale in force -- its periodic re-derivation from amax stays with the engine
+        # with the scale in force -- its periodic re-derivation from amax stays with the engine (asynchronous: a new scale
+        # is adopted at a forward pass, which then requantises both layouts itself for that one step)
         f8 = p.__dict__.get('_w2l_fp8')
-        if f8 is not None and (precise or f8['q'].shape != fwd_hi.shape or f8['q'].device != dev
-                               or f8['age'] >= E.FP8_WEIGHT_RESCALE):
+        if f8 is not None and (precise or f8['q'].shape != fwd_hi.shape or f8['q'].device != dev):
             f8 = None
         check(lib.w2l_sgd_pack(ptr(p), ptr(g), ptr(buf), int(first), float(lr), float(mu), float(wd), int(nesterov),
                                int(recycle), cout, cin, kw, ptr(fwd_hi), ptr(fwd_lo), ptr(dgr_hi), ptr(dgr_lo),

@@ -14,18 +14,26 @@ from __future__ import annotations
 import os
 import sys
 
-import torch
-from torch.utils.data.distributed import DistributedSampler
-
-from . import Jasper, Wav2Letter
 from .config import _yaml_load, load_config, to_cfg
-from .data import label_sets
-from .data.data_loader import BatchAudioDataLoader, SpectrogramDataset
-from .defaults import root_config
 from .launch import spawn_ranks, under_launcher
-from .trainer import Trainer
 
-name_to_model = {'jasper': Jasper, 'wav2letter': Wav2Letter}
+# Nothing above maps libw2l_hip.so (or imports torch): with trainer.gpus=N this process only starts the ranks, and a launch
+# parent must not have touched the GPU (launch.py; bench.py follows the same rule).  The model / data / trainer modules are
+# imported where a rank first needs them.
+
+
+class _Models(dict):
+    """``name_to_model`` of the reference's train.py:15-19, filled on first lookup"""
+
+    def __missing__(self, key):
+        from . import Jasper, Wav2Letter
+        self.update(jasper=Jasper, wav2letter=Wav2Letter)
+        if key not in self:
+            raise KeyError(key)
+        return self[key]
+
+
+name_to_model = _Models()
 
 
 def get_data_loaders(labels, cfg, rank: int = 0, world: int = 1):
@@ -33,6 +41,8 @@ def get_data_loaders(labels, cfg, rank: int = 0, world: int = 1):
     over the raw items (indices rank, rank + world, ...; the tail padded so every rank takes the same number of steps --
     a rank that ran out of batches early would leave the others waiting in a collective), which is what Lightning's DDP
     injects into the reference's loaders."""
+    from torch.utils.data.distributed import DistributedSampler
+    from .data.data_loader import BatchAudioDataLoader, SpectrogramDataset
     loaders = []
     for manifest in (cfg.train_manifest, cfg.val_manifest):
         ds = SpectrogramDataset(manifest, cfg.audio_conf, labels, mel_spec=cfg.mel_spec)
@@ -57,6 +67,7 @@ def build_config(argv):
     overrides = [a for a in rest if '=' in a]
     if config_dir is not None:
         return load_config(config_dir, overrides)
+    from .defaults import root_config
     group = 'wav2letter'
     plain = []
     for ov in overrides:
@@ -100,6 +111,9 @@ def main(argv=None):
         if rc:
             raise SystemExit(rc)
         return None, None
+    import torch
+    from .data import label_sets
+    from .trainer import Trainer
     if type(cfg.model.labels) is str:
         cfg.model.labels = list(label_sets.labels_map[cfg.model.labels])
     if isinstance(cfg.model.get('decoder'), dict):

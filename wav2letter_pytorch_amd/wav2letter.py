@@ -7,7 +7,7 @@ from typing import Tuple
 
 import torch.nn as nn
 
-from .base_asr_models import ConvCTCASR
+from .base_asr_models import ConvCTCASR, feature_size
 from .engine import ACT_CLAMP20, ACT_NONE, PAD_REFLECT, StackEngine, UnitSpec
 from .layers import BatchNorm1d, Conv1d, conv_spec, default_precision, run_stack, solo_engine
 
@@ -59,8 +59,7 @@ class Wav2Letter(ConvCTCASR):
     def __init__(self, cfg):
         super(Wav2Letter, self).__init__(cfg)
         self.mid_layers = cfg.mid_layers
-        # spectrogram bins when the config gives no feature size (wav2letter.py:53-57): 1 + n_fft / 2
-        self.input_size = cfg.input_size or int(1 + self.audio_conf['sample_rate'] * self.audio_conf['window_size'] / 2)
+        self.input_size = feature_size(cfg, self.audio_conf)
         self.precision = default_precision(cfg)
         rows = list(cfg.layers[: self.mid_layers])
         widths = [self.input_size] + [r.output_size for r in rows]
