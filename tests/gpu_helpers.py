@@ -86,9 +86,11 @@ def check_gate_ties(ref_step, gates, layers, tie=2e-3, max_frac=2e-3):
             assert dis.float().mean() < max_frac
 
 
-def compare_step(model, layers, sd, x, il, tg, tl, precision, drop=False, tie=None, max_frac=None):
+def compare_step(model, layers, sd, x, il, tg, tl, precision, drop=False, tie=None, max_frac=None, fp8_layers=()):
     """device step vs oracle step (gates/masks replayed); returns dict of errors.  ``tie`` / ``max_frac``: how far from
-    a clamp bound (in the oracle's free-running activations) a differing gate decision may sit, and how many may differ."""
+    a clamp bound (in the oracle's free-running activations) a differing gate decision may sit, and how many may differ.
+    ``fp8_layers``: conv blocks the oracle evaluates under its e4m3 operand model (oracle.fp8_conv1d) -- the statement of
+    what ``precision: fp8`` computes."""
     out, out_lens, loss, ectx = device_step(model, x, il, tg, tl)
     gates = device_gates(ectx)
     masks = device_dropout_masks(ectx, [l[0] for l in layers]) if drop else None
@@ -97,7 +99,8 @@ def compare_step(model, layers, sd, x, il, tg, tl, precision, drop=False, tie=No
     if tie != 'skip':      # (fp8 over 21 layers: the free-running activations are too far apart for the check to mean anything)
         check_gate_ties(free, gates, layers, tie=tie if tie is not None else (2e-3 if precision == 'fp32' else 0.25),
                         max_frac=max_frac if max_frac is not None else (2e-3 if precision == 'fp32' else 0.05))
-    ref = O.wav2letter_step(x, il, tg, tl, sd_ref, layers, drop_masks=masks, gates=gates)
+    ref = O.wav2letter_step(x, il, tg, tl, sd_ref, layers, drop_masks=masks, gates=gates, fp8_layers=fp8_layers)
+    compare_step.ref = ref
     errs = {'log_probs': scale_err(out.cpu().numpy(), ref['log_probs'].numpy()),
             'loss': abs(float(loss) - float(ref['loss'])) / max(1.0, abs(float(ref['loss'])))}
     head = f'conv1ds.conv1d_{len(layers)}.'

@@ -36,7 +36,13 @@ def _bf16_grad_bound(key, n):
     return 0.2 if n >= 32 else 0.35
 
 
-BF16_N32_GRAD_L2, BF16_N32_GRAD_COS = 0.08, 0.995      # per-tensor gradient bounds at N=32, bf16 vs the fp32 oracle
+# per-tensor gradient bounds at N=32, bf16 vs the fp32 oracle.  Measured on MI355X: L2 0.090-0.116, cosine 0.9933-0.9960, nearly
+# the same for all 20 layers -- the deviation enters at the TOP (the bf16 forward's ~3e-2 of the log-prob scale changes
+# softmax - posterior, and the last BatchNorm's backward subtracts the large per-channel mean of that gradient, which
+# amplifies the difference) and travels down unchanged; the classifier's own gradient is at 0.006.  (Carrying the
+# classifier's data gradient in fp32 with a hi + lo split of softmax - posterior was measured: no change -- the source is
+# the forward deviation, not a backward rounding.)
+BF16_N32_GRAD_L2, BF16_N32_GRAD_COS = 0.14, 0.991
 
 
 def _report(title, errs):

@@ -14,7 +14,7 @@ block order MEASURED by the tuner exactly as in the bench's warm-up step:
 against a float64 evaluation of the same bf16-rounded operands (per-tap matrix products in torch float64 on the device:
 14.7 TFLOP of float64 is minutes on the host cores, a second on the GPU; a slice of each result is re-derived on the CPU so
 the reference itself is cross-checked).  Bounds: fp32 results within 1e-4 of the tensor scale (measured ~1e-6: fp32
-accumulation over K <= 25 984), bf16-stored results within half a bf16 ulp of the float64 value plus that 1e-4."""
+accumulation over K <= 25 984), bf16-stored results within half a bf16 ulp (at most 2^-8 of the value) of the float64 value plus that 1e-4."""
 import ctypes as C
 
 import pytest
@@ -109,7 +109,7 @@ def test_headline_layer_kernels_exact(L, shape):
         if f32:
             assert _err(got, ref) < 1e-4, ('forward fp32 store', _err(got, ref))
         else:
-            slack = (got - ref).abs() - (2.0 ** -9 * 1.01) * ref.abs() - 1e-4 * scale
+            slack = (got - ref).abs() - (2.0 ** -8 * 1.01) * ref.abs() - 1e-4 * scale
             assert float(slack.max()) <= 0, ('forward bf16 store', float(slack.max()) / scale)
         if coutp > cout:
             assert not bool(y[:, :, cout:].float().abs().max() > 0)
@@ -174,5 +174,5 @@ def test_headline_layer_kernels_exact(L, shape):
         if f32:
             assert _err(got, refx) < 1e-4, ('data gradient fp32 store', _err(got, refx))
         else:
-            slack = (got - refx).abs() - (2.0 ** -9 * 1.01) * refx.abs() - 1e-4 * scale
+            slack = (got - refx).abs() - (2.0 ** -8 * 1.01) * refx.abs() - 1e-4 * scale
             assert float(slack.max()) <= 0, ('data gradient bf16 store', float(slack.max()) / scale)
