@@ -150,6 +150,8 @@ def main():
                          'RCCL helpers) and keep torch.distributed (or what W2L_DP_NATIVE says)')
     ap.add_argument('--serial-wgrad', action='store_true', help='keep weight gradients on the main stream (clean per-kernel durations for profiling)')
     ap.add_argument('--trace-steps', action='store_true', help='per-step host-enqueue vs GPU time (stderr), then exit')
+    ap.add_argument('--lead-trace', action='store_true',
+                    help='how far the host runs ahead of the GPU at four points of every step (stderr), then exit')
     ap.add_argument('--host-profile', action='store_true', help='cProfile of the host side of the step (stderr), then exit')
     ap.add_argument('--breakdown', action='store_true', help='print the per-kernel event timing table to stderr')
     args = ap.parse_args()
@@ -314,6 +316,46 @@ def main():
         print('load average: %s' % open('/proc/loadavg').read().strip(), file=sys.stderr)
         print('host enqueue ms/step: ' + ' '.join('%.1f' % v for v in host), file=sys.stderr)
         print('gpu ms/step:          ' + ' '.join('%.1f' % v for v in gpu), file=sys.stderr)
+        return
+    if args.lead_trace:
+        # Is the GPU ever starved by the host?  At four program points of every step -- step start, forward enqueued, backward
+        # enqueued, optimizer enqueued -- the host notes its clock and records an event on the main stream; afterwards
+        # lead = (GPU time at which the event fired) - (host time at which it was recorded), both measured from a common
+        # synchronised origin.  A lead near zero means the GPU reached that point as soon as the host had enqueued it: the
+        # stream was running dry there.
+        names = ('step start', 'forward enqueued', 'backward enqueued', 'optimizer enqueued')
+        torch.cuda.synchronize()
+        origin = torch.cuda.Event(enable_timing=True)
+        origin.record()
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        marks = []
+
+        def mark():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append((time.perf_counter() - h0, e))
+
+        for _ in range(args.steps):
+            mark()
+            opt.zero_grad(set_to_none=True)
+            out, _ = model(x, lens_arg)
+            loss = model.criterion(out.transpose(0, 1), tg_d, ol, tl_d)
+            mark()
+            loss.backward()
+            mark()
+            opt.step()
+            mark()
+        torch.cuda.synchronize()
+        print('lead of the host over the GPU in ms (rows = steps):', file=sys.stderr)
+        print('  ' + ' | '.join('%-18s' % n for n in names) + ' | host ms in step | gpu ms in step', file=sys.stderr)
+        for i in range(args.steps):
+            row = marks[4 * i: 4 * i + 4]
+            leads = [origin.elapsed_time(e) - h * 1e3 for h, e in row]
+            nxt = marks[4 * i + 4] if i + 1 < args.steps else None
+            host_ms = (nxt[0] - row[0][0]) * 1e3 if nxt else float('nan')
+            gpu_ms = row[0][1].elapsed_time(nxt[1]) if nxt else float('nan')
+            print('  ' + ' | '.join('%18.3f' % v for v in leads) + ' | %15.3f | %14.3f' % (host_ms, gpu_ms), file=sys.stderr)
         return
     if args.host_profile:
         import cProfile

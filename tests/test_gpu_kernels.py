@@ -212,7 +212,8 @@ def test_conv_igemm_every_configuration(L, with_stats):
 
 @pytest.mark.parametrize('Kw,s,d', [(5, 1, 2), (6, 1, 1), (7, 1, 2), (8, 1, 1), (11, 2, 1)])
 def test_conv_wgrad_every_plan(L, Kw, s, d):
-    """split counts x both block orders x one or two tap groups per block (the autotuner's search space).  Tap counts
+    """split counts x both block orders x {one tap group, two tap groups, 32x32x16 MFMA fragments (order bit 3; stride 1)}
+    per block (the autotuner's search space).  Tap counts
     4k+1 .. 4k+4: with two tap groups (the 8-wave kernel, order bit 2) the last block then has an idle tap group and a
     one-tap wave (Kw = 5), an idle tap group (6), a one-tap second group (7), or is full (8); stride 2 takes the other
     instantiation"""
@@ -231,7 +232,7 @@ def test_conv_wgrad_every_plan(L, Kw, s, d):
     F.conv1d(F.pad(bf(x), (pl, pr), mode='reflect'), wr, None, stride=s, dilation=d).backward(bf(dy))
     ws = torch.zeros(int(L.lib.w2l_wgrad_workspace_bytes(Cin, Cout, Kw)), dtype=torch.uint8, device='cuda')
     for splits in (1, 2, 3, 5, 18):
-        for order in (0, 1, 4, 5):
+        for order in (0, 1, 4, 5, 8, 9):
             # (a) without a workspace: fp32 atomics into a zero-filled dw
             dw = torch.zeros(Kw, Cout, Cin, device='cuda')
             L.lib.w2l_wgrad_force_plan(splits, order)

@@ -95,7 +95,7 @@ def main():
 
         if args.wgrad_plans:
             res = []
-            for order in (0, 1, 4, 5, 2, 3):
+            for order in (0, 1, 4, 5, 8, 9, 2, 3):          # bit 0 block order, bit 2 two tap groups, bit 3 32x32x16 MFMA, bit 1 stream-K
                 best = (float('inf'), 0)
                 for sp in ((1,) if order & 2 else (1, 2, 3, 4, 5, 6, 8, 10, 12, 16)):
                     L.lib.w2l_wgrad_force_plan(sp, order)
