@@ -115,6 +115,49 @@ def gather_objects(dist, world, obj):
     return out
 
 
+def live_traffic(E, kernel, timeout_s=170):
+    """HBM-side bytes per launch of ``kernel``, measured NOW: two child runs of this script (2 steps each) under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the two counters do not fit one),
+    started as ordinary subprocesses while this process idles, with this run's kernel plans handed over through a tune-cache
+    file.  traffic = 2 * FETCH_SIZE KiB + WRITE_SIZE KiB (gfx950: FETCH_SIZE tallies wide streaming reads at half their
+    bytes, MI355X_MICROARCH.md 'HBM').  Returns (bytes, how) or (None, why-not); never raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, 'rocprofv3 not found'
+    tmp = tempfile.mkdtemp(prefix='w2l_pmc_', dir='/tmp')
+    try:
+        cache = os.path.join(tmp, 'tune.txt')
+        E.save_tune_cache(cache)
+        env = dict(os.environ, W2L_TUNE_CACHE=cache, TMPDIR='/tmp')
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+            env.pop(k, None)
+        vals = {}
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', out, '--', sys.executable,
+                   os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-live-traffic']
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f'rocprofv3 --pmc {counter} exited with {r.returncode}'
+            v = [float(row['Counter_Value']) for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True)
+                 for row in csv.DictReader(open(f)) if row['Counter_Name'] == counter and kernel in row['Kernel_Name']]
+            if not v:
+                return None, f'no {counter} rows for {kernel}'
+            vals[counter] = sum(v) / len(v)
+        return 2 * vals['FETCH_SIZE'] * 1024 + vals['WRITE_SIZE'] * 1024, (
+            'measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command (2 steps each), mean over '
+            'the kernel\'s launches, traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)')
+    except Exception as e:            # noqa: BLE001 -- the bench line must come out whatever the profiler does
+        return None, 'live PMC pass failed: ' + repr(e)[:160]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _launcher():
     """wav2letter_pytorch_amd/launch.py loaded by path: importing the package would load libw2l_hip.so (and the HIP
     runtime) into the parent, which only spawns the ranks"""
@@ -138,6 +181,9 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp8'],
                     help='fp8 = forward, data-gradient and weight-gradient convolutions on e4m3 operands (BASELINE config 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-live-traffic', action='store_true',
+                    help='do not start the two rocprofv3 --pmc child passes that measure roofline.traffic (the committed '
+                         'profiles/r*_pmc_bench.json is quoted instead when it was measured on this build)')
     ap.add_argument('--no-optimizer', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the step as a captured hipGraph (graph.GraphedTrainStep; Wav2Letter)')
     ap.add_argument('--no-sgd-overlap', action='store_true', help='keep the fused SGD updates on the main stream')
@@ -458,21 +504,29 @@ def main():
             if rest[2] > 0:
                 roof['other_launches'] = {'achieved': round(rest[0] / rest[1] / 1e12, 1), 'launches_per_step': rest[2] // 3,
                                           'avg_launch_ms': round(rest[1] / rest[2] * 1e3, 4)}
-        if args.model == 'wav2letter' and args.mid_layers == 20 and args.batch == 32 and args.dtype == 'bf16':
-            # HBM-side bytes per launch from the committed PMC passes of this same command (tools/make_profiles.sh):
-            # FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 FETCH correction applied (tools/prof_summary.py).  Each file
-            # carries the fingerprint of the kernel sources it was measured on: only a file measured on THIS build is quoted
-            # (newest round first); otherwise traffic = null.
+        headline = args.model == 'wav2letter' and args.mid_layers == 20 and args.batch == 32 and args.dtype == 'bf16'
+        profiled = 'rocprof' in os.environ.get('LD_PRELOAD', '') or any(k.startswith('ROCPROF') for k in os.environ)
+        if headline and world == 1 and not args.no_live_traffic and not args.graph and not profiled:
+            # HBM-side bytes per launch of the dominant kernel, measured by this very run (two profiled child passes)
+            roof['traffic'], roof['traffic_source'] = live_traffic(E, name)
+            if roof['traffic'] is not None:
+                roof['traffic'] = round(roof['traffic'])
+        if headline and roof['traffic'] is None:
+            # fall back to the committed PMC passes of this same command (tools/make_profiles.sh): FETCH_SIZE and WRITE_SIZE in
+            # separate runs, gfx950 FETCH correction applied (tools/prof_summary.py).  Each file carries the fingerprint of the
+            # kernel sources it was measured on: only a file measured on THIS build is quoted (newest round first).
             import glob
             sha = csrc_fingerprint()
-            roof['traffic_source'] = 'none: no profiles/r*_pmc_bench.json was measured on these kernel sources (' + sha + ')'
+            why = roof.get('traffic_source')
+            roof['traffic_source'] = ('none: no profiles/r*_pmc_bench.json was measured on these kernel sources (' + sha + ')'
+                                      + ('; ' + why if why else ''))
             for pmc_file in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_bench.json')), reverse=True):
                 pmc = json.load(open(pmc_file))
                 k = pmc.get('kernels', {}).get(name, {})
                 if pmc.get('csrc_sha') == sha and 'traffic_bytes_per_launch' in k:
                     roof['traffic'] = round(k['traffic_bytes_per_launch'])
                     roof['traffic_source'] = ('profiles/' + os.path.basename(pmc_file) + ' (rocprofv3 --pmc, mean over the '
-                                              'step\'s launches; kernel sources ' + sha + ')')
+                                              'step\'s launches; kernel sources ' + sha + ')' + ('; ' + why if why else ''))
                     break
         if 'conv_igemm_fp8_kernel' in agg:
             # fp8 mode: the forward convolutions of the units ran on e4m3 operands; they are priced against the fp8 peak, the

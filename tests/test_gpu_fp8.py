@@ -267,42 +267,57 @@ def test_w2l_full_table_fp8_gradients_vs_oracle():
     masks and gates replayed.  What can be asked of 20 chained e4m3 layers: a quantiser turns a perturbation d of its input
     into sqrt(d * ulp) of its output (a rounding decision flips with probability d / ulp), so two evaluations that differ by
     a bf16 rounding (2^-8) after the first layer differ by the full e4m3 noise (~2^-4) a few layers on -- the network is
-    chaotic at the e4m3 grain, for the device and for the oracle's own e4m3 model alike.  Hence three reference points:
-      (a) the fp32 oracle                     -- the reference's arithmetic;
-      (b) the oracle's e4m3 operand model     -- the same quantisation points as the device (oracle.fp8_conv1d);
-      (c) (b) against (a), both on the CPU    -- what the ARITHMETIC costs with no device involved.
-    Asserted: loss within 5e-2; finite gradients; the classifier's gradient (above every e4m3 backward) within 0.15 / 0.99;
-    and per weight tensor the device is no further from the e4m3 model than 1.25 x the model's own distance from fp32 (+0.05)
-    in relative L2 -- the device adds nothing beyond the arithmetic's noise -- with cosine >= 0.6 against both.  The
-    training signal as a whole is judged where it matters, on the loss curve: test_fp8_training_tracks_bf16."""
-    from gpu_helpers import compare_step, l2_cos
+    chaotic at the e4m3 grain, for the device and for the oracle's own e4m3 model alike.  Hence three comparisons, all with
+    the SAME dropout masks and clamp gates (the device's):
+      (a) device vs the fp32 oracle                  -- the reference's arithmetic;
+      (b) device vs the oracle's e4m3 operand model  -- the same quantisation points as the device (oracle.fp8_conv1d);
+      (c) the e4m3 model vs fp32, both on the CPU    -- what the ARITHMETIC costs with no device involved.
+    Asserted: loss within 5e-2 of both; finite gradients; the classifier's gradient (above every e4m3 backward) within 0.15 /
+    0.99 of the model's; and per conv weight the device is no further from the e4m3 model than 1.25 x (c) + 0.05 in relative
+    L2 and its cosine with both oracles is no lower than (c)'s cosine - 0.1: the device adds nothing to the arithmetic's own
+    noise.  The training signal as a whole is judged where it matters, on the loss curve: test_fp8_training_tracks_bf16."""
+    from gpu_helpers import device_dropout_masks, device_gates, device_step, l2_cos
     from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd import engine as E
     layers = list(O.W2L_LAYERS)
-    model, errs, stats = _fp8_step(layers, N=4, T=1000, seed=0, dropout=True, tie='skip', dgrad='1', wgrad='1', model_oracle=True)
-    vs_model, ref_model = dict(compare_step.norms), compare_step.ref
-    print(f'fp8 full table N=4 vs the e4m3 model: log-probs {errs["log_probs"]:.3f} loss {errs["loss"]:.4f}; weight gradient L2 / '
-          'cosine by layer: ' + _table_rows(vs_model, len(layers) + 1))
-    assert errs['loss'] < 5e-2 and errs['log_probs'] < 3e-1
+    sd = O.init_wav2letter_state(layers, seed=0)
+    model = build_w2l(layers, sd, 'fp8', dropout=True).train()
+    x, il, tg, tl = O.synthetic_batch(4, 1000, seed=1, s_lo=83, s_hi=166)
+    E.FP8_DGRAD = E.FP8_WGRAD = '1'
+    try:
+        out, out_lens, loss, ectx = device_step(model, x, il, tg, tl)
+    finally:
+        E.FP8_DGRAD = E.FP8_WGRAD = 'auto'
+    gates = device_gates(ectx)
+    masks = device_dropout_masks(ectx, [l[0] for l in layers])
+    del ectx
     got = {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}
-    del model
-    torch.cuda.empty_cache()
-    model, errs32, _ = _fp8_step(layers, N=4, T=1000, seed=0, dropout=True, tie='skip', dgrad='1', wgrad='1', model_oracle=False)
-    vs_fp32, ref_fp32 = dict(compare_step.norms), compare_step.ref
-    print(f'fp8 full table N=4 vs fp32: log-probs {errs32["log_probs"]:.3f} loss {errs32["loss"]:.4f}; ' + _table_rows(vs_fp32, len(layers) + 1))
-    assert errs32['loss'] < 5e-2
-    arith = {k: l2_cos(ref_model['grads'][k].numpy(), ref_fp32['grads'][k].numpy()) for k in ref_fp32['grads']}
-    print('the e4m3 model vs fp32 (CPU only): ' + _table_rows(arith, len(layers) + 1))
+    cins = [64] + [l[0] for l in layers]
+    f8 = tuple(i for i, l in enumerate(layers) if cins[i] % 128 == 0 and l[2] == 1)
+    assert f8 == tuple(range(1, 20))
+    ref = {}
+    for name, fl in (('fp32', ()), ('e4m3_model', f8)):
+        ref[name] = O.wav2letter_step(x, il, tg, tl, {k: v.clone() for k, v in sd.items()}, layers, drop_masks=masks,
+                                      gates=gates, fp8_layers=fl)
     head = f'conv1ds.conv1d_{len(layers)}.'
+    wkeys = [f'conv1ds.conv1d_{i}.conv1.weight' for i in range(len(layers) + 1)]
+    vs = {name: {k: l2_cos(got[k], r['grads'][k].numpy()) for k in got} for name, r in ref.items()}
+    arith = {k: l2_cos(ref['e4m3_model']['grads'][k].numpy(), ref['fp32']['grads'][k].numpy()) for k in got}
+    for title, d in (('device vs the e4m3 model', vs['e4m3_model']), ('device vs fp32', vs['fp32']), ('the e4m3 model vs fp32 (CPU)', arith)):
+        print(f'fp8 full table N=4, {title}: weight gradient L2 / cosine by layer: ' + _table_rows(d, len(layers) + 1))
+    for name, r in ref.items():
+        e_loss = abs(float(loss) - float(r['loss'])) / abs(float(r['loss']))
+        e_lp = scale_err(out.cpu().numpy(), r['log_probs'].numpy())
+        print(f'  vs {name}: loss {e_loss:.4f} log-probs {e_lp:.3f}')
+        assert e_loss < 5e-2 and e_lp < 3e-1
     for k, g in got.items():
         assert np.isfinite(g).all(), k
-        if k.endswith('conv1.bias') and not k.startswith(head):
-            continue                                   # identically zero under batch-statistics BatchNorm
-        (l2m, cosm), (l2f, cosf), (l2a, _) = vs_model[k], vs_fp32[k], arith[k]
-        if k.startswith(head):
-            assert l2m <= 0.15 and cosm >= 0.99 and l2f <= 0.2, (k, l2m, cosm, l2f)
-        else:
-            assert l2m <= 1.25 * l2a + 0.05, (k, l2m, l2a)
-            assert cosm >= 0.6 and cosf >= 0.6, (k, cosm, cosf)
+    l2m, cosm = vs['e4m3_model'][head + 'conv1.weight']
+    assert l2m <= 0.15 and cosm >= 0.99, (l2m, cosm)
+    for k in wkeys[:-1]:
+        (l2m, cosm), (l2f, cosf), (l2a, cosa) = vs['e4m3_model'][k], vs['fp32'][k], arith[k]
+        assert l2m <= 1.25 * l2a + 0.05, (k, l2m, l2a)
+        assert cosm >= cosa - 0.1 and cosf >= cosa - 0.1 and min(cosm, cosf) > 0.5, (k, cosm, cosf, cosa)
 
 
 def test_fp8_training_tracks_bf16():
