@@ -16,3 +16,10 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionstart(session):
+    """The CPU oracle's torch ops default to one thread per visible core -- 256 on a GPU box whose share of the host is 16
+    cores: oversubscribed, slow and noisy (the same suite took 384 s on one box and 529 s on another).  Cap the pool."""
+    import torch
+    torch.set_num_threads(int(os.environ.get('W2L_TEST_THREADS', min(16, os.cpu_count() or 1))))

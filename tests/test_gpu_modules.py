@@ -185,3 +185,53 @@ def test_invalidate_packed_after_raw_weight_update():
         model.conv1ds.conv1d_0.conv1.weight.mul_(1.0 / 1.5)             # a version-bumping in-place op needs no call
         back, _ = model(x)
         assert scale_err(back.cpu().numpy(), a.cpu().numpy()) < 2e-2
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('bf16', 2e-2)])
+@pytest.mark.parametrize('k,stride,dil,c', [(33, 1, 1, 256), (11, 2, 1, 128), (13, 1, 2, 96)])
+def test_depthwise_conv_standalone(precision, tol, k, stride, dil, c):
+    """the depthwise half of Jasper's separable blocks called as a module of its own -- MaskedConv1d(C, C, k, groups=C)
+    (jasper.py:96-105,319-330: masked_fill by length, conv, float length update) and the bare grouped Conv1d holder --
+    forward, dL/dx and dL/dw against torch CPU ops"""
+    import torch.nn.functional as F
+    from wav2letter_pytorch_amd.jasper import MaskedConv1d, get_same_padding
+    from wav2letter_pytorch_amd.layers import Conv1d
+    torch.manual_seed(k)
+    pad = get_same_padding(k, stride, dil)
+    m = MaskedConv1d(c, c, k, stride=stride, padding=pad, dilation=dil, groups=c).cuda()
+    m.conv.precision = precision
+    n, t = 3, 301
+    x = torch.randn(n, c, t)
+    lens = torch.tensor([t, 200, 77])
+    w = m.conv.weight.detach().cpu().clone()
+    assert tuple(w.shape) == (c, 1, k)
+    xd = x.cuda().requires_grad_(True)
+    y, lens_out = m(xd, lens)
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(1))
+    y.backward(gy.cuda())
+    xr = (x * (torch.arange(t)[None, None, :] < lens[:, None, None])).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv1d(xr, wr, None, stride=stride, padding=pad, dilation=dil, groups=c)
+    yr.backward(gy)
+    want_lens = (lens + 2 * pad - dil * (k - 1) - 1) / stride + 1           # true division: float lengths (jasper.py:109-112)
+    assert torch.equal(lens_out.cpu().float(), want_lens.float())
+    assert y.shape == yr.shape and scale_err(y.detach().cpu().numpy(), yr.detach().numpy()) < tol
+    gx = xd.grad.cpu() * (torch.arange(t)[None, None, :] < lens[:, None, None])
+    assert torch.equal(gx, xd.grad.cpu())                                    # no gradient flows into masked frames
+    assert scale_err(gx.numpy(), xr.grad.numpy()) < tol
+    assert m.conv.weight.grad.shape == (c, 1, k)
+    assert scale_err(m.conv.weight.grad.cpu().numpy(), wr.grad.numpy()) < tol
+    # the bare holder (no mask, with a bias)
+    conv = Conv1d(c, c, k, stride=stride, padding=pad, dilation=dil, groups=c, bias=True).cuda()
+    conv.precision = precision
+    x2 = x.cuda().requires_grad_(True)
+    y2 = conv(x2)
+    y2.backward(gy.cuda())
+    w2, b2 = conv.weight.detach().cpu().clone().requires_grad_(True), conv.bias.detach().cpu().clone().requires_grad_(True)
+    x2r = x.clone().requires_grad_(True)
+    F.conv1d(x2r, w2, b2, stride=stride, padding=pad, dilation=dil, groups=c).backward(gy)
+    assert scale_err(x2.grad.cpu().numpy(), x2r.grad.numpy()) < tol
+    assert scale_err(conv.weight.grad.cpu().numpy(), w2.grad.numpy()) < tol
+    assert scale_err(conv.bias.grad.cpu().numpy(), b2.grad.numpy()) < max(tol, 1e-4)
+    with pytest.raises(NotImplementedError):
+        Conv1d(64, 64, 3, groups=4).cuda()(torch.randn(1, 64, 20).cuda())

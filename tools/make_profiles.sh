@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the artefacts committed under profiles/ (run through gpurun; outputs land in gpurun_out/final/ and are then
-# copied into profiles/ with the round prefix by hand: `for f in gpurun_out/final/*; do cp $f profiles/r02_$(basename $f); done`).
+# copied into profiles/ with the round prefix by hand: `for f in gpurun_out/final/*; do cp $f profiles/r03_$(basename $f); done`).
 # Stages are independent: a failing one leaves its file empty, the others still run.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/final
@@ -16,6 +16,8 @@ for d in default serial; do
   cp $f $OUT/${d}_kernel_stats.csv
   python3 tools/prof_summary.py stats $f > $OUT/${d}_kernel_families.txt
 done
+# the overlapped step as a timeline: MFMA-busy time, time with only HBM-bound kernels running, idle (tools/timeline.py)
+python3 tools/timeline.py $(ls $OUT/prof_default/*/*kernel_trace.csv | head -1) --steps 6 --from 4 > $OUT/step_timeline.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_bench_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done

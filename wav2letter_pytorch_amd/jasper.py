@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from .base_asr_models import ConvCTCASR, feature_size
 from .engine import ACT_NONE, ACT_RELU, PAD_ZERO, StackEngine, UnitSpec
-from .layers import BatchNorm1d, Conv1d, conv_spec, default_precision, run_stack, solo_engine
+from .layers import BatchNorm1d, Conv1d, conv_spec, default_precision, depthwise_forward, run_stack, solo_engine
 
 jasper_activations = {
     "hardtanh": nn.Hardtanh,
@@ -105,9 +105,9 @@ class MaskedConv1d(nn.Module):
     def forward(self, x, lens):
         """(x [N, C, T], lens [N]) -> (conv(masked x), updated float lens) -- jasper.py:114-132 -- as a one-unit open engine
         with autograd; inside Jasper the model's engine runs the conv fused with its neighbours."""
-        if self.conv.groups != 1:
-            raise NotImplementedError('a stand-alone depthwise MaskedConv1d has no execution path: it runs in front of its '
-                                      'pointwise partner inside a separable JasperBlock')
+        if self.conv.groups != 1:          # depthwise half of a separable block, on its own (jasper.py:319-330)
+            out = depthwise_forward(self.conv, x, lens if self.use_mask else None)
+            return out, (self.get_seq_len(lens) if self.use_mask else lens)
         pad = self.conv.padding[0]
         eng = solo_engine(self, lambda: [UnitSpec(main=conv_spec(self.conv, None, pad, pad, PAD_ZERO, 'mconv'), src=0,
                                                    act=ACT_NONE, update_lens=self.use_mask)])

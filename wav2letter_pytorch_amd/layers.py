@@ -72,8 +72,7 @@ class Conv1d(nn.Module):
         """[N, C_in, T] -> [N, C_out, T'] fp32: the convolution alone (zero padding ``self.padding``), as a one-unit open
         engine with autograd.  Inside a model the parent's engine runs it fused with its neighbours instead."""
         if self.groups != 1:
-            raise NotImplementedError('a stand-alone grouped / depthwise Conv1d has no execution path: depthwise convs run '
-                                      'in front of their pointwise partner inside a separable JasperBlock')
+            return depthwise_forward(self, x, None)        # groups == channels; other group counts raise there
         pad = self.padding[0]
         eng = solo_engine(self, lambda: [UnitSpec(main=conv_spec(self, None, pad, pad, PAD_ZERO, 'conv'), src=0, act=ACT_NONE)])
         out, _ = run_stack(eng, x, None, self.training)
@@ -100,6 +99,66 @@ class BatchNorm1d(nn.Module):
     def forward(self, x):
         raise RuntimeError('BatchNorm1d holds parameters and running statistics only: the kernels normalise the output of '
                            'the convolution in front of it (Conv1dBlock / JasperBlock), there is no conv-less BatchNorm pass')
+
+
+class _DepthwiseFn(torch.autograd.Function):
+    """A depthwise convolution (``nn.Conv1d(C, C, k, groups=C)``, jasper.py:96-105,319-330) called on its own: the kernels
+    of csrc/dwconv.hip through the step engine's own depthwise helpers, with autograd.  Inside a separable JasperBlock the
+    model's engine runs the same kernels in front of the pointwise convolution instead."""
+
+    @staticmethod
+    def forward(ctx, x, conv, lens, weight, bias):
+        import ctypes as C
+        from . import _lib
+        from ._lib import check, lib, ptr, stream_ptr
+        from .engine import Act, padded_channels
+        _lib.require_device(x)
+        prec = getattr(conv, 'precision', None) or default_precision()
+        eng = StackEngine([], None, 0, precise=prec == 'fp32')
+        pad = conv.padding[0]
+        spec = conv_spec(conv, None, pad, pad, PAD_ZERO, 'depthwise', depthwise=True)
+        x = x.contiguous().float()
+        n, c, t = x.shape
+        cp = padded_channels(c)
+        dev = x.device
+        lens_dev = None if lens is None else lens.to(device=dev, dtype=torch.int32)
+        a_hi = torch.empty(n, t + 2 * pad, cp, dtype=torch.bfloat16, device=dev)
+        a_lo = torch.empty_like(a_hi) if eng.precise else None
+        check(lib.w2l_nct_to_ntc(ptr(x), n, c, t, cp, pad, pad, PAD_ZERO, ptr(lens_dev), ptr(a_hi), ptr(a_lo), stream_ptr()),
+              'w2l_nct_to_ntc')
+        src = Act(a_hi, a_lo, n, t, c, cp, pad, pad, PAD_ZERO, lens_dev)
+        mid = eng._dw_forward(spec, src, None)              # the output is not masked: the NEXT MaskedConv1d does that
+        out = mid.hi[:, :, :c].float()
+        if mid.lo is not None:
+            out = out + mid.lo[:, :, :c].float()
+        out = out.transpose(1, 2).contiguous()
+        if bias is not None:
+            out = out + bias.detach()[None, :, None]
+        ctx.state = (eng, spec, src, mid, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        eng, spec, src, mid, has_bias = ctx.state
+        n, c, t, cp = src.N, src.C, src.T, src.CP
+        gp = torch.zeros(n, mid.T, cp, dtype=torch.float32, device=g.device)
+        gp[:, :, :c] = g.float().transpose(1, 2)
+        grads = {}
+        gsrc = eng._dw_backward(spec, (gp, 0, 0, PAD_ZERO, mid.T), src, mid, True, grads)
+        dxp, pl, _, _, per = gsrc[:5]
+        dx = dxp.view(n, per, cp)[:, pl:pl + t, :c].float()
+        if src.lens is not None:                             # masked_fill on the input (jasper.py:116-119)
+            dx = dx * (torch.arange(t, device=dx.device)[None, :, None] < src.lens.long()[:, None, None])
+        ctx.state = None
+        return dx.transpose(1, 2).contiguous(), None, None, grads[id(spec.weight)], (g.sum((0, 2)) if has_bias else None)
+
+
+def depthwise_forward(conv: 'Conv1d', x, lens):
+    """[N, C, T] -> [N, C, T'] through the depthwise kernels; ``lens`` (optional) zeroes input frames t >= len first"""
+    if conv.groups != conv.in_channels or conv.in_channels != conv.out_channels:
+        raise NotImplementedError('grouped convolution with 1 < groups < channels is not built (not reachable from the '
+                                  'config: jasper.py:440-449 never passes groups)')
+    return _DepthwiseFn.apply(x, conv, lens, conv.weight, conv.bias)
 
 
 def conv_spec(conv: Conv1d, bn: Optional[BatchNorm1d], pad_l: int, pad_r: int, pad_mode: int, name: str = '',
