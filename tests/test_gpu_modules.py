@@ -209,7 +209,8 @@ def test_depthwise_conv_standalone(precision, tol, k, stride, dil, c):
     y, lens_out = m(xd, lens)
     gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(1))
     y.backward(gy.cuda())
-    xr = (x * (torch.arange(t)[None, None, :] < lens[:, None, None])).requires_grad_(True)
+    xin = x.clone().requires_grad_(True)
+    xr = xin * (torch.arange(t)[None, None, :] < lens[:, None, None])          # masked_fill(t >= len, 0), jasper.py:116-119
     wr = w.clone().requires_grad_(True)
     yr = F.conv1d(xr, wr, None, stride=stride, padding=pad, dilation=dil, groups=c)
     yr.backward(gy)
@@ -218,7 +219,7 @@ def test_depthwise_conv_standalone(precision, tol, k, stride, dil, c):
     assert y.shape == yr.shape and scale_err(y.detach().cpu().numpy(), yr.detach().numpy()) < tol
     gx = xd.grad.cpu() * (torch.arange(t)[None, None, :] < lens[:, None, None])
     assert torch.equal(gx, xd.grad.cpu())                                    # no gradient flows into masked frames
-    assert scale_err(gx.numpy(), xr.grad.numpy()) < tol
+    assert scale_err(gx.numpy(), xin.grad.numpy()) < tol
     assert m.conv.weight.grad.shape == (c, 1, k)
     assert scale_err(m.conv.weight.grad.cpu().numpy(), wr.grad.numpy()) < tol
     # the bare holder (no mask, with a bias)
