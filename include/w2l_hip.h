@@ -232,6 +232,10 @@ typedef struct {
     const int32_t* lens;    /* optional [N]: rows t >= lens[n] produce 0 / receive 0 gradient */
     const uint64_t* offset_dev; /* optional device word ADDED to `offset` when the mask is drawn: a step counter that lives
                                in device memory, so that a captured hipGraph of the step draws fresh masks at every replay */
+    uint64_t* q_clipped;    /* optional (w2l_bn_act_fwd_q with out_q): device counter incremented by the number of activation
+                               elements whose e4m3 copy SATURATED (|a * q_scale| > 448): the per-tensor activation scales of
+                               fp8 mode are fixed, so an unbounded activation (ReLU after a residual sum) clips silently
+                               otherwise.  NULL: not counted.  (ABI version 2) */
 } w2l_bnact_t;
 
 /* a = act(dropout(y*scale+shift [+ y2*scale2+shift2])) written to a padded buffer

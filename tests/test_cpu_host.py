@@ -26,7 +26,7 @@ def test_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(_lib.lib, name), f'{name} declared in the header but not exported'
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
-    assert _lib.lib.w2l_abi_version() == 1
+    assert _lib.lib.w2l_abi_version() == 2
 
 
 def _cfg(mid_layers=20, **kw):

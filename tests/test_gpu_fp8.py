@@ -511,3 +511,35 @@ def test_fused_sgd_keeps_the_e4m3_operands_current(overlap, rescale_every, monke
             L.check(L.lib.w2l_quantize_e4m3(L.ptr(src), 0, src.numel(), st['scale'], L.ptr(want), L.stream_ptr()))
             torch.cuda.synchronize()
             assert torch.equal(q, want), name
+
+
+def test_e4m3_activation_saturation_is_counted(L):
+    """fp8 mode's activation scales are fixed per tensor (x16 after clamp(0, 20), x8 after ReLU: |a| > 56 saturates); the
+    forward kernel counts the elements whose e4m3 copy saturated into a device word (w2l_bnact_t.q_clipped, ABI v2) so that
+    clipping is never silent: exact count over the valid frames (halo copies are not counted twice), nothing without it"""
+    import ctypes as C
+    N, T, Cc, pl, pr = 2, 40, 128, 3, 3
+    g = torch.Generator().manual_seed(9)
+    y = torch.randn(N, T, Cc, generator=g) * 30                       # ReLU outputs up to ~120: beyond 448 / 8 = 56
+    yd = y.to(torch.bfloat16).cuda()
+    one, zero = torch.ones(Cc, device='cuda'), torch.zeros(Cc, device='cuda')
+    d = L.BnActDesc()
+    d.N, d.T, d.C = N, T, Cc
+    d.y, d.y_f32 = yd.data_ptr(), 0
+    d.scale, d.shift = one.data_ptr(), zero.data_ptr()
+    d.act, d.drop_p = 2, 0.0
+    counter = torch.zeros(1, dtype=torch.int64, device='cuda')
+    d.q_clipped = counter.data_ptr()
+    R = pl + T + pr
+    hi = torch.empty(N, R, Cc, dtype=torch.bfloat16, device='cuda')
+    q = torch.empty(N, R, Cc, dtype=torch.uint8, device='cuda')
+    L.check(L.lib.w2l_bn_act_fwd_q(C.byref(d), L.ptr(hi), None, L.ptr(q), 8.0, R, pl, pr, 1, L.stream_ptr()))
+    torch.cuda.synchronize()
+    a = yd.float().clamp(min=0)
+    want = int((a > 56.0).sum())
+    assert want > 50 and int(counter) == want
+    sat = q.cpu().view(torch.float8_e4m3fn).float()[:, pl:pl + T]
+    assert int((sat == 448.0).sum()) >= want                          # those elements hold the format's largest value
+    L.check(L.lib.w2l_bn_act_fwd_q(C.byref(d), L.ptr(hi), None, L.ptr(q), 2.0, R, pl, pr, 1, L.stream_ptr()))     # x2: nothing clips
+    torch.cuda.synchronize()
+    assert int(counter) == want

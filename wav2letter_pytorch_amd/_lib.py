@@ -36,7 +36,7 @@ class BnActDesc(C.Structure):
         ('scale', c_p), ('shift', c_p), ('mean', c_p), ('invstd', c_p),
         ('y2', c_p), ('scale2', c_p), ('shift2', c_p), ('mean2', c_p), ('invstd2', c_p),
         ('act', C.c_int32), ('drop_p', c_f), ('seed', c_u64), ('offset', c_u64),
-        ('mask', c_p), ('lens', c_p), ('offset_dev', c_p),
+        ('mask', c_p), ('lens', c_p), ('offset_dev', c_p), ('q_clipped', c_p),
     ]
 
 

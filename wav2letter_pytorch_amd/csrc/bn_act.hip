@@ -158,6 +158,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(w2l_bnact_t d, bf16_raw
                                                           float inv_keep, uint8_t* out_q, float q_scale) {
     const int G = d.C >> 3;
     const unsigned total = (unsigned)d.N * R * G;            // < 2^31 (checked by the launcher): 32-bit index math
+    unsigned clipped = 0;                                    // e4m3 copy: elements beyond the format's range at this scale
+    const float q_limit = 448.f / q_scale;
     for (unsigned it = blockIdx.x * 256u + threadIdx.x; it < total; it += gridDim.x * 256u) {
         const unsigned orow = it / (unsigned)G;
         const int cg = (int)(it - orow * G);
@@ -178,7 +180,18 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(w2l_bnact_t d, bf16_raw
             for (int j = 0; j < 8; ++j) a[j] = activate(z[j], d.act);
         }
         store8_split(out_hi, out_lo, (int64_t)orow * d.C + cg * 8, a);
-        if (out_q) *reinterpret_cast<uint2*>(out_q + (int64_t)orow * d.C + cg * 8) = quant8_e4m3(a, q_scale);
+        if (out_q) {
+            *reinterpret_cast<uint2*>(out_q + (int64_t)orow * d.C + cg * 8) = quant8_e4m3(a, q_scale);
+            if (d.q_clipped && r - pad_l == t) {             // (halo copies of a frame are not counted twice)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) clipped += fabsf(a[j]) > q_limit ? 1u : 0u;
+            }
+        }
+    }
+    if (out_q && d.q_clipped && __any(clipped != 0)) {       // rare: one atomic per wave that saw any
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) clipped += __shfl_xor(clipped, m, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long*>(d.q_clipped), (unsigned long long)clipped);
     }
 }
 

@@ -26,7 +26,7 @@ hipError_t w2l_allow_big_lds(const void* kernel) {
 }
 
 extern "C" const char* w2l_last_error(void) { return g_err; }
-extern "C" int w2l_abi_version(void) { return 1; }
+extern "C" int w2l_abi_version(void) { return 2; }        // 2: w2l_bnact_t gained q_clipped
 
 // ---- tuning cache persistence (the measured block-shape / split-K choices of w2l_conv1d_*_tune) ----
 void w2l_igemm_tune_dump(FILE* f);

@@ -489,6 +489,9 @@ class StackEngine:
         # graph mode (graph.GraphedTrainStep): a uint64 step counter in device memory; dropout offsets become
         # (unit index) + counter, so a captured step draws new masks at every replay
         self.dropout_counter: Optional[torch.Tensor] = None
+        # fp8 mode: device counter of activation elements whose e4m3 copy saturated (fixed per-tensor activation scales:
+        # clamp(0, 20) outputs never do, ReLU outputs beyond 448 / 8 = 56 would) -- read on demand by fp8_saturated()
+        self._q_clipped: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------ parameters
     def parameters(self) -> List[torch.Tensor]:
@@ -584,6 +587,9 @@ class StackEngine:
             if self.fp8 and coutp % 128 == 0 and self._fp8_consumers(ui + 1):
                 out_q = torch.empty(N, opl + Tout + opr, coutp, dtype=torch.uint8, device=dev)
                 q_scale = FP8_ACT_SCALE[u.act]
+                if self._q_clipped is None or self._q_clipped.device != dev:
+                    self._q_clipped = torch.zeros(1, dtype=torch.int64, device=dev)
+                d.q_clipped = self._q_clipped.data_ptr()
             check(lib.w2l_bn_act_fwd_q(C.byref(d), ptr(out_hi), ptr(out_lo), ptr(out_q), q_scale, opl + Tout + opr, opl, opr,
                                        omode, st()), 'w2l_bn_act_fwd_q')
             uc.out_index = ui + 1
@@ -612,6 +618,16 @@ class StackEngine:
         for hook in list(AFTER_FORWARD):
             hook()
         return out, ctx
+
+    def fp8_saturated(self, reset: bool = True) -> int:
+        """fp8 mode: how many activation elements saturated the e4m3 range (|a| * scale > 448) since the last reset.
+        SYNCHRONISES (reads a device counter): call it at a logging point, not per step."""
+        if self._q_clipped is None:
+            return 0
+        n = int(self._q_clipped.item())
+        if reset and n:
+            self._q_clipped.zero_()
+        return n
 
     def _fp8_consumers(self, act_index: int) -> bool:
         """does a stride-1 dense conv of some unit read this activation (the e4m3 copy is written only then)?"""

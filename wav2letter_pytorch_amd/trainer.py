@@ -143,6 +143,12 @@ class Trainer:
                 os.makedirs(self.default_root_dir, exist_ok=True)
                 path = os.path.join(self.default_root_dir, f'epoch={epoch}-step={self.global_step}.ckpt')
                 self.save_checkpoint(path, model, optimizers, schedulers, epoch)
+            eng = getattr(model, '_engine_cache', None)
+            if eng is not None and getattr(eng[1], 'fp8', False):
+                clipped = eng[1].fp8_saturated()          # one sync per epoch
+                if clipped:
+                    self._say(f'epoch {epoch}: {clipped} activation elements saturated the e4m3 range in fp8 mode (fixed '
+                              'per-tensor activation scales, engine.FP8_ACT_SCALE): their forward operands were clipped')
             self._say(f'epoch {epoch} done in {time.time() - t0:.1f}s')
         join()
         return model
