@@ -266,7 +266,7 @@ def test_conv_wgrad_every_plan(L, Kw, s, d):
                 L.lib.w2l_wgrad_force_plan(0, -1)
     # stream-K decomposition (order bit 1): persistent blocks cut the (tile, step) space into equal ranges that straddle
     # tile boundaries (18 tiles x 18 steps over 20 blocks here); whole tiles are stored, pieces are added atomically
-    for order in (2, 3):
+    for order in (2, 3) + ((6, 7) if s == 1 and Kw > 2 else ()):          # 6, 7: the 8-wave (two tap groups) stream-K form
         L.lib.w2l_wgrad_force_plan(0, order)
         try:
             assert L.lib.w2l_wgrad_needs_zero(N, Cin, Cout, Tout, Kw) == 1

@@ -95,7 +95,7 @@ def main():
 
         if args.wgrad_plans:
             res = []
-            for order in (0, 1, 4, 5, 8, 9, 2, 3):          # bit 0 block order, bit 2 two tap groups, bit 3 32x32x16 MFMA, bit 1 stream-K
+            for order in (0, 1, 4, 5, 8, 9, 2, 3, 6, 7):    # bit 0 block order, 2 two tap groups, 3 32x32x16 MFMA, 1 stream-K (6, 7: both)
                 best = (float('inf'), 0)
                 for sp in ((1,) if order & 2 else (1, 2, 3, 4, 5, 6, 8, 10, 12, 16)):
                     L.lib.w2l_wgrad_force_plan(sp, order)

@@ -21,6 +21,19 @@
 #include <mutex>
 #include <tuple>
 
+// Diagnostic build only (-DW2L_STAMP, never shipped): where a K step of the 16x16x32 two-tap kernel spends its cycles, per wave.
+// s_memtime stamps around the step's segments, summed in scalar registers, stored once per wave after the loop into a
+// buffer nothing else reads (MI355X guide, "In-kernel stamps").  tools/stamp_wgrad.py builds, runs and prints the shares.
+#ifdef W2L_STAMP
+__device__ unsigned long long g_wgrad_stamps[8 * 8192];
+#define W2L_STAMP_AT(var)                                                                            \
+    do {                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+    } while (0)
+#endif
+
 namespace {
 
 constexpr int BM = 128;       // co per block
@@ -298,6 +311,9 @@ __global__ __launch_bounds__(256 * TG, TG == 1 ? 2 : 1) void conv_wgrad_kernel(W
     //    fragments of step+1 are requested from the other buffers, and all of it hides behind the last 16 MFMAs.
     // NT / LAST are compile-time so that each body is straight-line code with in-place accumulators (the compiler
     // does not move reads across a branch).
+#ifdef W2L_STAMP
+    unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0;
+#endif
     bf16x8 a[4], b[2][4];
     auto load_a1 = [&](int i, int ks) {
 #pragma unroll
@@ -352,10 +368,29 @@ __global__ __launch_bounds__(256 * TG, TG == 1 ? 2 : 1) void conv_wgrad_kernel(W
             const int ks2 = (g + 1) / NT, tp2 = (g + 1) % NT;
             if (!lastg) load_b(b[(g + 1) & 1], tp2, ks2);
             if (lastg && !LAST) {
+#ifdef W2L_STAMP
+                unsigned long long t0, t1, t2, t3;
+                W2L_STAMP_AT(t0);
+                st_sum[0] += t0 - st_prev;                          // groups 0 .. NG-2: fragment reads + MFMAs
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step+1's tiles (this wave's part) have landed
+#ifdef W2L_STAMP
+                W2L_STAMP_AT(t1);
+                st_sum[1] += t1 - t0;                               // waiting for this wave's LDS-DMA
+#endif
                 __syncthreads();                                    // ... everyone's; and nobody reads this step's buffers any more
+#ifdef W2L_STAMP
+                W2L_STAMP_AT(t2);
+                st_sum[2] += t2 - t1;                               // the block barrier
+#endif
                 toggle();                                           // read pointers -> step+1's buffers
                 if (have_nn) stage(adst, bdst, n_nn, ts_nn);        // step+2 -> this step's buffers
+#ifdef W2L_STAMP
+                W2L_STAMP_AT(t3);
+                st_sum[3] += t3 - t2;                               // pointer toggles + issuing the LDS-DMA pieces
+                st_prev = t3;
+                st_sum[5] += 1;
+#endif
                 load_b(b[(g + 1) & 1], 0, 0);
             }
 #pragma unroll
@@ -437,6 +472,9 @@ __global__ __launch_bounds__(256 * TG, TG == 1 ? 2 : 1) void conv_wgrad_kernel(W
             for (int i = 0; i < 4; ++i) load_a1(i, 0);
             load_b(b[0], 0, 0);
         }
+#ifdef W2L_STAMP
+        W2L_STAMP_AT(st_prev);
+#endif
         for (int step = step_begin; step + 1 < step_end; ++step) {
             const int par = (step - step_begin) & 1;
             advance(n, ts);                               // now step+2
@@ -492,6 +530,15 @@ __global__ __launch_bounds__(256 * TG, TG == 1 ? 2 : 1) void conv_wgrad_kernel(W
     if (TG > 1 && ntaps == 0) run_idle();
     else if (KWB == 1 || ntaps == KWB) run(std::integral_constant<int, KWB>{});
     else run(std::integral_constant<int, 1>{});
+#ifdef W2L_STAMP
+    if (lane == 0) {
+        const int slot = (blockIdx.y * gridDim.x + blockIdx.x) * NWV + wave_all;
+        if (slot < 8192) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) g_wgrad_stamps[slot * 8 + i] = st_sum[i];
+        }
+    }
+#endif
     // the read pointers were toggled once per non-last step: bring them back to buffer 0 for a following segment
     if (step_end > step_begin && ((step_end - step_begin - 1) & 1)) toggle();
     // a piece of a tile (stream-K) is added atomically; a tile this block covered completely is stored
@@ -715,7 +762,7 @@ extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const voi
     // stream-K is the atomic path's alternative to split-K: with a workspace (deterministic slabs) the classic plan runs
     p.streamk = (order & kStreamK) && ws == nullptr ? 1 : 0;
     if (p.streamk) splits = 1;
-    const bool tg2 = (order & kTapGroups2) && !p.streamk && Kw > 2;
+    const bool tg2 = (order & kTapGroups2) && Kw > 2;      // (with stream-K: 256 persistent 8-wave blocks, one per CU)
     const bool m32 = (order & kMfma32) && !p.streamk && !tg2 && stride == 1;
     p.total_steps = N * p.tsteps;
     p.steps_per_split = (p.total_steps + splits - 1) / splits;
@@ -738,7 +785,8 @@ extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const voi
         const int64_t W = (int64_t)grid.x * p.total_steps;
         W2L_CHECK_ARG(W < (1LL << 31), "conv1d_wgrad: (tile, step) space exceeds 32 bits");
         int64_t g = W / 16;
-        if (g > kResidentBlocks) g = kResidentBlocks;
+        const int64_t resident = tg2 ? kResidentBlocks / 2 : kResidentBlocks;
+        if (g > resident) g = resident;
         if (g < 1) g = 1;
         grid = dim3((unsigned)g, 1);
     }
@@ -755,6 +803,10 @@ extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const voi
             W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<1, true, false, 1, true>));
             hipLaunchKernelGGL((conv_wgrad_kernel<1, true, false, 1, true>), grid, block, lds, (hipStream_t)stream, p);
         }
+    } else if (tg2 && p.streamk) {
+        W2L_CHECK_ARG(stride == 1, "conv1d_wgrad: the stream-K form of the 8-wave kernel is built for stride 1");
+        W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<2, true, true, 2>));
+        hipLaunchKernelGGL((conv_wgrad_kernel<2, true, true, 2>), grid, block, lds, (hipStream_t)stream, p);
     } else if (tg2) {
         if (stride == 1) {
             W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<2, true, false, 2>));
@@ -808,13 +860,15 @@ extern "C" int w2l_conv1d_wgrad_tune_ws(const void* dy, int64_t dy_bstride, cons
     for (int vi = 0; vi < 3; ++vi) {
     const int tgbit = variants[vi];
     if ((tgbit == kTapGroups2 && Kw <= 2) || (tgbit == kMfma32 && stride != 1)) continue;
-    for (int ci = tgbit ? 0 : -2; ci < ncand; ++ci) {
+    const bool has_sk = tgbit == 0 || (tgbit == kTapGroups2 && stride == 1);
+    for (int ci = has_sk ? -2 : 0; ci < ncand; ++ci) {
         // ci = -2, -1: the stream-K decomposition in both block orders (no workspace form: skipped in deterministic mode);
-        // tgbit: the same split counts and block orders once more with two tap groups per block (the 8-wave kernel), and
+        // tgbit: the same split counts and block orders once more with two tap groups per block (the 8-wave kernel: classic and
+        // stream-K -- 256 persistent blocks, the balanced form of a kernel whose 1-block-per-CU tiles quantise badly), and
         // once more with 32x32x16 MFMA fragments
         const bool sk = ci < 0;
         if (sk && ws != nullptr) continue;
-        const int s = sk ? 1 : cands[ci >> 1], order = sk ? (kStreamK | (ci & 1)) : ((ci & 1) | tgbit);
+        const int s = sk ? 1 : cands[ci >> 1], order = sk ? (kStreamK | (ci & 1) | tgbit) : ((ci & 1) | tgbit);
         if (!sk && (s > total || s > 0xffff || (s > 1 && total / s < 4))) break;
         g_force_splits = s;
         g_force_order = order;
@@ -852,6 +906,15 @@ extern "C" int w2l_conv1d_wgrad_tune(const void* dy, int64_t dy_bstride, const v
                                     reps, nullptr, 0, stream);
 }
 
+#ifdef W2L_STAMP
+// diagnostic build: copy the per-wave stamp sums out (8 words per wave: five segments' cycle sums, the step count, 2 spare)
+extern "C" int w2l_wgrad_read_stamps(unsigned long long* dst, int nwords) {
+    const size_t n = (size_t)(nwords < 8 * 8192 ? nwords : 8 * 8192) * sizeof(unsigned long long);
+    W2L_CHECK_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wgrad_stamps), n));
+    return 0;
+}
+#endif
+
 // Tuning-cache (de)serialisation used by w2l_tune_save / w2l_tune_load (runtime.hip).
 void w2l_wgrad_tune_dump(FILE* f) {
     std::lock_guard<std::mutex> lock(g_wtuned_mu);
@@ -863,8 +926,7 @@ void w2l_wgrad_tune_dump(FILE* f) {
 }
 
 bool w2l_wgrad_tune_put(const int* v) {          // v[0..4] = key, v[5] = split count, v[6] = block order
-    if (v[5] < 1 || v[5] > 0xffff || v[0] < 1 || v[3] < 1 || v[6] < 0 || v[6] > 15 || (v[6] & 6) == 6 ||
-        ((v[6] & 8) && (v[6] & 6))) return false;
+    if (v[5] < 1 || v[5] > 0xffff || v[0] < 1 || v[3] < 1 || v[6] < 0 || v[6] > 15 || ((v[6] & 8) && (v[6] & 6))) return false;
     const int ts = (v[3] + BT - 1) / BT;
     if ((int64_t)v[5] > (int64_t)v[0] * ts) return false;
     std::lock_guard<std::mutex> lock(g_wtuned_mu);
