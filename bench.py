@@ -213,6 +213,12 @@ def main():
     if L.under_launcher() and int(os.environ['WORLD_SIZE']) != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} inside a {os.environ['WORLD_SIZE']}-rank launch: the two must agree")
 
+    # stdout carries exactly ONE line, the JSON record: libraries that print there (RCCL's version banner on the first
+    # communicator, for one) are sent to stderr for the life of the run, and the record goes to the saved descriptor
+    sys.stdout.flush()
+    record_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from wav2letter_pytorch_amd import Jasper, Wav2Letter, engine as E
     from wav2letter_pytorch_amd.distributed import GradReducer, NativeComm, broadcast_parameters, init_process_group_from_env
     import torch.distributed as dist
@@ -604,7 +610,8 @@ def main():
                            {'shared_from_rank0': tune_path, 'sha16_by_rank': tune_shas, 'identical': len(set(tune_shas)) == 1}),
             'per_gpu_value': round(value / world, 1),
         }
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(record_fd, (json.dumps(line) + '\n').encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
