@@ -317,7 +317,7 @@ def test_w2l_full_table_fp8_gradients_vs_oracle():
     for k in wkeys[:-1]:
         (l2m, cosm), (l2f, cosf), (l2a, cosa) = vs['e4m3_model'][k], vs['fp32'][k], arith[k]
         assert l2m <= 1.25 * l2a + 0.05, (k, l2m, l2a)
-        assert cosm >= cosa - 0.1 and cosf >= cosa - 0.1 and min(cosm, cosf) > 0.5, (k, cosm, cosf, cosa)
+        assert cosm >= cosa - 0.15 and cosf >= cosa - 0.15 and min(cosm, cosf) > 0.45, (k, cosm, cosf, cosa)
 
 
 def test_fp8_training_tracks_bf16():

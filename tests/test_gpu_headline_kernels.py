@@ -13,8 +13,8 @@ block order MEASURED by the tuner exactly as in the bench's warm-up step:
 
 against a float64 evaluation of the same bf16-rounded operands (per-tap matrix products in torch float64 on the device:
 14.7 TFLOP of float64 is minutes on the host cores, a second on the GPU; a slice of each result is re-derived on the CPU so
-the reference itself is cross-checked).  Bounds: fp32 results within 1e-4 of the tensor scale (measured ~1e-6: fp32
-accumulation over K <= 25 984), bf16-stored results within half a bf16 ulp (at most 2^-8 of the value) of the float64 value plus that 1e-4."""
+the reference itself is cross-checked).  Bounds: fp32 results within 2e-5 of the tensor scale (measured 2e-7 .. 3e-6: fp32
+accumulation over K <= 25 984), bf16-stored results within half a bf16 ulp (at most 2^-8 of the value) of the float64 value plus 1e-4 of scale."""
 import ctypes as C
 
 import pytest
@@ -83,6 +83,7 @@ def test_headline_layer_kernels_exact(L, shape):
     xd = x.cuda()
     x64, w64 = xd.double(), w.cuda().double()
     st = L.stream_ptr()
+    worst = {}
     bd = torch.zeros(coutp, device='cuda')
     bd[:cout] = bias.cuda()
 
@@ -107,7 +108,8 @@ def test_headline_layer_kernels_exact(L, shape):
         got = y[:, :, :cout].double()
         scale = float(ref.abs().max())
         if f32:
-            assert _err(got, ref) < 1e-4, ('forward fp32 store', _err(got, ref))
+            worst['fwd'] = _err(got, ref)
+            assert worst['fwd'] < 2e-5, ('forward fp32 store', worst['fwd'])
         else:
             slack = (got - ref).abs() - (2.0 ** -8 * 1.01) * ref.abs() - 1e-4 * scale
             assert float(slack.max()) <= 0, ('forward bf16 store', float(slack.max()) / scale)
@@ -141,13 +143,15 @@ def test_headline_layer_kernels_exact(L, shape):
     dw = torch.zeros(kw, coutp, cin, device='cuda') if zero else torch.full((kw, coutp, cin), float('nan'), device='cuda')
     L.check(L.lib.w2l_conv1d_wgrad_ws(*wargs, L.ptr(dw), *wdims, 0, None, 0, st))
     torch.cuda.synchronize()
-    assert _err(dw[:, :cout].double(), refw) < 1e-4, ('weight gradient', _err(dw[:, :cout].double(), refw))
+    worst['wgrad'] = _err(dw[:, :cout].double(), refw)
+    assert worst['wgrad'] < 2e-5, ('weight gradient', worst['wgrad'])
     if coutp > cout:
         assert not bool(dw[:, cout:].abs().max() > 0)
     del refw, dw, scratch
 
     # ---------------------------------------------------------------- data gradient (stride-1 layers; layer 0 has none in training)
     if stride != 1:
+        print(f'  {cin}->{cout} k{kw}: forward {worst["fwd"]:.1e}, weight gradient {worst["wgrad"]:.1e} of scale')
         return
     tp = TOUT + hb
     # dx[n, t', ci] = sum_k sum_co dy[n, t' - k*d, co] w[co, ci, k], t' in padded-input coordinates
@@ -172,7 +176,10 @@ def test_headline_layer_kernels_exact(L, shape):
         torch.cuda.synchronize()
         got = dx.view(N, per, cin)[:, :tp].double()
         if f32:
-            assert _err(got, refx) < 1e-4, ('data gradient fp32 store', _err(got, refx))
+            worst['dgrad'] = _err(got, refx)
+            assert worst['dgrad'] < 2e-5, ('data gradient fp32 store', worst['dgrad'])
         else:
             slack = (got - refx).abs() - (2.0 ** -8 * 1.01) * refx.abs() - 1e-4 * scale
             assert float(slack.max()) <= 0, ('data gradient bf16 store', float(slack.max()) / scale)
+    print(f'  {cin}->{cout} k{kw} d{dil}: forward {worst["fwd"]:.1e}, data gradient {worst["dgrad"]:.1e}, weight gradient '
+          f'{worst["wgrad"]:.1e} of scale (fp32 stores)')
