@@ -1,6 +1,7 @@
 #!/bin/bash
 # Regenerates the artefacts committed under profiles/ (run through gpurun; outputs land in gpurun_out/final/ and are then
-# copied into profiles/ with the round prefix by hand: `for f in gpurun_out/final/*; do cp $f profiles/r03_$(basename $f); done`).
+# copied into profiles/ with the round prefix by hand -- delete the local gpurun_out/final first (gpurun MERGES: files of older
+# runs stay there): `rm -rf gpurun_out/final; gpurun ... bash tools/make_profiles.sh; for f in gpurun_out/final/*; do cp $f profiles/r03_$(basename $f); done`).
 # Stages are independent: a failing one leaves its file empty, the others still run.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/final
