@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 const char* w2l_last_error(void);
-int w2l_abi_version(void);
+int w2l_abi_version(void);            /* 2 (1 -> 2: w2l_bnact_t gained the trailing field q_clipped) */
 
 /* ---- layout / packing ---------------------------------------------------- */
 
