@@ -262,7 +262,7 @@ def test_tune_cache_roundtrip(tmp_path):
     """w2l_tune_save / w2l_tune_load: host-only persistence of the measured block-shape / split-K choices."""
     from wav2letter_pytorch_amd import _lib as L
     src = tmp_path / 'in.txt'
-    src.write_text('w2l-tune v1 gfx950\n'
+    src.write_text('w2l-tune v2 gfx950\n'
                    'igemm 7 640 768 1000 21 1 1 1 15\n'
                    'igemm 7 640 768 1000 21 1 1 1 999\n'     # unknown configuration: skipped
                    'igemm 7 640 768 500 21 2 1 0 15\n'       # stride 2 only runs on shape 2: skipped
@@ -277,7 +277,7 @@ def test_tune_cache_roundtrip(tmp_path):
     out = tmp_path / 'out.txt'
     assert L.lib.w2l_tune_save(str(out).encode()) == 0
     lines = out.read_text().splitlines()
-    assert lines[0] == 'w2l-tune v1 gfx950'
+    assert lines[0] == 'w2l-tune v2 gfx950'
     assert 'igemm 7 640 768 1000 21 1 1 1 15' in lines and 'wgrad 7 640 768 1000 21 3 1' in lines
     assert 'wgradf8 7 640 768 1000 21 5 1' in lines and 'igemmf8 7 640 768 1000 21 1 1 1 3' in lines
     assert not any(' 99' in ln or ' 999' in ln for ln in lines)
@@ -286,6 +286,9 @@ def test_tune_cache_roundtrip(tmp_path):
     bad = tmp_path / 'bad.txt'
     bad.write_text('something else\n')
     assert L.lib.w2l_tune_load(str(bad).encode()) == -1
+    old = tmp_path / 'old.txt'              # a cache of the previous format (other configuration indices) is refused whole
+    old.write_text('w2l-tune v1 gfx950\nigemm 7 640 768 1000 21 1 1 1 15\n')
+    assert L.lib.w2l_tune_load(str(old).encode()) == -1
 
 
 def test_data_loader_host_side(tmp_path):

@@ -176,9 +176,9 @@ def test_conv_igemm_every_configuration(L, with_stats):
         r1, r2 = ref.sum((0, 2)), (ref * ref).sum((0, 2))
         tiles = L.lib.w2l_conv_stat_tiles(N, Tout)
         ws = torch.zeros(int(L.lib.w2l_conv_splitk_workspace_bytes(N, coutp, Tout)), dtype=torch.uint8, device='cuda')
-        for idx in range(42 * 7):
+        for idx in range(52 * 7):                        # (26 block shapes x 2 K-loop structures) x 7 split options
             outs = []
-            for rep in range(2 if idx >= 42 else 1):
+            for rep in range(2 if idx >= 52 else 1):
                 y = torch.full((N, Tout, coutp), float('nan'), dtype=torch.bfloat16, device='cuda')
                 stats = torch.zeros(tiles, 2, coutp, device='cuda')
                 L.lib.w2l_conv_force_tile_config(idx)
@@ -195,7 +195,7 @@ def test_conv_igemm_every_configuration(L, with_stats):
             if not outs:
                 continue
             ran += 1
-            split_ran += idx >= 42
+            split_ran += idx >= 52
             y, stats = outs[0]
             got = y.float().cpu().transpose(1, 2)
             assert torch.isfinite(got).all(), idx

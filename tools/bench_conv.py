@@ -115,7 +115,7 @@ def main():
             print('      ' + ' | '.join(res))
         if args.sweep:
             res = []
-            for ci in range(21):
+            for ci in range(26):
                 L.lib.w2l_conv_force_tile_config(ci)
                 try:
                     a = timeit(fwd, args.reps)

@@ -546,13 +546,19 @@ constexpr TileCfg kCfgs[] = {
     {2, 4, 2, 4, 0.85f}, {2, 4, 3, 4, 0.97f}, {2, 4, 4, 4, 1.00f}, {2, 4, 5, 4, 1.04f},   // BN 256, 8 waves, 1 block/CU
     {2, 4, 6, 4, 1.10f}, {2, 4, 7, 4, 1.06f}, {2, 4, 8, 4, 1.12f},
     {2, 3, 4, 6, 1.00f}, {2, 3, 5, 6, 1.00f}, {2, 3, 6, 6, 1.00f}, {2, 3, 7, 6, 1.00f},   // BN 288, 6 waves, 1 block/CU
+    // BN 384, 8 waves (round 3): a weight tile serves 384 columns instead of 256 -- a third less LDS-DMA per MFMA, the
+    // instruction a K step spends a third of its issue time on (in-kernel stamps).  Useful where the column count
+    // tiles well: the flat data gradients of the 640-wide layers +12-14 %, 768-wide +1-4 %; never the per-utterance forward
+    // pass (500 columns = 2 tiles of 384)
+    {2, 4, 4, 6, 1.00f}, {2, 4, 5, 6, 1.00f}, {2, 4, 6, 6, 1.00f},
+    {2, 4, 4, 7, 1.00f}, {2, 4, 5, 7, 1.00f},                                               // BN 448, 8 waves
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 template <int MW, int NW, int MS, int NS, int PIPE>
 int launch_cfg1(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream, int epi = 0) {
     if (epi == 1) {
-        if constexpr ((16 * NW * NS) % 128 == 0) {        // statistics rows are per 128-column tile
+        if constexpr ((16 * NW * NS) % 128 == 0 && 16 * NW * NS <= 256) {        // statistics rows are per 128-column tile
             auto kern1 = conv_igemm_kernel<MW, NW, MS, NS, 1, PIPE, false, 1>;
             W2L_CHECK_HIP(w2l_allow_big_lds((const void*)kern1));
             hipLaunchKernelGGL(kern1, dim3(tiles_m * p.ncols), dim3(64 * MW * NW), lds, stream, p);
@@ -589,7 +595,8 @@ int launch_cfg(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream
 }
 
 // e4m3 launches: K-loop structure 0, stride 1, a subset of the block shapes (indices into kCfgs)
-constexpr int kF8Cfgs[] = {2, 5, 12, 14, 16, 1, 3, 8, 9, 11, 13, 18, 19};     // (the first five were round 2's first set)
+constexpr int kF8Cfgs[] = {2, 5, 12, 14, 16, 1, 3, 8, 9, 11, 13, 18, 19, 21, 24};     // (the first five were round 2's first set;
+                                                                              //  21 / 24: the 384- / 448-column shapes, round 3)
 constexpr int kNumF8Cfgs = sizeof(kF8Cfgs) / sizeof(kF8Cfgs[0]);
 
 template <int MW, int NW, int MS, int NS>
@@ -628,7 +635,7 @@ static bool cfg_feasible(int idx, int Kw, int stride, int dil, bool need_bn128) 
     const int i = idx % kNumCfgs;
     const TileCfg& c = kCfgs[i];
     const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
-    if (need_bn128 && bn % 128 != 0) return false;
+    if (need_bn128 && (bn % 128 != 0 || bn > 256)) return false;   // the statistics epilogue assumes whole waves per 128-column tile
     if (stride != 1 && i != 2) return false;
     if (i == 20) return false;                               // spills (kept only for index stability)
     const size_t lds = 2 * (size_t)bm * ROWB + 2 * (size_t)cfg_xrows(c, stride, Kw, dil) * ROWB;
@@ -649,7 +656,7 @@ static int choose_cfg(int N, int Cin, int Cout, int Tout, int Kw, int stride, in
     for (int i = 0; i < kNumCfgs; ++i) {
         const TileCfg& c = kCfgs[i];
         const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
-        if (need_bn128 && bn % 128 != 0) continue;     // BatchNorm partial statistics are per 128-column tile
+        if (need_bn128 && (bn % 128 != 0 || bn > 256)) continue;     // BatchNorm partial statistics are per 128-column tile
         if (stride != 1 && i != 2) continue;          // strided convs (first layer only) use the 128x128 shape
         if (i == 20) continue;
         const size_t lds = 2 * (size_t)bm * ROWB + 2 * (size_t)cfg_xrows(c, stride, Kw, dil) * ROWB;
@@ -798,7 +805,12 @@ static int igemm_launch(const void* xp, int64_t x_bstride, int64_t x_rows_total,
         case 17: return launch_cfg<2, 3, 4, 6>(p, tiles_m, lds, st, pipe, epi);
         case 18: return launch_cfg<2, 3, 5, 6>(p, tiles_m, lds, st, pipe, epi);
         case 19: return launch_cfg<2, 3, 6, 6>(p, tiles_m, lds, st, pipe, epi);
-        default: return launch_cfg<2, 3, 7, 6>(p, tiles_m, lds, st, pipe, epi);
+        case 20: return launch_cfg<2, 3, 7, 6>(p, tiles_m, lds, st, pipe, epi);
+        case 21: return launch_cfg<2, 4, 4, 6>(p, tiles_m, lds, st, pipe, epi);
+        case 22: return launch_cfg<2, 4, 5, 6>(p, tiles_m, lds, st, pipe, epi);
+        case 23: return launch_cfg<2, 4, 6, 6>(p, tiles_m, lds, st, pipe, epi);
+        case 24: return launch_cfg<2, 4, 4, 7>(p, tiles_m, lds, st, pipe, epi);
+        default: return launch_cfg<2, 4, 5, 7>(p, tiles_m, lds, st, pipe, epi);
     }
 }
 
@@ -921,7 +933,7 @@ extern "C" void w2l_conv_force_fp8_config(int idx) { g_force_f8 = idx; }
 static bool f8_feasible(int k, int Kw, int dil, bool need_bn128) {
     if (k < 0 || k >= kNumF8Cfgs) return false;
     const TileCfg& c = kCfgs[kF8Cfgs[k]];
-    if (need_bn128 && (16 * c.nw * c.ns) % 128 != 0) return false;
+    if (need_bn128 && ((16 * c.nw * c.ns) % 128 != 0 || 16 * c.nw * c.ns > 256)) return false;
     const size_t lds = 2 * (size_t)(16 * c.mw * c.ms) * ROWB + 2 * (size_t)cfg_xrows(c, 1, Kw, dil) * ROWB;
     return lds <= 160 * 1024;
 }
@@ -999,7 +1011,9 @@ extern "C" int w2l_conv1d_igemm_fp8(const void* xq, int64_t x_bstride, int64_t x
         case 11: return launch_f8<2, 4, 3, 4>(p, tiles_m, lds, st);
         case 13: return launch_f8<2, 4, 5, 4>(p, tiles_m, lds, st);
         case 18: return launch_f8<2, 3, 5, 6>(p, tiles_m, lds, st);
-        default: return launch_f8<2, 3, 6, 6>(p, tiles_m, lds, st);
+        case 19: return launch_f8<2, 3, 6, 6>(p, tiles_m, lds, st);
+        case 21: return launch_f8<2, 4, 4, 6>(p, tiles_m, lds, st);
+        default: return launch_f8<2, 4, 4, 7>(p, tiles_m, lds, st);
     }
 }
 

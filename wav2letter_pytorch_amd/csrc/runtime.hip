@@ -37,7 +37,7 @@ void w2l_wgrad_fp8_tune_dump(FILE* f);
 void w2l_igemm_fp8_tune_dump(FILE* f);
 bool w2l_igemm_fp8_tune_put(const int* v);
 bool w2l_wgrad_fp8_tune_put(const int* v);
-static const char kTuneHeader[] = "w2l-tune v1 gfx950";
+static const char kTuneHeader[] = "w2l-tune v2 gfx950";      // v2: 26 implicit-GEMM block shapes (configuration indices moved)
 
 extern "C" int w2l_tune_save(const char* path) {
     W2L_CHECK_ARG(path != nullptr, "tune_save: null path");
