@@ -36,6 +36,8 @@ def main():
     ap.add_argument('--n', type=int, default=32)
     ap.add_argument('--t', type=int, default=1000)
     ap.add_argument('--sweep', action='store_true', help='time every igemm block-shape candidate per layer')
+    ap.add_argument('--sweep-cfgs', default='', help='with --sweep: comma-separated configuration indices instead of the 26 PIPE=0 shapes '
+                                                     '(index + 26 = the PIPE=1 loop of the same shape)')
     ap.add_argument('--deterministic', action='store_true', help='weight gradients through slabs + ticket (W2L_DETERMINISTIC=1 path)')
     ap.add_argument('--no-splitk', action='store_true', help='with --tune: measure without the split-K configurations')
     ap.add_argument('--wgrad-plans', action='store_true',
@@ -115,7 +117,7 @@ def main():
             print('      ' + ' | '.join(res))
         if args.sweep:
             res = []
-            for ci in range(26):
+            for ci in ([int(v) for v in args.sweep_cfgs.split(',')] if args.sweep_cfgs else range(26)):
                 L.lib.w2l_conv_force_tile_config(ci)
                 try:
                     a = timeit(fwd, args.reps)
