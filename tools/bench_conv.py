@@ -17,9 +17,19 @@ TABLE = ([(64, 256, 11, 2, 1)] + [(256, 256, 11, 1, 1)] * 3 + [(256, 384, 13, 1,
          + [(896, 1024, 1, 1, 1), (1024, 64, 1, 1, 1)])
 
 
+WARM_S = 0.0
+
+
 def timeit(fn, reps):
     for _ in range(3):
         fn()
+    if WARM_S > 0:                      # hold the launch for a while first: the chip settles at the clock it sustains
+        import time
+        t0 = time.time()
+        while time.time() - t0 < WARM_S:
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(reps):
@@ -38,6 +48,7 @@ def main():
     ap.add_argument('--sweep', action='store_true', help='time every igemm block-shape candidate per layer')
     ap.add_argument('--sweep-cfgs', default='', help='with --sweep: comma-separated configuration indices instead of the 26 PIPE=0 shapes '
                                                      '(index + 26 = the PIPE=1 loop of the same shape)')
+    ap.add_argument('--warm-s', type=float, default=0.0, help='seconds of back-to-back launches before every timing')
     ap.add_argument('--deterministic', action='store_true', help='weight gradients through slabs + ticket (W2L_DETERMINISTIC=1 path)')
     ap.add_argument('--no-splitk', action='store_true', help='with --tune: measure without the split-K configurations')
     ap.add_argument('--wgrad-plans', action='store_true',
@@ -45,6 +56,8 @@ def main():
     ap.add_argument('--fp8', action='store_true', help='also time the e4m3 weight-gradient kernel (w2l_conv1d_wgrad_fp8) on each layer')
     ap.add_argument('--tune', action='store_true', help='let the library measure and pick its configurations first')
     args = ap.parse_args()
+    global WARM_S
+    WARM_S = args.warm_s
     N = args.n
     uniq = []
     for sh in TABLE:
