@@ -158,6 +158,64 @@ def test_w2l_full_table_N32_bench_workload_bf16():
         assert l2 <= BF16_N32_GRAD_L2 and cos >= BF16_N32_GRAD_COS, (k, l2, cos)
 
 
+def test_w2l_full_table_bf16_vs_operand_model():
+    """WHERE the bf16 mode's distance from the fp32 oracle comes from.  The 21-layer table at N=8 x T=1000, dropout on, one
+    device step; its masks and clamp gates replayed through (a) the fp32 oracle and (b) the oracle's bf16 OPERAND MODEL
+    (oracle.bf16_conv1d + conv1d_block_forward(stats_before_rounding): bf16 operands, fp32 accumulation, BatchNorm statistics
+    from the accumulators, every stored tensor -- y, activation, dy, dx -- rounded to bf16: the places where the engine
+    rounds, and nothing else of it; the order of the fp32 sums is the one thing it does not share with the kernels).
+    Asserted:
+      * the device's stored activations are BIT-IDENTICAL to the model's for the first layer (>= 99.9 % of the elements; measured
+        100.00 %), >= 99 % / 96 % for the next two (99.87-99.88 / 98.8-99.0): the kernels round where the model says and nowhere else.
+        From there the two part ways one bf16 ulp at a time -- an element whose accumulator differs in the last fp32 bits rounds
+        the other way, and every such flip seeds more in the next layer (95 %, 87 %, ... ~70 % = the zeros);
+      * so three evaluations that agree on the ARITHMETIC still differ in the gradients: per tensor, device vs model
+        0.045-0.062 in relative L2 (cosine 0.998-0.999), model vs fp32 -- CPU only, no device involved -- 0.072-0.10, device vs
+        fp32 0.075-0.104.  The device must be closer to the model than the model is to fp32 (<= 0.8 x), and no further
+        from fp32 than the model is (<= 1.15 x + 0.005): the distance the fp32 comparisons of this file see is what storing
+        bf16 tensors costs, the device adds nothing to it."""
+    from oracle import w2l_oracle as O
+    layers = _w2l_table(True)
+    sd = O.init_wav2letter_state(layers, seed=0)
+    model = build_w2l(layers, sd, 'bf16', dropout=True).train()
+    x, il, tg, tl = O.synthetic_batch(8, 1000, seed=77)
+    out, out_lens, loss, ectx = device_step(model, x, il, tg, tl)
+    masks = device_dropout_masks(ectx, [l[0] for l in layers])
+    gates = device_gates(ectx)
+    acts = []
+    for i in range(4):
+        a = ectx['acts'][i + 1]
+        acts.append(a.hi[:, a.pad_l:a.pad_l + a.T, :a.C].float().transpose(1, 2).cpu())
+    del ectx
+    got = {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}
+    ref = {name: O.wav2letter_step(x, il, tg, tl, {k: v.clone() for k, v in sd.items()}, layers, drop_masks=masks, gates=gates,
+                                   bf16_model=flag) for name, flag in (('fp32', False), ('bf16_model', True))}
+    same = [float((a == r.to(torch.bfloat16).float()).float().mean()) for a, r in zip(acts, ref['bf16_model']['activations'])]
+    print('bf16 full table N=8: stored activations bit-identical to the operand model, layers 0-3: '
+          + ' '.join(f'{v:.4f}' for v in same))
+    assert same[0] >= 0.999 and same[1] >= 0.99 and same[2] >= 0.96, same
+    keys = [k for k in got if not (k.endswith('conv1.bias') and not k.startswith('conv1ds.conv1d_20.'))]
+    vs = {name: {k: l2_cos(got[k], r['grads'][k].numpy()) for k in keys} for name, r in ref.items()}
+    arith = {k: l2_cos(ref['bf16_model']['grads'][k].numpy(), ref['fp32']['grads'][k].numpy()) for k in keys}
+
+    def row(d):
+        return ' '.join(f'{i}:{d[f"conv1ds.conv1d_{i}.conv1.weight"][0]:.4f}/{d[f"conv1ds.conv1d_{i}.conv1.weight"][1]:.5f}'
+                        for i in range(21))
+    for title, d in (('device vs the bf16 operand model', vs['bf16_model']), ('device vs fp32', vs['fp32']),
+                     ('the bf16 operand model vs fp32 (CPU only)', arith)):
+        print(f'bf16 full table N=8, {title}: weight-gradient L2 / cosine by layer: {row(d)}')
+        print('   worst over all tensors: L2 %.4f  cosine %.5f' % (max(v[0] for v in d.values()), min(v[1] for v in d.values())))
+    for name, r, lp_bound in (('fp32', ref['fp32'], 5e-2), ('bf16_model', ref['bf16_model'], 3e-2)):
+        e_loss = abs(float(loss) - float(r['loss'])) / abs(float(r['loss']))
+        e_lp = scale_err(out.cpu().numpy(), r['log_probs'].numpy())
+        print(f'  vs {name}: loss {e_loss:.2e} log-probs {e_lp:.2e}')
+        assert e_loss < 1e-3 and e_lp < lp_bound, (name, e_loss, e_lp)
+    for k in keys:
+        (l2m, cosm), (l2f, cosf), (l2a, cosa) = vs['bf16_model'][k], vs['fp32'][k], arith[k]
+        assert l2m <= 0.8 * l2a + 1e-3 and cosm >= cosa, (k, l2m, l2a, cosm, cosa)
+        assert l2f <= 1.15 * l2a + 5e-3, (k, l2f, l2a)
+
+
 def _jasper10x5():
     from wav2letter_pytorch_amd import Jasper
     from wav2letter_pytorch_amd.defaults import jasper10x5_model

@@ -225,6 +225,74 @@ def test_fp8_operand_model_known_answers():
             assert amax * s <= top < 2 * amax * s and math.log2(s) == round(math.log2(s))
 
 
+def test_bf16_operand_model_known_answers():
+    """oracle.bf16_conv1d / conv1d_block_forward(stats_before_rounding): the bf16 operand model of the product's default
+    mode rounds exactly where it says -- operands, the stored output, dy and dx -- and takes BatchNorm's batch statistics from
+    the accumulators while normalising their bf16 rounding"""
+    import torch
+    import torch.nn.functional as F
+    from oracle import w2l_oracle as O
+    torch.manual_seed(0)
+    x, w, b = torch.randn(2, 8, 40), torch.randn(6, 8, 3) * 0.3, torch.randn(6)
+    xb, wb = x.bfloat16().float(), w.bfloat16().float()
+    x1, w1, b1 = (t.clone().requires_grad_(True) for t in (x, w, b))
+    y = O.bf16_conv1d(x1, w1, b1, stride=1, dilation=2)
+    assert torch.equal(y, F.conv1d(xb, wb, b, dilation=2).bfloat16().float())
+    g = torch.randn_like(y)
+    y.backward(g)
+    gb = g.bfloat16().float()
+    assert torch.equal(x1.grad, torch.nn.grad.conv1d_input(x.shape, wb, gb, dilation=2).bfloat16().float())
+    assert torch.equal(w1.grad, torch.nn.grad.conv1d_weight(xb, w.shape, gb, dilation=2))
+    assert torch.equal(b1.grad, gb.sum((0, 2)))
+    assert torch.equal(O.bf16_head_conv1d(x, w, b, dilation=2), F.conv1d(xb, wb, b, dilation=2))      # logits stay fp32
+    # one block: statistics from the accumulators, the normalised tensor is their rounding
+    sd = {'c.conv1.weight': w, 'c.conv1.bias': b, 'c.batch_norm.weight': torch.rand(6) + 0.5, 'c.batch_norm.bias': torch.randn(6),
+          'c.batch_norm.running_mean': torch.zeros(6), 'c.batch_norm.running_var': torch.ones(6)}
+    got = O.conv1d_block_forward(x, {k: v.clone() for k, v in sd.items()}, 'c.', stride=1, dilation=1, bn=True, activation=False, training=True,
+                                 conv=O.bf16_head_conv1d, stats_before_rounding=True)
+    xp = F.pad(x, (1, 1), mode='reflect')
+    acc = F.conv1d(xp.bfloat16().float(), wb, b)
+    mean, var = acc.mean((0, 2)), acc.var((0, 2), unbiased=False)
+    want = ((acc.bfloat16().float() - mean[None, :, None]) * torch.rsqrt(var + 1e-3)[None, :, None]
+            * sd['c.batch_norm.weight'][None, :, None] + sd['c.batch_norm.bias'][None, :, None])
+    assert torch.equal(got, want)
+    # the running statistics move like nn.BatchNorm1d(momentum=0.9)'s
+    ref_sd, mod_sd = ({k: v.clone() for k, v in sd.items()} for _ in range(2))      # F.batch_norm updates its buffers in place
+    O.conv1d_block_forward(xb, ref_sd, 'c.', stride=1, dilation=1, bn=True, activation=False, training=True,
+                           conv=lambda x_, w_, b_, **kw: F.conv1d(x_, wb, b_, **kw))
+    O.conv1d_block_forward(x, mod_sd, 'c.', stride=1, dilation=1, bn=True, activation=False, training=True,
+                           conv=O.bf16_head_conv1d, stats_before_rounding=True)
+    for k in ('c.batch_norm.running_mean', 'c.batch_norm.running_var'):
+        assert torch.allclose(ref_sd[k], mod_sd[k], rtol=1e-5, atol=1e-6), k
+
+
+def test_bf16_model_deviation_is_the_arithmetic():
+    """The bf16 operand model against the fp32 evaluation of the same small network, both on the CPU with the same clamp
+    gates: the loss agrees to 1e-3 but the gradients differ by percents in the L2 norm although nothing but bf16 storage
+    separates the two -- what tests/test_gpu_fullsize.py::test_w2l_full_table_bf16_vs_operand_model then measures the device
+    against."""
+    import torch
+    from oracle import w2l_oracle as O
+    layers = [(128, 11, 2, 1, 0.0), (128, 13, 1, 1, 0.0), (256, 5, 1, 2, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=1)
+    x, il, tg, tl = O.synthetic_batch(2, 120, seed=1, s_lo=5, s_hi=15)
+    a = O.wav2letter_step(x, il, tg, tl, {k: v.clone() for k, v in sd.items()}, layers)
+    gates = [(v > 0) & (v < 20) for v in a['activations']]
+    a = O.wav2letter_step(x, il, tg, tl, {k: v.clone() for k, v in sd.items()}, layers, gates=gates)
+    b = O.wav2letter_step(x, il, tg, tl, {k: v.clone() for k, v in sd.items()}, layers, gates=gates, bf16_model=True)
+    assert abs(float(a['loss']) - float(b['loss'])) < 1e-3 * float(a['loss'])
+    rel = {k: float((a['grads'][k] - b['grads'][k]).norm() / a['grads'][k].norm().clamp_min(1e-20))
+           for k in a['grads'] if k.endswith('conv1.weight')}
+    assert all(2e-3 < rel[f'conv1ds.conv1d_{i}.conv1.weight'] < 0.1 for i in range(3)), rel     # ~1e-2 after three layers
+    assert rel['conv1ds.conv1d_3.conv1.weight'] < 5e-3, rel                                     # the classifier: 1e-3
+    for k in ('running_mean', 'running_var'):                 # the model's buffers follow the fp32 path's
+        ka = f'conv1ds.conv1d_1.batch_norm.{k}'
+        sa, sb = {kk: v.clone() for kk, v in sd.items()}, {kk: v.clone() for kk, v in sd.items()}
+        O.wav2letter_step(x, il, tg, tl, sa, layers, gates=gates)
+        O.wav2letter_step(x, il, tg, tl, sb, layers, gates=gates, bf16_model=True)
+        assert torch.allclose(sa[ka], sb[ka], rtol=2e-2, atol=2e-3), ka
+
+
 def test_fp8_model_deviation_is_the_arithmetic():
     """The e4m3 operand model against the fp32 evaluation of the SAME small network, both on the CPU in float32 with the
     same clamp gates: gradients differ by tens of percent in the L2 norm although nothing but operand rounding separates
