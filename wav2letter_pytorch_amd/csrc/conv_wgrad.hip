@@ -41,7 +41,10 @@ constexpr int BNC = 128;      // ci per block
 constexpr int BT = 64;        // t rows per K step
 constexpr int ROWB = 256;     // bytes per LDS row (128 bf16)
 
-constexpr int KWB_DEFAULT = 2;   // taps per block
+#ifndef W2L_KWB
+#define W2L_KWB 2
+#endif
+constexpr int KWB_DEFAULT = W2L_KWB;   // taps per block (1: diagnostic builds only -- the one-tap form keeps 140-153 VGPRs)
 
 struct WgradParams {
     const bf16_raw* dy;
