@@ -17,8 +17,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k1, uint32_t out[4]) {
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a mul_lo / mul_hi pair: the multiplies are the
+        // forward BN-apply kernel's longest dependent chain
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -155,16 +158,21 @@ __device__ __forceinline__ uint2 quant8_e4m3(const float v[8], float scale) {
 template <bool F32, bool HAS2>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(w2l_bnact_t d, bf16_raw* out_hi, bf16_raw* out_lo, int R,
                                                           int pad_l, int pad_r, int pad_mode, uint32_t thresh,
-                                                          float inv_keep, uint8_t* out_q, float q_scale) {
+                                                          float inv_keep, uint8_t* out_q, float q_scale, float inv_g) {
+    // grid = (groups of one utterance / 256, N): the utterance is the block's y index, and the one remaining division (by the
+    // number of 8-channel groups per row) is a float reciprocal with a fix-up -- exact, since rows x groups of ONE utterance is
+    // below 2^24 (checked by the launcher).  The two integer divisions this replaces were a sixth of the kernel's VALU work.
     const int G = d.C >> 3;
-    const unsigned total = (unsigned)d.N * R * G;            // < 2^31 (checked by the launcher): 32-bit index math
+    const int n = blockIdx.y;
     unsigned clipped = 0;                                    // e4m3 copy: elements beyond the format's range at this scale
     const float q_limit = 448.f / q_scale;
-    for (unsigned it = blockIdx.x * 256u + threadIdx.x; it < total; it += gridDim.x * 256u) {
-        const unsigned orow = it / (unsigned)G;
-        const int cg = (int)(it - orow * G);
-        const int n = (int)(orow / (unsigned)R);
-        const int r = (int)(orow - (unsigned)n * R);
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < R * G) {
+        int r = (int)((float)idx * inv_g);
+        r -= (r * G > idx) ? 1 : 0;
+        r += ((r + 1) * G <= idx) ? 1 : 0;
+        const int cg = idx - r * G;
+        const unsigned orow = (unsigned)n * R + r;
         const int t = pad_src_row(r, d.T, pad_l, pad_r, pad_mode);
         float a[8];
 #pragma unroll
@@ -270,8 +278,10 @@ __device__ __forceinline__ void bwd_row(const w2l_bnact_t& d, const Chan& c1, co
 constexpr int BWD_SLAB = 64;             // channels per wave
 __host__ __device__ inline int bwd_rows_per_wave(int64_t rows, int C) {
     // ~4096 wave tasks per launch: 16 rows for the narrow layers, up to 64 for the wide ones
-    int64_t rw = rows * (C / BWD_SLAB) / 4096;
-    rw = rw / 8 * 8;
+    // (rounded UP to whole 8-row steps: rounding down left 4 600-6 000 tasks, i.e. a second, mostly empty round of waves behind
+    // the 4 096 that are resident at four per SIMD)
+    int64_t rw = (rows * (C / BWD_SLAB) + 4095) / 4096;
+    rw = (rw + 7) / 8 * 8;
     return (int)(rw < 16 ? 16 : (rw > 64 ? 64 : rw));
 }
 
@@ -724,11 +734,14 @@ extern "C" int w2l_bn_act_fwd_q(const w2l_bnact_t* d, void* out_hi, void* out_lo
     const uint32_t thresh = (uint32_t)(d->drop_p * 65536.f);
     const float inv_keep = 1.f / (1.f - d->drop_p);
     W2L_CHECK_ARG((int64_t)d->N * out_rows * (d->C / 8) < (1LL << 31), "bn_act_fwd: tensor too large for 32-bit indexing");
-    const int blocks = elementwise_blocks((int64_t)d->N * out_rows * (d->C / 8));
+    const int64_t per_utt = (int64_t)out_rows * (d->C / 8);
+    W2L_CHECK_ARG(per_utt < (1 << 24) && d->N <= 65535, "bn_act_fwd: more than 2^24 channel groups per utterance or N > 65535");
+    const dim3 grid((unsigned)((per_utt + 255) / 256), (unsigned)d->N);
+    const float inv_g = 1.f / (float)(d->C / 8);
 #define W2L_FWD(F, H)                                                                                        \
-    hipLaunchKernelGGL((bn_act_fwd_kernel<F, H>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d,          \
+    hipLaunchKernelGGL((bn_act_fwd_kernel<F, H>), grid, dim3(256), 0, (hipStream_t)stream, *d,                  \
                        (bf16_raw*)out_hi, (bf16_raw*)out_lo, out_rows, pad_l, pad_r, pad_mode, thresh, inv_keep,    \
-                       (uint8_t*)out_q, q_scale)
+                       (uint8_t*)out_q, q_scale, inv_g)
     if (d->y_f32) { if (d->y2) W2L_FWD(true, true); else W2L_FWD(true, false); }
     else { if (d->y2) W2L_FWD(false, true); else W2L_FWD(false, false); }
 #undef W2L_FWD
