@@ -184,9 +184,14 @@ def main():
     ap.add_argument('--no-live-traffic', action='store_true',
                     help='do not start the two rocprofv3 --pmc child passes that measure roofline.traffic (the committed '
                          'profiles/r*_pmc_bench.json is quoted instead when it was measured on this build)')
+    ap.add_argument('--defer-candidates', default=None, help="with --defer-wgrad auto: ';'-separated specs to measure instead of the built-in list")
     ap.add_argument('--no-optimizer', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the step as a captured hipGraph (graph.GraphedTrainStep; Wav2Letter)')
     ap.add_argument('--no-sgd-overlap', action='store_true', help='keep the fused SGD updates on the main stream')
+    ap.add_argument('--defer-wgrad', default=os.environ.get('W2L_DEFER_WGRAD', 'auto'),
+                    help='weight gradients (+ fused update, + all-reduce) of the top K conv units run beside the NEXT forward pass '
+                         '(optim.FusedSGD.defer_wgrad); an integer, or "auto": measured in this run after the warm-up (0 vs '
+                         'the candidates, the fastest serves the timed region)')
     ap.add_argument('--force-dp', action='store_true', help='run the RCCL gradient path even with one rank (plumbing check)')
     ap.add_argument('--early-collective', action='store_true',
                     help='with --force-dp: run one collective before the first step, as the parameter broadcast of a multi-rank run '
@@ -196,6 +201,9 @@ def main():
                          'RCCL helpers) and keep torch.distributed (or what W2L_DP_NATIVE says)')
     ap.add_argument('--serial-wgrad', action='store_true', help='keep weight gradients on the main stream (clean per-kernel durations for profiling)')
     ap.add_argument('--trace-steps', action='store_true', help='per-step host-enqueue vs GPU time (stderr), then exit')
+    ap.add_argument('--event-trace', default=None, metavar='CSV',
+                    help='HIP-event timeline of --steps steps without a profiler attached (_lib.trace_launches), written in the '
+                         'column layout of a rocprofv3 kernel trace for tools/timeline.py; then exit')
     ap.add_argument('--lead-trace', action='store_true',
                     help='how far the host runs ahead of the GPU at four points of every step (stderr), then exit')
     ap.add_argument('--host-profile', action='store_true', help='cProfile of the host side of the step (stderr), then exit')
@@ -268,6 +276,17 @@ def main():
     if hasattr(opt, 'overlap') and not args.no_sgd_overlap:
         opt.overlap = True            # conv-weight updates run on a side stream under the next step's forward (optim.FusedSGD)
 
+    can_defer = hasattr(opt, 'defer_wgrad') and getattr(opt, 'overlap', False) and not args.graph and not args.no_optimizer
+    defer_k = '0'            # 'k' = the top k units, 'a,b,c' = exactly those units (negative: counted from the top)
+
+    def defer_spec(text):
+        """'4' = the top 4 units; '-1,-3,-5' = exactly those units (counted from the top)"""
+        return [int(v) for v in text.split(',')] if ',' in text else int(text)
+
+    if can_defer and args.defer_wgrad != 'auto':
+        defer_k = args.defer_wgrad
+        opt.defer_wgrad(model, defer_spec(defer_k))
+
     def step():
         opt.zero_grad(set_to_none=True)
         out, _ = model(x, lens_arg)
@@ -314,6 +333,26 @@ def main():
         step()
     fence()
 
+    # ---- how many of the top units' weight gradients to hold back for the next forward pass?  Measured here: 0 against the
+    # candidates, a few steps each between fences, the slowest rank's time; all ranks take the same decision.
+    defer_ab = None
+    if can_defer and args.defer_wgrad == 'auto':
+        n_units = len(model.engine().units)
+        # (every-other-unit patterns, e.g. '-1,-3,-5,-7', were measured too: never ahead of the plain top-k sets)
+        cands = ['0'] + [str(k) for k in (4, 6) if k <= n_units]
+        if args.defer_candidates:
+            cands = ['0'] + args.defer_candidates.split(';')
+        defer_ab = {}
+        for k in cands:
+            opt.defer_wgrad(model, defer_spec(k))
+            step()
+            step()
+            defer_ab[k] = round(timed_ms(5), 3)
+        defer_k = min(defer_ab, key=lambda k: defer_ab[k])
+        opt.defer_wgrad(model, defer_spec(defer_k))
+        step()
+        fence()
+
     # ---- which collective path?  Measured here, in this run, on this node: nobody is there to flip a switch on the first
     # 8-GPU run.  k steps with the gradient collectives through torch.distributed (ProcessGroupNCCL: its own internal stream,
     # the one stream of the step streams.py cannot probe), k steps through the C ABI's RCCL helpers (NativeComm: the collective
@@ -353,6 +392,17 @@ def main():
             if comm is not None:
                 comm.close()
         fence()
+    if args.event_trace:
+        from wav2letter_pytorch_amd import _lib
+        fence()
+        _lib.trace_launches(True)
+        for _ in range(args.steps):
+            step()
+        fence()
+        _lib.trace_launches(False)
+        n = _lib.trace_dump(args.event_trace)
+        print(f'{n} launches of {args.steps} steps -> {args.event_trace} (defer_wgrad {defer_k}: {defer_ab})', file=sys.stderr)
+        return
     if args.trace_steps:
         # per-step host enqueue time vs GPU time (event to event): tells a host-bound box from a slow-clock box
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -603,6 +653,9 @@ def main():
             'collectives_via': (None if getattr(model, 'grad_reducer', None) is None or not model.grad_reducer.active else
                                 'w2l_rccl_* (C ABI)' if model.grad_reducer._comm is not None else 'torch.distributed'),
             'collective_paths_ms': collective_paths,
+            'defer_wgrad': {'units': defer_k, 'measured_ms_per_step': defer_ab,
+                            'note': 'weight gradients + fused updates of the top units run beside the next forward pass; every '
+                                    'deferred launch of a timed step is inside the timed region (the fences flush them)'},
             'rank_ms_per_step': [round(v, 3) for v in rank_ms],
             'exposed_comm_ms': None if exposed_comm_ms is None else round(exposed_comm_ms, 3),
             'exposed_comm_ms_by_rank': exposed_by_rank,

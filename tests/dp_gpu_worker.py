@@ -12,8 +12,44 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+def main_steps(out_path, defer, steps=3):
+    """``steps`` data-parallel training steps in bf16 mode with the top ``defer`` units' weight gradients held back for the
+    next forward pass (optim.FusedSGD.defer_wgrad; 0 = the plain step): final parameters of every rank"""
+    import torch.distributed as dist
+    from gpu_helpers import build_w2l
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd.distributed import GradReducer, broadcast_parameters, init_process_group_from_env
+    torch.cuda.set_device(0)
+    rank, world = init_process_group_from_env(backend='gloo')
+    layers = [(128, 11, 2, 1, 0.0), (256, 13, 1, 1, 0.0), (128, 29, 1, 2, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=60 + rank)
+    model = build_w2l(layers, sd, 'bf16').train()
+    broadcast_parameters(model)
+    model.grad_reducer = GradReducer()
+    model._cfg.optimizer.lr = 0.05
+    opt = model.configure_optimizers()[0][0]
+    opt.overlap = True
+    opt.defer_wgrad(model, defer)
+    x, il, tg, tl = O.synthetic_batch(4, 240, seed=70 + rank, s_lo=5, s_hi=20)
+    held = []
+    for _ in range(steps):
+        opt.zero_grad(set_to_none=True)
+        out, ol = model(x.cuda(), il)
+        model.criterion(out.transpose(0, 1), tg, ol, tl).backward()
+        held.append(len(model.engine()._deferred))
+        opt.step()
+    opt.join()
+    torch.cuda.synchronize()
+    np.savez(out_path + f'.rank{rank}.npz', held=np.array(held),
+             **{'p/' + k: v.detach().cpu().numpy() for k, v in model.named_parameters()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     out_path = sys.argv[1]
+    if len(sys.argv) > 2:
+        return main_steps(out_path, int(sys.argv[2]))
     import torch.distributed as dist
     from gpu_helpers import build_w2l
     from oracle import w2l_oracle as O

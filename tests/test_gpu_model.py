@@ -243,6 +243,61 @@ def test_fused_sgd_matches_torch_sgd(overlap, recycle):
     assert isinstance(ma.configure_optimizers()[0][0], FusedSGD)
 
 
+@pytest.mark.parametrize('k', [1, 3, (-3, -1)])
+def test_deferred_weight_gradients_match_plain_sgd(k):
+    """optim.FusedSGD.defer_wgrad: the top k units' weight gradients are computed at the start of the NEXT forward pass and
+    consumed by the fused update directly.  Four steps (with an eval-mode forward and a gradient-only backward in between)
+    must leave the same parameters as torch.optim.SGD on an identical model; the deferred weights never see a .grad."""
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd.optim import FusedSGD
+    layers = [(128, 11, 2, 1, 0.0), (128, 13, 1, 2, 0.0), (192, 5, 1, 1, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=14)
+    ma = build_w2l(layers, sd, 'bf16').train()
+    mb = build_w2l(layers, sd, 'bf16').train()
+    kw = dict(lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-3)
+    oa = FusedSGD.from_sgd(torch.optim.SGD(ma.parameters(), **kw))
+    oa.overlap = True
+    oa.defer_wgrad(ma, k)
+    ob = torch.optim.SGD(mb.parameters(), **kw)
+    x, il, tg, tl = O.synthetic_batch(2, 160, seed=11, s_lo=5, s_hi=15)
+    body = [b.conv1.weight for b in list(ma.conv1ds.children())[:-1]]
+    top = body[-k:] if isinstance(k, int) else [body[i] for i in k]
+    k = len(top)
+    for it in range(4):
+        for m, o in ((ma, oa), (mb, ob)):
+            o.zero_grad(set_to_none=True)
+            out, ol = m(x.cuda(), il)
+            m.criterion(out.transpose(0, 1), tg, ol, tl).backward()
+            if m is ma:
+                assert all(w.grad is None for w in top) and len(ma.engine()._deferred) == k
+            o.step()
+        if it == 1:                      # an eval forward between two steps sees the updated weights on both models
+            ea, eb = (m.eval()(x.cuda(), il)[0] for m in (ma, mb))
+            assert not ma.engine()._deferred
+            assert scale_err(ea.detach().cpu().numpy(), eb.detach().cpu().numpy()) < 2e-2
+            ma.train(), mb.train()
+    oa.join()
+    for (name, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert scale_err(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()) < 5e-5, name
+    # the operand packs the next forward will use are those of the updated weights
+    for w in top:
+        pk = w._w2l_pack[False]
+        assert pk.version == w._version and torch.equal(pk.fwd_hi, w.detach().permute(2, 0, 1).to(torch.bfloat16))
+    # a backward pass that is NOT followed by an optimizer step: the held-back gradients land in .grad at the next flush
+    for m in (ma, mb):
+        m.zero_grad(set_to_none=True)
+        out, ol = m(x.cuda(), il)
+        m.criterion(out.transpose(0, 1), tg, ol, tl).backward()
+    assert all(w.grad is None for w in top)
+    oa.join()
+    torch.cuda.synchronize()
+    for (name, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert pa.grad is not None, name
+        assert scale_err(pa.grad.detach().cpu().numpy(), pb.grad.detach().cpu().numpy()) < 1e-2 or float(pb.grad.abs().max()) < 1e-10, name
+    oa.defer_wgrad(ma, 0)
+    assert ma.engine().defer_wgrad == 0
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_jasper_dense_golden(precision):
     """Jasper with dense (non-separable) blocks, repeat 2, residual 1x1 conv + BN, dilation 2, stride-2 first block,
@@ -569,6 +624,36 @@ def test_data_parallel_two_ranks_on_one_gpu(tmp_path):
         assert not np.array_equal(z[0]['p1/' + k], z[0]['p0/' + k]) or 'conv1.bias' in k, k
 
 
+def test_data_parallel_deferred_wgrad_two_ranks(tmp_path):
+    """the deferred weight gradients under data parallelism: their all-reduce is started behind the kernel at the start of
+    the next forward pass and the fused update waits for it.  Two gloo ranks on cuda:0, three steps, once with the top two
+    units held back and once plain: replicas stay bit-identical across the ranks, and the two modes end on the same
+    parameters."""
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for defer in (2, 0):
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        base = str(tmp_path / f'dpd{defer}')
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                       W2L_AUTOTUNE='0')
+            procs.append(subprocess.Popen([sys.executable, os.path.join(here, 'dp_gpu_worker.py'), base, str(defer)], env=env))
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+        res[defer] = [np.load(base + f'.rank{r}.npz') for r in range(2)]
+    assert list(res[2][0]['held']) == [2, 2, 2] and list(res[0][0]['held']) == [0, 0, 0]
+    for k in [k for k in res[2][0].files if k.startswith('p/')]:
+        np.testing.assert_array_equal(res[2][0][k], res[2][1][k])
+        assert scale_err(res[2][0][k], res[0][0][k]) < 5e-5, k
+
+
 def test_bench_two_rank_command_line(tmp_path):
     """the driver's multi-GPU command line (python -m torch.distributed.run ... bench.py --gpus 2) rehearsed on one GPU with
     the gloo backend: both ranks must reach the end (every collective matched on every rank) and rank 0 prints one JSON line"""
@@ -604,12 +689,13 @@ def test_bench_self_launch_two_ranks(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     env['W2L_DIST_BACKEND'] = 'gloo'
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--mid-layers', '2',
-           '--batch', '2', '--frames', '200', '--no-cpu-baseline']
+           '--batch', '2', '--frames', '200', '--no-cpu-baseline', '--defer-wgrad', '1']
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1
     d = json.loads(lines[0])
+    assert d['defer_wgrad']['units'] == '1'
     assert d['n_gpus'] == 2 and d['rccl_world'] == 2 and d['backend'] == 'gloo' and d['config']['global_batch'] == 4
     assert len(d['rank_ms_per_step']) == 2 and all(v > 0 for v in d['rank_ms_per_step'])
     assert d['exposed_comm_ms'] is not None and abs(d['per_gpu_value'] * 2 - d['value']) < 1.0

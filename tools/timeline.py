@@ -91,6 +91,35 @@ def main():
             fam = family(n)
             agg[fam][0] += (e - s) / 1e3
             agg[fam][1] += 1
+    if '--gaps' in sys.argv:
+        # the intervals of ONE step (the first analysed) in which no MFMA-bound kernel runs: when (us from the step's start),
+        # how long, what runs meanwhile, and the MFMA kernels on either side
+        a, b = starts[0], starts[1]
+        seg = rows[a:b]
+        t0, t1 = seg[0][0], rows[b][0]
+        mf = sorted((s, min(e, t1), n) for s, e, n, _ in seg if family(n).startswith(MFMA))
+        merged = []
+        for s, e, n in mf:
+            if merged and s <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], e)
+            else:
+                merged.append([s, e])
+        gaps = [(t0, merged[0][0])] + [(merged[i][1], merged[i + 1][0]) for i in range(len(merged) - 1)] + [(merged[-1][1], t1)]
+        def short(n):
+            n = n.split('(')[0]
+            return n[n.rfind('::') + 2:] if '::' in n else n
+        print('gaps of step 0 (no MFMA kernel running), us from the step start; total %.1f us in %d gaps:' %
+              (sum(e - s for s, e in gaps) / 1e3, len(gaps)))
+        # where the CTC kernels sit splits the step into forward and backward
+        ctc0 = min((s for s, e, n, _ in seg if 'ctc' in n), default=t1)
+        fwd = sum(min(e, ctc0) - s for s, e in gaps if s < ctc0) / 1e3
+        print('  before the first CTC kernel (forward): %.1f us; after: %.1f us; forward lasts %.1f us' %
+              (fwd, sum(e - s for s, e in gaps) / 1e3 - fwd, (ctc0 - t0) / 1e3))
+        for s, e in gaps:
+            if e - s < 3000:
+                continue
+            inside = [short(n) + ':%.0f' % ((min(ke, e) - max(ks, s)) / 1e3) for ks, ke, n, _ in seg if ks < e and ke > s]
+            print('  @%8.1f  %7.1f us  %s' % ((s - t0) / 1e3, (e - s) / 1e3, ' '.join(inside)[:180]))
     n = len(starts) - 1
     print('per step over %d steps (us):' % n)
     for k in ('wall', 'MFMA busy', 'two MFMA kernels', 'non-MFMA only', 'idle'):

@@ -167,3 +167,67 @@ def require_device(*tensors):
         if t is not None and not t.is_cuda:
             raise W2LError('wav2letter_pytorch_amd runs on MI355X only: got a CPU tensor '
                            '(there is no CPU fallback; move the model and batch to cuda)')
+
+
+# ---------------------------------------------------------------------------------------------------------------- launch trace
+# A timeline of the step WITHOUT a profiler attached (under rocprofv3 the host needs ~13 ms to enqueue a step instead of ~5
+# and the step boundary shows bubbles the real run does not have): trace_launches(True) swaps every launching entry point
+# for a wrapper that records a HIP event before and after the call on the stream it launches on; trace_dump() turns the
+# pairs into rows with device timestamps (ns from the first event), in the column layout of rocprofv3's kernel trace, so
+# tools/timeline.py reads either.  ~10 us of host time per launch; diagnostic only (bench.py --event-trace).
+TRACE_NAMES = {
+    'w2l_conv1d_igemm': 'conv_igemm_kernel', 'w2l_conv1d_igemm_ws': 'conv_igemm_kernel',
+    'w2l_conv1d_dgrad_bnreduce_ws': 'conv_igemm_kernel/dgrad+bnreduce', 'w2l_conv1d_igemm_fp8': 'conv_igemm_fp8_kernel',
+    'w2l_conv1d_wgrad': 'conv_wgrad_kernel', 'w2l_conv1d_wgrad_ws': 'conv_wgrad_kernel', 'w2l_conv1d_wgrad_fp8': 'conv_wgrad_fp8_kernel',
+    'w2l_bn_finalize': 'bn_finalize_kernel', 'w2l_bn_act_fwd': 'bn_act_fwd_kernel', 'w2l_bn_act_fwd_q': 'bn_act_fwd_kernel',
+    'w2l_bn_act_bwd_reduce': 'bn_act_bwd_reduce_kernel', 'w2l_bn_bwd_finalize': 'bn_bwd_finalize_kernel',
+    'w2l_bn_act_bwd_apply': 'bn_act_bwd_apply_kernel', 'w2l_bn_act_bwd_apply_amax': 'bn_act_bwd_apply_kernel',
+    'w2l_bn_act_bwd_apply_fin': 'bn_act_bwd_apply_kernel', 'w2l_sgd_pack': 'sgd_pack_kernel', 'w2l_pack_weights': 'pack_weights_kernel',
+    'w2l_ctc_loss': 'ctc_kernels', 'w2l_log_softmax_fwd': 'log_softmax_fwd', 'w2l_log_softmax_bwd': 'log_softmax_bwd',
+    'w2l_nct_to_ntc': 'nct_to_ntc_kernel', 'w2l_pad_cast': 'pad_cast_kernel', 'w2l_quantize_e4m3': 'quantize_e4m3',
+    'w2l_quantize_e4m3_dyn': 'quantize_e4m3_dyn', 'w2l_dwconv_fwd': 'dw_fwd_kernel', 'w2l_dwconv_dgrad': 'dw_dgrad_kernel',
+    'w2l_dwconv_wgrad': 'dw_wgrad_kernel', 'w2l_argmax': 'argmax_kernel', 'w2l_novograd_pack': 'novograd_pack_kernel',
+}
+_trace = {'rows': None, 'saved': {}, 'pool': []}
+
+
+def trace_launches(enable: bool, capacity: int = 4096):
+    """start (True) or stop (False) recording an event pair around every launching entry point; the events of the first
+    ``capacity`` launches are created up front (hipEventCreate costs more than the launch it brackets)"""
+    if enable and _trace['rows'] is None:
+        _trace['rows'] = []
+        _trace['pool'] = [torch.cuda.Event(enable_timing=True) for _ in range(2 * capacity)]
+        for name, label in TRACE_NAMES.items():
+            fn = getattr(lib, name)
+            _trace['saved'][name] = fn
+
+            def wrapper(*args, _fn=fn, _label=label):
+                pool = _trace['pool']
+                s = pool.pop() if pool else torch.cuda.Event(enable_timing=True)
+                e = pool.pop() if pool else torch.cuda.Event(enable_timing=True)
+                s.record()
+                rc = _fn(*args)
+                e.record()
+                _trace['rows'].append((_label, torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()), s, e))
+                return rc
+
+            setattr(lib, name, wrapper)
+    elif not enable and _trace['rows'] is not None:
+        for name, fn in _trace['saved'].items():
+            setattr(lib, name, fn)
+        _trace['saved'] = {}
+
+
+def trace_dump(path: str) -> int:
+    """write the recorded launches as a rocprofv3-style kernel trace (csv) and forget them; returns the row count.
+    The device must be idle (torch.cuda.synchronize()) -- event times are read back."""
+    rows, _trace['rows'] = _trace['rows'] or [], None
+    if not rows:
+        return 0
+    origin = rows[0][2]
+    with open(path, 'w') as f:
+        f.write('Kernel_Name,Queue_Id,Start_Timestamp,End_Timestamp\n')
+        for label, stream, s, e in rows:
+            t0 = origin.elapsed_time(s)
+            f.write('%s,%d,%d,%d\n' % (label, stream, int(t0 * 1e6), int((t0 + s.elapsed_time(e)) * 1e6)))
+    return len(rows)

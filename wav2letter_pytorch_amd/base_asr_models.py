@@ -119,6 +119,13 @@ class ConvCTCASR(_Base):
         eng.grad_ready = reducer.on_grad if reducer is not None else None
         eng.flat_ready = getattr(reducer, 'on_flat', None)
         eng.backward_done = reducer.finish if reducer is not None else None
+        # deferred weight gradients (optim.FusedSGD.defer_wgrad): the top k units' dW + update run beside the NEXT forward
+        opt = getattr(self, '_deferred_opt', None)
+        eng.defer_wgrad = getattr(self, '_defer_wgrad', 0) if opt is not None else 0
+        eng.deferred = opt
+        eng.grad_reduce_start = reducer.start if (reducer is not None and reducer.active) else None
+        if opt is not None:
+            opt._register_engine(eng)
         return eng
 
     # ------------------------------------------------------------------ metrics

@@ -148,6 +148,24 @@ class _StreamWork:
         torch.cuda.current_stream().wait_event(self._event)
 
 
+class _Pending:
+    """one collective started by GradReducer.start()"""
+
+    def __init__(self, reducer, entry):
+        self._reducer, self._entry = reducer, entry
+
+    def finish(self):
+        work, buf, need_div = self._entry
+        work.wait()
+        if isinstance(buf, tuple):           # bf16 transport: widen the averaged copy back into the fp32 gradient
+            buf, half = buf
+            buf.copy_(half)
+            if half.is_cuda:
+                half.record_stream(torch.cuda.current_stream(half.device))
+        if need_div and self._reducer.world > 1:
+            buf.div_(self._reducer.world)
+
+
 class GradReducer:
     """Averages gradients across the ranks of ``group`` as they become ready."""
 
@@ -254,6 +272,13 @@ class GradReducer:
             work, need_div = self._all_reduce(half)
         self._works.append((work, (buf, half), need_div))
         return work, True                    # "not final until finish()": the fp32 buffer is rewritten there
+
+    def start(self, buf: torch.Tensor) -> '_Pending':
+        """launch the all-reduce of ONE dense gradient buffer now (ordered after the current stream's work) and return a
+        handle whose ``finish()`` makes the then-current stream wait for the averaged result.  Outside the backward pass's
+        on_grad / finish() cycle: the step engine's deferred weight gradients (engine.flush_deferred) use it."""
+        self._launch(buf)
+        return _Pending(self, self._works.pop())
 
     def finish(self):
         """Flush the small gradients, then make the current stream wait for every collective."""

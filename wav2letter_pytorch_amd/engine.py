@@ -30,6 +30,14 @@ ACT_NONE, ACT_CLAMP20, ACT_RELU = 0, 1, 2
 PAD_ZERO, PAD_REFLECT = 0, 1
 
 
+class _nullctx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
 def roundup(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -492,6 +500,17 @@ class StackEngine:
         # fp8 mode: device counter of activation elements whose e4m3 copy saturated (fixed per-tensor activation scales:
         # clamp(0, 20) outputs never do, ReLU outputs beyond 448 / 8 = 56 would) -- read on demand by fp8_saturated()
         self._q_clipped: Optional[torch.Tensor] = None
+        # deferred weight gradients (optim.FusedSGD.defer_wgrad): the weight gradients of the TOP ``defer_wgrad`` units --
+        # computed first in backward, needed last by the next forward -- are not launched in backward but at the START of
+        # the next forward, on the weight-gradient stream, each followed by its fused update (``deferred.apply``) and, data
+        # parallel, preceded by its all-reduce (``grad_reduce_start``).  They then run beside the forward's BatchNorm chain
+        # and CTC, where no other MFMA-bound kernel is ready (profiles/r03_step_timeline.txt: 1.5 ms per step).
+        # An int k = the top k units; a set of unit indices = exactly those (e.g. every other one of the top layers, so that
+        # the backward pass keeps weight gradients of its own to run beside its BatchNorm kernels).
+        self.defer_wgrad = 0
+        self.deferred = None              # the optimizer: accepts(p), token(), stepped(token), apply(p, grad)
+        self.grad_reduce_start: Optional[Callable] = None      # distributed.GradReducer.start
+        self._deferred: list = []
 
     # ------------------------------------------------------------------ parameters
     def parameters(self) -> List[torch.Tensor]:
@@ -531,6 +550,8 @@ class StackEngine:
         """x fp32 [N, C, T] on device -> (out fp32 [N, T', n_labels], lens_out or None)."""
         _lib.require_device(x)
         global _dropout_calls
+        if self._deferred:
+            self.flush_deferred()
         precise = self.precise
         N, C0, T0 = x.shape
         x = x.contiguous().float()
@@ -1020,7 +1041,8 @@ class StackEngine:
             # main branch
             pkm = pack_weights(main, precise)
             src = acts[u.src] if u.dw is None else uc.mid
-            self._wgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, grads, amax=None if amax_w is None else amax_w[0])
+            self._wgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, grads, amax=None if amax_w is None else amax_w[0],
+                        defer=self._defer_ok(ctx, uc, main))
             if main.bias is not None:
                 if main.has_bn and batch_stats:      # sum(dy) == 0 identically under batch-statistics BatchNorm
                     grads[id(main.bias)] = self._zeros(main.cout, dev)      # zero on every rank: nothing to average
@@ -1038,7 +1060,8 @@ class StackEngine:
             if res is not None:
                 pkr = pack_weights(res, precise)
                 rsrc = acts[u.res_src]
-                self._wgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc, grads, amax=None if amax_w is None else amax_w[1])
+                self._wgrad(res, pkr, dy2_hi, dy2_lo, h2, Tout, rsrc, grads, amax=None if amax_w is None else amax_w[1],
+                            defer=self._defer_ok(ctx, uc, res))
                 if res.bias is not None:
                     if res.has_bn and batch_stats:
                         grads[id(res.bias)] = self._zeros(res.cout, dev)
@@ -1125,7 +1148,78 @@ class StackEngine:
             hit = self._dyq[id(dy_hi)] = (dyq, inv, dy_hi)          # (dy_hi kept: its id must not be reused meanwhile)
         return hit[0], hit[1]
 
-    def _wgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, grads, amax=None):
+    def _defer_ok(self, ctx, uc: _UnitCtx, conv: ConvSpec) -> bool:
+        """is this unit's weight gradient one of those held back until the next forward?"""
+        k, opt = self.defer_wgrad, self.deferred
+        if not k or opt is None or not ctx['training'] or self.precise:
+            return False
+        ui, n = uc.out_index - 1, len(self.units)
+        if isinstance(k, int):                          # the top k units
+            if ui < n - k:
+                return False
+        elif ui not in k and ui - n not in k:           # an explicit set of unit indices (negative: counted from the top)
+            return False
+        w = conv.weight
+        # a gradient that autograd would ADD to an existing .grad (accumulation steps) is computed now
+        return (w.is_cuda and w.grad is None and not torch.cuda.is_current_stream_capturing() and opt.accepts(w))
+
+    def flush_deferred(self):
+        """launch the weight gradients held back by the last backward pass -- on the weight-gradient stream, in forward order,
+        each one handed to the optimizer's fused update (which tags the weight's operand pack with an event the forward
+        convolution of that layer waits for).  Called at the start of every forward; optim.FusedSGD.join() calls it too.
+        If no optimizer step was taken since that backward (the caller only wanted gradients), the gradients are computed
+        on the current stream and stored in ``param.grad`` instead."""
+        recs, self._deferred = self._deferred, []
+        if not recs:
+            return
+        recs.sort(key=lambda r: r['order'])
+        opt = self.deferred
+        dev = recs[0]['dy_hi'].device
+        main = torch.cuda.current_stream(dev)
+        pending = []
+
+        def sink(w, g, storage):
+            pending.append((w, g, storage, self.grad_reduce_start(storage) if self.grad_reduce_start is not None else None))
+
+        live = [r for r in recs if opt is not None and opt.stepped(r['token'])]
+        stale = [r for r in recs if not (opt is not None and opt.stepped(r['token']))]
+        for r in stale:                    # nobody stepped: plain gradients, on the caller's stream
+            self._wgrad_now(r['conv'], r['pk'], r['dy_hi'], r['dy_lo'], r['halo'], r['Tout'], r['src'], {}, f8=r['f8'], sink=sink)
+            w, g, _, work = pending.pop()
+            if work is not None:
+                work.finish()
+            w.grad = g if w.grad is None else w.grad + g
+        if not live:
+            return
+        fork = None
+        if self.overlap_wgrad:
+            if self._side is None or self._side.device != dev:
+                self._side = _side_stream(dev, main)
+            fork = (main, self._side)
+        for r in live:
+            self._wgrad_now(r['conv'], r['pk'], r['dy_hi'], r['dy_lo'], r['halo'], r['Tout'], r['src'], {}, fork=fork,
+                            f8=r['f8'], sink=sink)
+            if self.grad_reduce_start is None:           # one GPU: wgrad_i, update_i, wgrad_i+1, ... on one stream
+                w, g, _, _ = pending.pop()
+                with torch.cuda.stream(fork[1]) if fork else _nullctx():
+                    opt.apply(w, g)
+            if fork is not None:
+                self._held.extend(t for t in (r['dy_hi'], r['dy_lo'], r['src'].hi, r['src'].lo) +
+                                  ((r['src'].q,) + r['f8'] if r['f8'] else ()) if t is not None)
+        if pending:                        # data parallel: every all-reduce is in flight before the first update waits for one
+            with torch.cuda.stream(fork[1]) if fork else _nullctx():
+                for w, g, _, work in pending:
+                    work.finish()
+                    opt.apply(w, g)
+        if fork is not None:
+            self._side_used = True
+
+    def join_side(self):
+        """the current stream waits for the weight-gradient stream (deferred gradients and their updates run there)"""
+        if self._side is not None and self._side_used:
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+
+    def _wgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, grads, amax=None, defer=False):
         """dW, optionally on the side stream (ordered after everything enqueued so far on the current stream).
 
         No record_stream: dW is allocated (and zero-filled) on the main stream before the fork, and every tensor the
@@ -1137,6 +1231,10 @@ class StackEngine:
         if (self.fp8 and not DETERMINISTIC_WGRAD and amax is not None and src.q is not None and conv.stride == 1 and pk.coutp % 128 == 0
                 and src.CP == pk.cinp and pk.cinp % 128 == 0 and (min(conv.kernel, 2) - 1) * conv.dilation <= 32):
             f8 = self._dy_e4m3(dy_hi, amax)          # on the current (main) stream, before the fork
+        if defer:
+            self._deferred.append({'conv': conv, 'pk': pk, 'dy_hi': dy_hi, 'dy_lo': dy_lo, 'halo': halo, 'Tout': Tout, 'src': src,
+                                   'f8': f8, 'order': len(self._deferred) * -1, 'token': self.deferred.token()})
+            return
         if not self.overlap_wgrad or not dy_hi.is_cuda:
             return self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads, f8=f8)
         main = self._main_stream or torch.cuda.current_stream(dy_hi.device)
@@ -1151,7 +1249,7 @@ class StackEngine:
         self._held.extend(t for t in (dy_hi, dy_lo, src.hi, src.lo) + ((src.q,) + f8 if f8 else ()) if t is not None)
         self._side_used = True
 
-    def _wgrad_now(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, grads, fork=None, f8=None):
+    def _wgrad_now(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, grads, fork=None, f8=None, sink=None):
         """dW through w2l_conv1d_wgrad, written in the parameter's own physical layout when possible.
         fork=(main, side): allocate on main, launch on side after an event recorded on main."""
         w = conv.weight
@@ -1205,9 +1303,9 @@ class StackEngine:
                 self._held.append(recycled)
                 with torch.cuda.stream(fork[1]):
                     return self._wgrad_launch(conv, pk, recycled, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride,
-                                              x_rows_total, dy_bstride, row_off, direct, ws, f8)
+                                              x_rows_total, dy_bstride, row_off, direct, ws, f8, sink)
             return self._wgrad_launch(conv, pk, recycled, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total,
-                                      dy_bstride, row_off, direct, ws, f8)
+                                      dy_bstride, row_off, direct, ws, f8, sink)
         if fork is not None:
             # allocated on the main stream (the caching allocator then owns it there), zero-filled on the side stream:
             # the fill of a split-K gradient is as far off the critical path as the kernel that accumulates into it
@@ -1220,14 +1318,14 @@ class StackEngine:
                 if need_zero:
                     dw.zero_()
                 return self._wgrad_launch(conv, pk, dw, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total,
-                                          dy_bstride, row_off, direct, ws, f8)
+                                          dy_bstride, row_off, direct, ws, f8, sink)
         alloc = torch.zeros if need_zero else torch.empty
         dw = alloc(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
         return self._wgrad_launch(conv, pk, dw, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total, dy_bstride,
-                                  row_off, direct, ws, f8)
+                                  row_off, direct, ws, f8, sink)
 
     def _wgrad_launch(self, conv, pk, dw, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total, dy_bstride, row_off,
-                      direct, ws, f8=None):
+                      direct, ws, f8=None, sink=None):
         w = conv.weight
         cout, cin, kw = w.shape
         N = src.N
@@ -1256,6 +1354,8 @@ class StackEngine:
         g = dw.permute(1, 2, 0)                     # logical [CoutP, CinP, Kw]
         if not direct:
             g = g[:cout, :cin, :]
+        if sink is not None:                        # a deferred gradient: reduced / applied by flush_deferred, not by autograd
+            return sink(w, g, dw)
         self._set(grads, w, g, storage=dw)
 
     def _dgrad_fused(self, conv: ConvSpec, pk: _PackedW, dy_hi, halo, hb, per, flat_rows, total, dxp, src: Act, producer,

@@ -9,7 +9,15 @@ and tags each weight's operand pack with an event; the step engine waits for a l
 first convolution (engine.pack_weights).  The next forward therefore starts as soon as layer 0 is updated, and the other
 20 updates stream through HBM underneath it.  This is opt-in (``optimizer.overlap = True``; trainer.Trainer and bench.py
 do): ``join()`` (also called by ``state_dict``) makes the caller's stream wait for the updates in flight, and anything
-that reads the parameters outside the step engine must call it first."""
+that reads the parameters outside the step engine must call it first.
+
+``defer_wgrad(model, k)`` goes one step further: the weight gradients of the model's top ``k`` conv units are not computed
+in backward at all but at the start of the NEXT forward pass, on the weight-gradient stream, each followed by this
+optimizer's fused update of that weight (engine.StackEngine.flush_deferred).  The top layers are the first of the backward
+pass and the last of the forward pass, so their gradients are the ones with slack; launched beside the forward they give
+the matrix cores work while the forward's own BatchNorm / CTC kernels run.  One optimizer step per batch, as before: a
+layer's forward convolution waits for the event behind its update.  ``p.grad`` of those weights stays ``None`` (the update
+consumes the gradient directly); ``join()`` flushes whatever is pending."""
 from __future__ import annotations
 
 import os
@@ -49,7 +57,65 @@ class FusedSGD(torch.optim.SGD):
             self.__dict__['_w2l_side'] = st
         return st
 
+    # ------------------------------------------------------------------ deferred weight gradients
+    def _deferred_state(self):
+        st = self.__dict__.get('_w2l_deferred')
+        if st is None:
+            st = {'seq': 0, 'hp': {}, 'engines': []}
+            self.__dict__['_w2l_deferred'] = st
+        return st
+
+    def defer_wgrad(self, model, units):
+        """hold back the weight gradients of some of ``model``'s conv units until its next forward pass: an int k = the top k
+        units, an iterable of unit indices (negative: counted from the top) = exactly those; 0 / empty switches it off"""
+        self.join()
+        units = int(units) if isinstance(units, int) else frozenset(int(u) for u in units)
+        model._defer_wgrad = units
+        model._deferred_opt = self if units else None
+
+    def _register_engine(self, eng):
+        engines = self._deferred_state()['engines']
+        if not any(e is eng for e in engines):
+            engines.append(eng)
+
+    def accepts(self, p) -> bool:
+        """would step() take this parameter through the fused conv-weight update?"""
+        hp = self._deferred_state()['hp'].get(id(p))
+        if hp is None:
+            for group in self.param_groups:
+                ok = group['momentum'] != 0 and group['dampening'] == 0 and not group.get('maximize', False)
+                for q in group['params']:
+                    self._deferred_state()['hp'][id(q)] = [ok, group, None]
+            hp = self._deferred_state()['hp'].get(id(p))
+        return bool(hp is not None and hp[0] and self.overlap and p.is_cuda and p.dtype == torch.float32 and _is_tap_major(p)
+                    and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0)
+
+    def token(self) -> int:
+        return self._deferred_state()['seq']
+
+    def stepped(self, token: int) -> bool:
+        """has step() run since ``token`` was drawn (i.e. since the backward pass that deferred a gradient)?"""
+        return self._deferred_state()['seq'] > token
+
+    @torch.no_grad()
+    def apply(self, p, g):
+        """the fused update of ONE conv weight with gradient ``g``, on the current stream (the stream that produced ``g``),
+        with the hyper-parameters of the last step() call"""
+        ok, group, hp = self._deferred_state()['hp'][id(p)]
+        lr, mu, wd, nesterov = hp
+        pk = self._fused_conv(p, g, lr, mu, wd, nesterov)
+        pk.ready = torch.cuda.Event()
+        pk.ready.record(torch.cuda.current_stream(p.device))
+
     def join(self):
+        """make the current stream wait for every update of the last step: deferred weight gradients are launched and
+        applied first, then the weight-gradient stream and the optimizer's side stream are joined"""
+        for eng in self._deferred_state()['engines']:
+            eng.flush_deferred()
+            eng.join_side()
+        self._join_updates()
+
+    def _join_updates(self):
         """make the current stream wait for the updates still running on the optimizer's side stream"""
         st = self._side_state()
         if st['pending'] and st['stream'] is not None:
@@ -78,11 +144,17 @@ class FusedSGD(torch.optim.SGD):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        self.join()                  # (normally a no-op: the forward pass has already waited for every event)
+        self._join_updates()         # (normally a no-op: the forward pass has already waited for every event)
         st = self._side_state()
+        dst = self._deferred_state()
+        dst['seq'] += 1              # gradients deferred by the backward pass just run now count as "stepped"
         for group in self.param_groups:
             lr, mu, wd = group['lr'], group['momentum'], group['weight_decay']
             nesterov, dampening, maximize = group['nesterov'], group['dampening'], group.get('maximize', False)
+            for p in group['params']:                     # what a deferred update of this step is applied with
+                ent = dst['hp'].get(id(p))
+                if ent is not None:
+                    ent[2] = (lr, mu, wd, nesterov)
             fused_ok = mu != 0 and dampening == 0 and not maximize
             rest, fused = [], []
             for p in group['params']:

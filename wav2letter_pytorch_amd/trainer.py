@@ -92,6 +92,11 @@ class Trainer:
         model._optimizers = opt
         if hasattr(opt, 'overlap'):          # optim.FusedSGD: weight updates stream under the next forward pass
             opt.overlap = True
+            # ... and the top units' weight gradients run beside it (W2L_DEFER_WGRAD=k, 0 = off; default: 4 of a deep stack)
+            n_units = len(model.engine().units) if hasattr(model, 'engine') else 0
+            k = int(os.environ.get('W2L_DEFER_WGRAD', min(4, n_units // 4)))
+            if k and hasattr(opt, 'defer_wgrad'):
+                opt.defer_wgrad(model, k)
         join = getattr(opt, 'join', lambda: None)
         first_epoch = 0
         ckpt_path = ckpt_path or self.resume_from_checkpoint
