@@ -390,8 +390,35 @@ def features_fixture():
     print('features.npz', [out[f'spect{i}'].shape for i in range(4)], float(np.abs(out['spect1']).max()))
 
 
+def jasper_nomask_fixture():
+    """Jasper blocks with ``conv_mask: False`` (jasper.py:446 -> plain nn.Conv1d, :288-298; un-masked loop :393-397)
+    between masked ones: masked stride-2 prologue, an UN-masked residual block with two repeats (sees the prologue's
+    un-masked output, passes the lengths through), a masked residual block behind it, and an un-masked last block.
+    State-dict keys of the plain convs carry no ``.conv``.  (An un-masked STRIDED block leaves the lengths un-halved and the
+    reference's CTC call then fails -- input_lengths > T' -- so the strided block stays masked.)"""
+    _install_stubs()
+    from jasper import Jasper
+    from data import label_sets
+    labels = label_sets.labels_map['english_lowercase']
+    blocks = [dict(layer_size=64, kernel_size=11, stride=2, residual=False, separable=False),
+              dict(layer_size=64, kernel_size=13, stride=1, residual=True, separable=False, repeat=2, conv_mask=False),
+              dict(layer_size=128, kernel_size=5, stride=1, residual=True, separable=False, repeat=2),
+              dict(layer_size=128, kernel_size=7, stride=1, residual=True, separable=False, conv_mask=False)]
+    torch.manual_seed(23)
+    model = Jasper(model_cfg('jasper', labels, mid_layers=4, jasper_blocks=blocks))
+    x, il, tg, tl = batch(3, 150, 123, True, smax_cap=None)
+    il[1] = 61                                   # shorter than T' = 75: the masked block really masks
+    x[1, :, 61:] = 0
+    tl = torch.minimum(tl, torch.tensor([20, 20, 20], dtype=torch.int32))
+    for n in range(3):
+        tg[n, int(tl[n]):] = 0
+    run_model_case(model, x, il, tg, tl, labels, 'jasper_nomask.npz', dict(case='jasper_nomask', blocks=blocks, mid_layers=4, seed=23))
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'novograd':
+    if len(sys.argv) > 1 and sys.argv[1] == 'jasper_nomask':
+        jasper_nomask_fixture()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'novograd':
         novograd_fixture()
     elif len(sys.argv) > 1 and sys.argv[1] == 'features':
         features_fixture()

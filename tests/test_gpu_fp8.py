@@ -275,7 +275,9 @@ def test_w2l_full_table_fp8_gradients_vs_oracle():
     Asserted: loss within 5e-2 of both; finite gradients; the classifier's gradient (above every e4m3 backward) within 0.15 /
     0.99 of the model's; and per conv weight the device is no further from the e4m3 model than 1.25 x (c) + 0.05 in relative
     L2 and its cosine with both oracles is no lower than (c)'s cosine - 0.1: the device adds nothing to the arithmetic's own
-    noise.  The training signal as a whole is judged where it matters, on the loss curve: test_fp8_training_tracks_bf16."""
+    noise.  (No absolute floor is asked of the 20-deep chain: the ABSOLUTE bound is per layer, teacher-forced --
+    test_w2l_full_table_fp8_layerwise_vs_operand_model: every layer within 1.5e-2 / 0.03 / 0.999 of the model.)  The training
+    signal as a whole is judged where it matters, on the loss curve: test_fp8_training_tracks_bf16."""
     from gpu_helpers import device_dropout_masks, device_gates, device_step, l2_cos
     from oracle import w2l_oracle as O
     from wav2letter_pytorch_amd import engine as E
@@ -317,7 +319,7 @@ def test_w2l_full_table_fp8_gradients_vs_oracle():
     for k in wkeys[:-1]:
         (l2m, cosm), (l2f, cosf), (l2a, cosa) = vs['e4m3_model'][k], vs['fp32'][k], arith[k]
         assert l2m <= 1.25 * l2a + 0.05, (k, l2m, l2a)
-        assert cosm >= cosa - 0.15 and cosf >= cosa - 0.15 and min(cosm, cosf) > 0.45, (k, cosm, cosf, cosa)
+        assert cosm >= cosa - 0.15 and cosf >= cosa - 0.15, (k, cosm, cosf, cosa)
 
 
 def test_fp8_training_tracks_bf16():
@@ -399,6 +401,13 @@ def test_jasper10x5_fp8_T16000():
         names = [n for n, *_ in E.KERNEL_TIMER]
     finally:
         E.KERNEL_TIMER = None
+    # the first two blocks' activations (the bf16 stride-2 prologue + the five e4m3 units and the residual of block 1) against
+    # the oracle's operand model, free-running from the same spectrogram: T' = 8 000 frames through the time-tiled e4m3 kernels
+    first = []
+    for i in range(6):
+        act, uc = ectx['acts'][i + 1], ectx['units'][i]
+        a = act.hi[:, act.pad_l:act.pad_l + act.T, :act.C].float().transpose(1, 2).cpu()
+        first.append((a, None if uc.lens_out is None else uc.lens_out.cpu().long()))
     del ectx
     # which convolutions qualify for e4m3 operands (engine._conv_forward / _dgrad / _wgrad): stride 1, 128 | C_in, 128 | C_out
     q = 0
@@ -422,6 +431,102 @@ def test_jasper10x5_fp8_T16000():
     print(f'jasper10x5 fp8 T=16000: loss {float(loss):.4f} vs oracle {float(ls):.4f} ({e_loss:.4f}), '
           f'log-probs {scale_err(out.cpu().numpy(), lp.numpy()):.3f} of scale')
     assert e_loss < 5e-2
+
+    def conv(xx, w, b, stride=1, padding=0, dilation=1):
+        if stride == 1 and w.shape[1] % 128 == 0:
+            return O.fp8_conv1d(xx, w, b, stride=stride, padding=padding, dilation=dilation, act_scale=8.0)
+        return O.bf16_conv1d(xx, w, b, stride=stride, padding=padding, dilation=dilation, round_out=False)
+
+    inter = []
+    with torch.no_grad():
+        work = {k: v.clone() for k, v in sd.items()}
+        cur, lens = x, il
+        for b in range(2):
+            cur, lens = O.jasper_block_forward(cur, lens, work, f'jasper_encoder.{b}.', blocks[b], training=True, inter=inter,
+                                               conv=conv, stats_before_rounding=True)
+    errs = []
+    for (a, ln), ref in zip(first, inter):
+        if ln is not None:
+            ref = ref * (torch.arange(ref.shape[2])[None, None, :] < ln[:, None, None])
+        errs.append(scale_err(a.numpy(), ref.numpy()))
+    print('jasper10x5 fp8 T=16000: first six activations vs the e4m3 operand model ' + ' '.join(f'{e:.3f}' for e in errs))
+    assert errs[0] < 1e-2 and max(errs) < 6e-2, errs
+
+
+def _teacher_forced_w2l_layers(layers, sd, x, il, tg, tl):
+    """the fp32 oracle's Wav2Letter step kept layer by layer: every layer's input and the gradient of the loss wrt its output"""
+    from oracle import w2l_oracle as O
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running' not in k}
+    work = {k: v.clone() for k, v in sd.items()}
+    work.update(params)
+    cur = x
+    rec = []
+    for i, (c, k, s_, d, p) in enumerate(layers):
+        out = O.conv1d_block_forward(cur, work, f'conv1ds.conv1d_{i}.', stride=s_, dilation=d, bn=True, activation=True,
+                                     training=True)
+        out.retain_grad()
+        rec.append(dict(x=cur, out=out))
+        cur = out
+    y = O.conv1d_block_forward(cur, work, f'conv1ds.conv1d_{len(layers)}.', stride=1, dilation=1, bn=False, activation=False,
+                               training=True)
+    lp = torch.log_softmax(y.transpose(1, 2), dim=-1)
+    O.ctc_criterion(lp, tg, il // 2, tl).backward()
+    return rec
+
+
+def test_w2l_full_table_fp8_layerwise_vs_operand_model(monkeypatch):
+    """The per-layer bound that the whole-table comparison above cannot give (20 chained e4m3 layers are chaotic at the e4m3
+    grain): every Conv1dBlock of the 21-layer table on its own, in ``precision: fp8`` with e4m3 forward, data and weight
+    gradients, teacher-forced from the fp32 oracle's layer input (rounded to bf16) and upstream gradient, against the
+    oracle's e4m3 operand model of that one layer with the device's clamp gates replayed: output within 1.5e-2 of scale,
+    input and weight gradients within 0.03 in the L2 norm, cosine >= 0.999 (measured 0.003-0.007 / 0.001-0.005 / 1.0000; the
+    64-mel stride-2 first layer runs in bf16)."""
+    from gpu_helpers import device_gates, l2_cos
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd import engine as E
+    layers = [l[:4] + (0.0,) for l in O.W2L_LAYERS]
+    sd = O.init_wav2letter_state(layers, seed=0)
+    model = build_w2l(layers, sd, 'fp8').train()
+    x, il, tg, tl = O.synthetic_batch(4, 1000, seed=1, s_lo=83, s_hi=166)
+    rec = _teacher_forced_w2l_layers(layers, sd, x, il, tg, tl)
+    monkeypatch.setattr(E, 'FP8_DGRAD', '1')
+    monkeypatch.setattr(E, 'FP8_WGRAD', '1')
+    rows = []
+    for i, (blk, r, (c, k, s_, d, p)) in enumerate(zip(model.conv1ds.children(), rec, layers)):
+        f8 = s_ == 1 and r['x'].shape[1] % 128 == 0
+        blk.precision = 'fp8'
+        blk._debug_keep_ctx = True
+        xin = r['x'].detach().to(torch.bfloat16).float()
+        gout = r['out'].grad
+        xd = xin.cuda().requires_grad_(True)
+        out = blk(xd)
+        out.backward(gout.cuda())
+        ectx = blk._last_ctx
+        gate = device_gates(ectx)[0]
+        assert (ectx['acts'][0].q is not None) == f8, i
+        blk._last_ctx = None
+        del ectx
+        prefix = f'conv1ds.conv1d_{i}.'
+        params = {kk: v.clone().requires_grad_(True) for kk, v in sd.items()
+                  if kk.startswith(prefix) and v.dtype.is_floating_point and 'running' not in kk}
+        work = {kk: v.clone() for kk, v in sd.items() if kk.startswith(prefix)}
+        work.update(params)
+        xm = xin.clone().requires_grad_(True)
+        conv = ((lambda *a, **kw: O.fp8_conv1d(*a, round_dx=True, **kw)) if f8 else
+                (lambda *a, **kw: O.bf16_conv1d(*a, round_out=False, **kw)))
+        mo = O.conv1d_block_forward(xm, work, prefix, stride=s_, dilation=d, bn=True, activation=True, training=True, gate=gate,
+                                    conv=conv, stats_before_rounding=True)
+        mo.backward(gout)
+        e_out = scale_err(out.detach().cpu().numpy(), mo.detach().numpy())
+        gx = l2_cos(xd.grad.cpu().numpy(), xm.grad.numpy())
+        gw = l2_cos(blk.conv1.weight.grad.cpu().numpy(), params[prefix + 'conv1.weight'].grad.numpy())
+        rows.append((i, e_out, gx, gw))
+        out_tol, l2_tol, cos_tol = 1.5e-2, 0.03, 0.999       # measured on MI355X: 0.003-0.007 | 0.001-0.005 | 1.0000, e4m3 and bf16 layers alike
+        assert e_out < out_tol and gx[0] < l2_tol and gx[1] > cos_tol and gw[0] < l2_tol and gw[1] > cos_tol, (i, e_out, gx, gw)
+        blk.zero_grad(set_to_none=True)
+        blk.__dict__.pop('_solo_engine', None)
+    print('fp8 table, layer by layer vs the e4m3 operand model (output err | dx L2/cos | dw L2/cos): '
+          + ' '.join(f'{i}:{e:.3f}|{gx[0]:.3f}/{gx[1]:.4f}|{gw[0]:.3f}/{gw[1]:.4f}' for i, e, gx, gw in rows))
 
 
 def test_jasper_fp8_long_utterance_T16000():

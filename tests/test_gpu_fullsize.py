@@ -296,6 +296,145 @@ def test_jasper10x5_blockwise_fp32():
     print(f'jasper10x5 blockwise fp32: worst L2 error of an input gradient {worst_in:.2e}, of a parameter gradient {worst_p:.2e}')
 
 
+def _bf16r(t):
+    return t.to(torch.bfloat16).float()
+
+
+def _operand_model_conv(mode):
+    """the dense-convolution stand-in of the oracle's Jasper blocks for ``precision: bf16`` / ``fp8``: which convolutions
+    take e4m3 operands follows engine._conv_forward (stride 1, 128 | C_in; ReLU activations carry scale 8)"""
+    from oracle import w2l_oracle as O
+
+    def conv(x, w, b, stride=1, padding=0, dilation=1):
+        if mode == 'fp8' and stride == 1 and w.shape[1] % 128 == 0:
+            return O.fp8_conv1d(x, w, b, stride=stride, padding=padding, dilation=dilation, act_scale=8.0, round_dx=True)
+        return O.bf16_conv1d(x, w, b, stride=stride, padding=padding, dilation=dilation, round_out=False)
+
+    return conv
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'fp8'])
+def test_jasper10x5_blockwise_operand_model(mode, monkeypatch):
+    """Jasper 10x5 (BASELINE configs 4 / 5) in its PRODUCTION arithmetic, block by block, teacher-forced, against a model of
+    that arithmetic -- the oracle's blocks with every dense convolution replaced by the bf16 / e4m3 operand model
+    (oracle.bf16_conv1d / fp8_conv1d: operands rounded where the engine rounds them, fp32 accumulation, BatchNorm statistics
+    from the accumulators, y / dy / dx stored as bf16 tensors).  Each of the 13 blocks runs on the device as a stand-alone
+    JasperBlock in ``precision: <mode>`` from the fp32 oracle's block input (rounded to bf16: what the previous block's
+    BatchNorm kernel would have stored) and backward from the fp32 oracle's upstream gradient; the model does the same on
+    the CPU with the device's ReLU gates replayed.  fp8: forward, data and weight gradients of every qualifying convolution
+    on e4m3 operands (the first convolutions of a block included: an open fp8 engine quantises its input like the network
+    does).  Bounds: block output within 1e-2 (bf16) / 6e-2 (fp8: five chained quantisers) of scale, input and parameter
+    gradients within 0.03 / 0.10 in the L2 norm and cosine >= 0.999 / 0.995; in fp8 mode every unit of a five-repeat block is
+    held to the model on its own as well (1e-2 / 0.03 / 0.999)."""
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd import engine as E
+    blocks, sd = _jasper10x5()
+    model = build_jasper(blocks, sd, mode).train()
+    x, il, tg, tl = O.synthetic_batch(2, 1000, seed=99)
+    il[1] = 801
+    x[1, :, 801:] = 0
+    rec, lp, ol, loss, pgrads, xgrad = _oracle_jasper_blocks(x, il, tg, tl, sd, blocks)
+    monkeypatch.setattr(E, 'FP8_DGRAD', '1')
+    monkeypatch.setattr(E, 'FP8_WGRAD', '1')
+    conv = _operand_model_conv(mode)
+    # fp8, a block of FIVE chained e4m3 units: measured 0.032-0.041 / 0.059 / 0.9983 (one-unit blocks: 0.003-0.005 / 0.005 /
+    # 1.0000); the per-unit bound below is the tight one (1e-2 / 0.03 / 0.999)
+    out_tol, l2_tol, cos_tol = (1e-2, 0.03, 0.999) if mode == 'bf16' else (6e-2, 0.10, 0.995)
+    worst = dict(out=0.0, l2=0.0, cos=1.0)
+    report, failed, unit_rows = [], [], []
+    for i, (blk, r) in enumerate(zip(model.jasper_encoder, rec)):
+        blk.precision = mode
+        blk._debug_keep_ctx = True
+        xin = _bf16r(r['x'].detach())
+        gout = r['out'].grad
+        xd = xin.cuda().requires_grad_(True)
+        out, lens_out = blk((xd, r['lens']))
+        out.backward(gout.cuda())
+        ectx = blk._last_ctx
+        gates = device_gates(ectx, relu=True)
+        if mode == 'fp8':          # every stride-1 convolution with 128 | C_in of the block ran on e4m3 operands
+            want_q = sum(1 for u in ectx['units'] for c in (u.unit.main, u.unit.res)
+                         if c is not None and c.stride == 1 and c.cin % 128 == 0)
+            have_q = sum(1 for u in ectx['units'] for c, a in ((u.unit.main, ectx['acts'][u.unit.src]),
+                                                               (u.unit.res, ectx['acts'][u.unit.res_src] if u.unit.res else None))
+                         if c is not None and a is not None and a.q is not None and c.stride == 1)
+            assert want_q == have_q and (want_q > 0 or i == 0), (i, want_q, have_q)
+        del ectx
+        blk._last_ctx = None
+        prefix = f'jasper_encoder.{i}.'
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+                  if k.startswith(prefix) and v.dtype.is_floating_point and 'running' not in k}
+        work = {k: v.clone() for k, v in sd.items() if k.startswith(prefix)}
+        work.update(params)
+        xm = xin.clone().requires_grad_(True)
+        inter = []
+        mo, mlens = O.jasper_block_forward(xm, r['lens'], work, prefix, blocks[i], training=True, gates=list(gates), conv=conv,
+                                           stats_before_rounding=True, inter=inter)
+        for a in inter:
+            a.retain_grad()
+        mo.backward(gout)
+        assert torch.equal(lens_out.cpu().float(), mlens.float()), i
+        e_out = scale_err(out.detach().cpu().numpy(), mo.detach().numpy())
+        l2, cos = l2_cos(xd.grad.cpu().numpy(), xm.grad.numpy())
+        worst['out'] = max(worst['out'], e_out)
+        report.append((i, e_out, l2, cos))
+        failed += [(i, 'out', e_out)] if e_out >= out_tol else []
+        rows = [('x', l2, cos)]
+        for k, p in blk.named_parameters():
+            rows.append((k, *l2_cos(p.grad.cpu().numpy(), params[prefix + k].grad.numpy())))
+        for name, l2, cos in rows:
+            worst['l2'], worst['cos'] = max(worst['l2'], l2), min(worst['cos'], cos)
+            failed += [(i, name, l2, cos)] if not (l2 < l2_tol and cos > cos_tol) else []
+        blk.zero_grad(set_to_none=True)
+        if mode == 'fp8' and len(inter) > 1:
+            # five chained e4m3 units drift apart like any chain of quantisers (test_gpu_fp8.py): hold every UNIT to the model
+            # as well -- units 0 .. repeat-2 of the block (the last one carries the residual branch), each as a one-unit
+            # engine from the model's own unit input (rounded to bf16) and the model's gradient wrt the unit's output
+            from wav2letter_pytorch_amd.engine import StackEngine, UnitSpec
+            from wav2letter_pytorch_amd.layers import run_stack
+            us = blk.units(0, 1, 'blk', mask_last_output=False)
+            for ur in range(len(inter) - 1):
+                uin = xin if ur == 0 else _bf16r(inter[ur - 1].detach())
+                gu = inter[ur].grad
+                u = us[ur]
+                eng = StackEngine([UnitSpec(main=u.main, src=0, act=u.act, update_lens=u.update_lens, mask_out=False)], None, 0,
+                                  fp8=True)
+                ud = uin.cuda().requires_grad_(True)
+                uo, _, uctx = run_stack(eng, ud, r['lens'], True, keep_ctx=True)
+                uo.backward(gu.cuda())
+                ugate = device_gates(uctx, relu=True)
+                assert uctx['acts'][0].q is not None
+                del uctx
+                mini = {'u.mconv.0.conv.weight': sd[f'{prefix}mconv.{4 * ur}.conv.weight'].clone().requires_grad_(True)}
+                for kk in ('weight', 'bias', 'running_mean', 'running_var'):
+                    mini[f'u.mconv.1.{kk}'] = sd[f'{prefix}mconv.{4 * ur + 1}.{kk}'].clone()
+                mini['u.mconv.1.weight'].requires_grad_(True)
+                mini['u.mconv.1.bias'].requires_grad_(True)
+                one = dict(kernel_size=mini['u.mconv.0.conv.weight'].shape[2], stride=1, dilation=blocks[i].get('dilation', 1),
+                           repeat=1, residual=False, separable=False)
+                um = uin.clone().requires_grad_(True)
+                umo, _ = O.jasper_block_forward(um, r['lens'], mini, 'u.', one, training=True, gates=list(ugate), conv=conv,
+                                                stats_before_rounding=True)
+                umo.backward(gu)
+                e_u = scale_err(uo.detach().cpu().numpy(), umo.detach().numpy())
+                gx = l2_cos(ud.grad.cpu().numpy(), um.grad.numpy())
+                gw = l2_cos(u.main.weight.grad.cpu().numpy(), mini['u.mconv.0.conv.weight'].grad.numpy())
+                unit_rows.append((i, ur, e_u, gx, gw))
+                failed += [(i, ur, 'unit', e_u, gx, gw)] if not (e_u < 1e-2 and gx[0] < 0.03 and gx[1] > 0.999
+                                                                 and gw[0] < 0.03 and gw[1] > 0.999) else []
+                blk.zero_grad(set_to_none=True)
+        blk.__dict__.pop('_solo_engine', None)
+    print(f'jasper10x5 blockwise {mode} vs its operand model: worst block output {worst["out"]:.2e} of scale, worst gradient '
+          f'L2 {worst["l2"]:.3f}, lowest cosine {worst["cos"]:.5f}; per block (output | dx L2/cos): '
+          + ' '.join(f'{i}:{e:.3f}|{l2:.3f}/{c:.4f}' for i, e, l2, c in report))
+    if unit_rows:
+        print('   unit by unit (one-unit engines, teacher-forced from the model): worst output %.2e, worst dx L2 %.4f / cosine %.5f, '
+              'worst dw L2 %.4f / cosine %.5f over %d units' % (max(r_[2] for r_ in unit_rows), max(r_[3][0] for r_ in unit_rows),
+                                                               min(r_[3][1] for r_ in unit_rows), max(r_[4][0] for r_ in unit_rows),
+                                                               min(r_[4][1] for r_ in unit_rows), len(unit_rows)))
+    assert not failed, failed
+
+
 def test_jasper10x5_whole_network_fp32():
     """the same step through Jasper.forward -> CTC -> backward as ONE engine (tuned kernels, split-K plans, residual
     fan-out): lengths bit-equal, loss within 1e-3, log-probs within the network's own sensitivity -- the oracle's response

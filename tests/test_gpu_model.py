@@ -324,6 +324,34 @@ def test_jasper_dense_golden(precision):
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_jasper_conv_mask_false_golden(precision):
+    """``conv_mask: False`` blocks (plain nn.Conv1d: no length masking, lengths passed through; jasper.py:288-298,393-397,446)
+    between masked ones: reference-generated fixture jasper_nomask.npz -- state-dict keys without ``.conv``, an un-masked
+    block reading a masked block's un-masked output, a masked block behind it, an un-masked block in front of the head"""
+    from gpu_helpers import build_jasper, compare_jasper_step
+    z = load('jasper_nomask.npz')
+    meta = ast.literal_eval(str(z['meta']))
+    sd = {k[3:]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith('p0/')}
+    assert 'jasper_encoder.1.mconv.0.weight' in sd and 'jasper_encoder.2.mconv.0.conv.weight' in sd
+    model = build_jasper(meta['blocks'], sd, precision).train()
+    assert set(model.state_dict()) == set(sd)
+    x = torch.from_numpy(z['x'])
+    il, tg, tl = (torch.from_numpy(z[k]) for k in ('in_lens', 'targets', 'target_lens'))
+    errs, stats, out, out_lens = compare_jasper_step(model, meta['blocks'], sd, x, il, tg, tl, precision)
+    check(errs, stats, precision)
+    np.testing.assert_array_equal(out_lens.numpy(), z['out_lens'])
+    assert scale_err(out.cpu().numpy(), z['log_probs']) < TOL[precision]['lp']
+    if precision == 'fp32':
+        check_fixture_grads(model, z)
+        model.eval()
+        with torch.no_grad():
+            oe, _ = model(x.cuda(), il)
+        assert scale_err(oe.cpu().numpy(), z['out_eval']) < 2e-3
+    with pytest.raises(AttributeError):          # jasper.py:458 reads mconv[0].conv.stride: a bare Conv1d has no .conv
+        model.scaling_factor
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_jasper_separable_golden(precision):
     """the shipped jasper.yaml form: depthwise (k32->33 / k38->39, stride 2 first) + pointwise convs, residual,
     masking with an odd ragged length (float length arithmetic): reference-generated fixture jasper_sep2.npz"""

@@ -59,7 +59,7 @@ def test_w2l_end_to_end_matches_reference(case):
     np.testing.assert_allclose(lp_eval.numpy(), z['out_eval'], rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize('case', ['jasper_sep2', 'jasper_dense'])
+@pytest.mark.parametrize('case', ['jasper_sep2', 'jasper_dense', 'jasper_nomask'])
 def test_jasper_end_to_end_matches_reference(case):
     z = load(case + '.npz')
     meta = meta_of(z)

@@ -564,9 +564,22 @@ class StackEngine:
         cp0 = padded_channels(C0)
         a_hi = torch.empty(N, pl + T0 + pr, cp0, dtype=torch.bfloat16, device=dev)
         a_lo = torch.empty_like(a_hi) if precise else None
-        check(lib.w2l_nct_to_ntc(ptr(x), N, C0, T0, cp0, pl, pr, mode, ptr(lens_dev), ptr(a_hi), ptr(a_lo), st()),
+        # the input is masked by its lengths only if a MaskedConv1d reads it (a block of plain convolutions sees it whole)
+        if lens_dev is not None and not any((u.src == 0 and u.update_lens) for u in self.units):
+            in_mask = None
+        else:
+            in_mask = lens_dev
+        check(lib.w2l_nct_to_ntc(ptr(x), N, C0, T0, cp0, pl, pr, mode, ptr(in_mask), ptr(a_hi), ptr(a_lo), st()),
               'w2l_nct_to_ntc')
-        acts: List[Act] = [Act(a_hi, a_lo, N, T0, C0, cp0, pl, pr, mode, lens_dev)]
+        acts: List[Act] = [Act(a_hi, a_lo, N, T0, C0, cp0, pl, pr, mode, in_mask)]
+        if self.fp8 and self.head is None and self.units and cp0 % 128 == 0 and self._fp8_consumers(0):
+            # an OPEN stack in fp8 mode (a Conv1dBlock / JasperBlock called on its own): inside a network the block's input
+            # is the previous block's activation and carries an e4m3 copy at that activation's scale; give the caller's
+            # tensor the same, so that the block's first convolutions run on e4m3 operands as they do in the network
+            a0 = acts[0]
+            a0.q = torch.empty(a_hi.shape, dtype=torch.uint8, device=dev)
+            a0.q_scale = FP8_ACT_SCALE[self.units[0].act]
+            check(lib.w2l_quantize_e4m3(ptr(a_hi), 0, a_hi.numel(), a0.q_scale, ptr(a0.q), st()), 'w2l_quantize_e4m3')
 
         for ui, u in enumerate(self.units):
             uc = _UnitCtx(unit=u)

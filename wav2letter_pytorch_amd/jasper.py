@@ -6,8 +6,10 @@ even kernel sizes are bumped to odd (jasper.py:53-58), lengths are updated with 
 (:109-112), eval mode returns softmax instead of log-softmax (:470-473), NaN assert (:474).
 
 Only what ``Jasper._build_encoder`` can reach is executable (jasper.py:440-449): batch
-normalisation, ReLU, 'add' residual from the block input, conv_mask, dense or separable convs;
-separable blocks run a depthwise kernel (csrc/dwconv.hip) followed by the 1x1 pointwise implicit GEMM."""
+normalisation, ReLU, 'add' residual from the block input, masked (``conv_mask: True``, the default) or plain
+(``conv_mask: False``: bare ``Conv1d`` modules whose keys carry no ``.conv``, no length masking, lengths passed through
+unchanged -- jasper.py:288-298,393-397) convolutions, dense or separable; separable blocks run a depthwise kernel
+(csrc/dwconv.hip) followed by the 1x1 pointwise implicit GEMM."""
 from __future__ import annotations
 
 from typing import List
@@ -148,8 +150,6 @@ class JasperBlock(nn.Module):
             raise NotImplementedError('groups / heads / dense residual / max residual are not reachable from the config')
         if activation is not None and not isinstance(activation, nn.ReLU):
             raise NotImplementedError('Jasper._build_encoder always passes nn.ReLU() (jasper.py:448)')
-        if not conv_mask:
-            raise NotImplementedError('conv_mask=False (plain nn.Conv1d blocks) is not built; the config default is True')
         kernel_size_factor = float(kernel_size_factor)
         if type(kernel_size) in (list, tuple):
             kernel_size = [compute_new_kernel_size(k, kernel_size_factor) for k in kernel_size][0]
@@ -185,8 +185,11 @@ class JasperBlock(nn.Module):
 
     def _get_conv(self, in_channels, out_channels, kernel_size=11, stride=1, dilation=1, padding=0, bias=False,
                   groups=1):
+        if not self.conv_mask:            # jasper.py:288-298: a bare nn.Conv1d -- no mask, no length update, key ``mconv.{j}.weight``
+            return Conv1d(in_channels, out_channels, kernel_size, stride=stride, dilation=dilation, padding=padding,
+                          bias=bias, groups=groups, init='xavier_uniform')
         return MaskedConv1d(in_channels, out_channels, kernel_size, stride=stride, dilation=dilation, padding=padding,
-                            bias=bias, groups=groups, use_mask=self.conv_mask)
+                            bias=bias, groups=groups, use_mask=True)
 
     def _get_conv_bn_layer(self, in_channels, out_channels, kernel_size=11, stride=1, dilation=1, padding=0,
                            separable=False):
@@ -209,13 +212,14 @@ class JasperBlock(nn.Module):
         mods = list(self.mconv)
         groups = []                       # (depthwise MaskedConv1d or None, conv MaskedConv1d, BatchNorm1d)
         i = 0
+        bare = lambda m: m.conv if isinstance(m, MaskedConv1d) else m          # noqa: E731 -- the Conv1d parameter holder
         while i < len(mods):
-            if isinstance(mods[i], MaskedConv1d):
+            if isinstance(mods[i], (MaskedConv1d, Conv1d)):
                 if self.separable:
-                    groups.append((mods[i], mods[i + 1], mods[i + 2]))
+                    groups.append((bare(mods[i]), bare(mods[i + 1]), mods[i + 2]))
                     i += 3
                 else:
-                    groups.append((None, mods[i], mods[i + 1]))
+                    groups.append((None, bare(mods[i]), mods[i + 1]))
                     i += 2
             else:
                 i += 1
@@ -224,16 +228,18 @@ class JasperBlock(nn.Module):
         for r, (dwm, mc, bn) in enumerate(groups):
             last = r == len(groups) - 1
             if dwm is None:
-                spec = conv_spec(mc.conv, bn, self.padding_val, self.padding_val, PAD_ZERO, f'{name}.mconv{r}')
+                spec = conv_spec(mc, bn, self.padding_val, self.padding_val, PAD_ZERO, f'{name}.mconv{r}')
                 dws = None
             else:
-                dws = conv_spec(dwm.conv, None, self.padding_val, self.padding_val, PAD_ZERO, f'{name}.dw{r}', depthwise=True)
-                spec = conv_spec(mc.conv, bn, 0, 0, PAD_ZERO, f'{name}.pw{r}')
+                dws = conv_spec(dwm, None, self.padding_val, self.padding_val, PAD_ZERO, f'{name}.dw{r}', depthwise=True)
+                spec = conv_spec(mc, bn, 0, 0, PAD_ZERO, f'{name}.pw{r}')
+            # an activation is masked where it is WRITTEN, for the masked_fill of the MaskedConv1d that READS it
+            # (jasper.py:116-119): inside the block that is this block's own conv_mask, behind its last unit the next block's
             u = UnitSpec(main=spec, src=src, act=ACT_RELU, drop_p=float(self.dropout), update_lens=self.conv_mask,
-                         mask_out=self.conv_mask and not (last and not mask_last_output), dw=dws)
+                         mask_out=mask_last_output if last else self.conv_mask, dw=dws)
             if last and self.res is not None:
                 rc, rbn = self.res[0][0], self.res[0][1]
-                u.res = conv_spec(rc.conv, rbn, 0, 0, PAD_ZERO, f'{name}.res')
+                u.res = conv_spec(bare(rc), rbn, 0, 0, PAD_ZERO, f'{name}.res')
                 u.res_src = a_in
             out.append(u)
             src = next_act + r
@@ -246,6 +252,9 @@ class JasperBlock(nn.Module):
         if isinstance(xs, (list, tuple)):
             xs = xs[-1]
         eng = solo_engine(self, lambda: self.units(0, 1, 'block', mask_last_output=False))
+        if getattr(self, '_debug_keep_ctx', False):        # test hook: expose the engine's saved activations
+            out, lens_f, self._last_ctx = run_stack(eng, xs, lens, self.training, keep_ctx=True)
+            return out, lens_f
         out, lens_f = run_stack(eng, xs, lens, self.training)
         return out, lens_f
 
@@ -288,8 +297,9 @@ class Jasper(ConvCTCASR):
         a_in = 0
         blocks = list(self.jasper_encoder)
         for b, blk in enumerate(blocks):
-            # the classifier is a plain nn.Conv1d (jasper.py:433,468): the last block's output is NOT masked
-            us = blk.units(a_in, len(units) + 1, f'block{b}', mask_last_output=b != len(blocks) - 1)
+            # the classifier is a plain nn.Conv1d (jasper.py:433,468): the last block's output is NOT masked, and neither
+            # is the input of a block of plain convolutions (conv_mask: False)
+            us = blk.units(a_in, len(units) + 1, f'block{b}', mask_last_output=b != len(blocks) - 1 and blocks[b + 1].conv_mask)
             units += us
             a_in = len(units)
         head = conv_spec(self.final_layer[0], None, 0, 0, PAD_ZERO, 'head')

@@ -51,6 +51,9 @@ class Conv1dBlock(nn.Module):
     def forward(self, xs):
         """[N, C_in, T] -> [N, C_out, T'] fp32 (wav2letter.py:40-47)"""
         eng = solo_engine(self, lambda: [self.unit(0, 'conv1d')])
+        if getattr(self, '_debug_keep_ctx', False):        # test hook: expose the engine's saved activations
+            out, _, self._last_ctx = run_stack(eng, xs, None, self.training, keep_ctx=True)
+            return out
         out, _ = run_stack(eng, xs, None, self.training)
         return out
 
