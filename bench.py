@@ -58,9 +58,11 @@ def cpu_baseline(budget_s=20.0):
         t0 = time.perf_counter()
         O.wav2letter_step(x, il, tg, tl, sd, layers)
         times.append(time.perf_counter() - t0)
-    best = min(times)
+    best, mean = min(times), sum(times) / len(times)
     return {'value': round(N * T / best, 1), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': f'W2L mid_layers=20 fp32 N={N} T={T}: {nsteps} timed step(s) after 1 warm-up, best step {best:.3f}s, '
+            'mean_value': round(N * T / mean, 1),
+            'sample': f'W2L mid_layers=20 fp32 N={N} T={T}, dropout off (p = 0 in every layer; the GPU leg has the yaml dropout on): '
+                      f'{nsteps} timed step(s) after 1 warm-up, best step {best:.3f}s (value), mean step {mean:.3f}s (mean_value), '
                       f'torch CPU ops on {cores} threads of {os.cpu_count()} host cores'}
 
 
@@ -353,45 +355,7 @@ def main():
         step()
         fence()
 
-    # ---- which collective path?  Measured here, in this run, on this node: nobody is there to flip a switch on the first
-    # 8-GPU run.  k steps with the gradient collectives through torch.distributed (ProcessGroupNCCL: its own internal stream,
-    # the one stream of the step streams.py cannot probe), k steps through the C ABI's RCCL helpers (NativeComm: the collective
-    # is a launch on the reducer's probed stream); the faster one (slowest rank's time) serves the timed region.  The two
-    # communicators never have work in flight together: every switch sits between two fences (device sync + barrier).
     collective_paths = None
-    reducer0 = getattr(model, 'grad_reducer', None)
-    forced_native = os.environ.get('W2L_DP_NATIVE')
-    if (reducer0 is not None and reducer0.active and not args.no_collective_ab and not args.graph and forced_native is None):
-        k_ab = 5
-        collective_paths = {'torch.distributed': round(timed_ms(k_ab), 3), 'w2l_rccl_* (C ABI)': None}
-        comm, why = None, None
-        try:
-            comm = NativeComm.from_process_group()
-        except Exception as e:            # noqa: BLE001 -- reported in the line; the run goes on with torch.distributed
-            why = repr(e)
-        ok = torch.tensor([1.0 if comm is not None else 0.0], device=dev)
-        if world > 1:
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)            # all ranks or none
-        if float(ok) == 1.0:
-            fence()
-            reducer0.set_native(comm)
-            step()
-            step()                        # the communicator's first collectives (channel set-up) stay out of the timing
-            collective_paths['w2l_rccl_* (C ABI)'] = round(timed_ms(k_ab), 3)
-            if comm.rehearsal:
-                collective_paths['note'] = ('one-GPU rehearsal (W2L_DIST_BACKEND=gloo): the native path ran on one-rank '
-                                            'communicators, averaging nothing')
-            if collective_paths['w2l_rccl_* (C ABI)'] >= collective_paths['torch.distributed']:
-                reducer0.set_native(None)
-            collective_paths['kept'] = 'w2l_rccl_* (C ABI)' if reducer0._comm is not None else 'torch.distributed'
-            fence()
-            broadcast_parameters(model)   # replicas that stepped through a rehearsal communicator have drifted apart
-        else:
-            collective_paths['kept'] = 'torch.distributed'
-            collective_paths['native_unavailable'] = why or 'another rank could not create its communicator'
-            if comm is not None:
-                comm.close()
-        fence()
     if args.event_trace:
         from wav2letter_pytorch_amd import _lib
         fence()
@@ -479,23 +443,27 @@ def main():
         torch.cuda.synchronize()
         pstats.Stats(pr, stream=sys.stderr).sort_stats('tottime').print_stats(50)
         return
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    rank_ms = [elapsed / args.steps * 1e3]
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        every = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(every, t)
-        rank_ms = [float(v) / args.steps * 1e3 for v in every]
-        elapsed = max(float(v) for v in every)               # the job is as fast as its slowest rank
-    ms = elapsed / args.steps * 1e3
-    value = world * N * T / (elapsed / args.steps)
+    def timed_region():
+        """EXACTLY --steps steps between two fences (barrier + device sync on both sides); the job is as fast as its slowest rank"""
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss_ = step()
+        fence()
+        elapsed_ = time.perf_counter() - t0
+        rank_ms_ = [elapsed_ / args.steps * 1e3]
+        if world > 1:
+            t = torch.tensor([elapsed_], device=dev, dtype=torch.float64)
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            rank_ms_ = [float(v) / args.steps * 1e3 for v in every]
+            elapsed_ = max(float(v) for v in every)
+        return elapsed_ / args.steps * 1e3, rank_ms_, loss_
+
+    ms, rank_ms, loss = timed_region()
+    value = world * N * T / (ms * 1e-3)
 
     # ---- exposed communication: the same step with the gradient reducer detached (no collectives), same run, per rank ----
-    exposed_comm_ms = exposed_by_rank = None
+    exposed_comm_ms = exposed_by_rank = solo_ms = None
     reducer = getattr(model, 'grad_reducer', None)
     if reducer is not None and not args.graph:
         model.grad_reducer = None
@@ -507,7 +475,8 @@ def main():
             step()
         fence()
         solo = time.perf_counter() - t0
-        own = rank_ms[rank] - solo / k2 * 1e3                 # this rank's step with the collectives minus its step without
+        solo_ms = solo / k2 * 1e3
+        own = rank_ms[rank] - solo_ms                         # this rank's step with the collectives minus its step without
         exposed_by_rank = [round(v, 3) for v in gather_objects(dist, world, own)]
         exposed_comm_ms = max(exposed_by_rank)
         model.grad_reducer = reducer
@@ -658,13 +627,94 @@ def main():
                                     'deferred launch of a timed step is inside the timed region (the fences flush them)'},
             'rank_ms_per_step': [round(v, 3) for v in rank_ms],
             'exposed_comm_ms': None if exposed_comm_ms is None else round(exposed_comm_ms, 3),
+            # what a bandwidth-bound ring all-reduce of this step's gradients would take on xGMI: 2 (N-1)/N x bytes over ONE
+            # link's ~153 GB/s (point-to-point links: a ring is per-link bound) -- to read exposed_comm_ms against
+            'expected_ring_ms': (None if world < 2 else round(
+                2.0 * (world - 1) / world * sum(p.numel() for p in model.parameters()) * 4 / 153e9 * 1e3, 3)),
             'exposed_comm_ms_by_rank': exposed_by_rank,
             'tune_plans': (None if tune_shas is None else
                            {'shared_from_rank0': tune_path, 'sha16_by_rank': tune_shas, 'identical': len(set(tune_shas)) == 1}),
             'per_gpu_value': round(value / world, 1),
         }
-        sys.stdout.flush()
-        os.write(record_fd, (json.dumps(line) + '\n').encode())
+    else:
+        line = None
+
+    def emit():
+        if rank == 0:
+            sys.stdout.flush()
+            os.write(record_fd, (json.dumps(line) + '\n').encode())
+
+    # ---- which collective path?  Measured here, in this run, on this node: nobody is there to flip a switch on the first
+    # 8-GPU run.  The record above is complete and was measured with the gradient collectives through torch.distributed
+    # (ProcessGroupNCCL: its own internal stream, the one stream of the step streams.py cannot probe).  Now the same timed
+    # region once more through the C ABI's RCCL helpers (NativeComm: a collective is a launch on the reducer's probed stream);
+    # if that is faster it becomes the record.  RCCL through this path has never run more than one rank, so the leg is bounded:
+    # the communicator is created on a helper thread with a deadline, and a watchdog prints the record already in hand and
+    # ends the process (exit code 0: the timed region it reports did complete) should a native collective never return.  The
+    # two communicators never have work in flight together: every switch sits between two fences (device sync + barrier).
+    reducer0 = getattr(model, 'grad_reducer', None)
+    forced_native = os.environ.get('W2L_DP_NATIVE')
+    if (reducer0 is not None and reducer0.active and not args.no_collective_ab and not args.graph and forced_native is None):
+        import threading
+        leg_s = float(os.environ.get('W2L_AB_TIMEOUT', '150'))
+        native, via_torch = 'w2l_rccl_* (C ABI)', 'torch.distributed'
+        collective_paths = {via_torch: round(ms, 3), native: None, 'kept': via_torch}
+        if line is not None:
+            line['collective_paths_ms'] = collective_paths
+
+        def give_up():
+            collective_paths['native_unavailable'] = f'the native-collective leg did not finish within {leg_s:.0f} s: abandoned'
+            emit()
+            os._exit(0)
+
+        watchdog = threading.Timer(leg_s, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        box = {}
+
+        def create():
+            try:
+                box['comm'] = NativeComm.from_process_group()
+            except Exception as e:        # noqa: BLE001 -- reported in the line; the run keeps torch.distributed
+                box['why'] = repr(e)
+
+        th = threading.Thread(target=create, daemon=True)
+        th.start()
+        th.join(min(60.0, leg_s / 2))
+        comm = box.get('comm') if not th.is_alive() else None
+        why = box.get('why') or ('communicator creation timed out' if th.is_alive() else None)
+        ok = torch.tensor([1.0 if comm is not None else 0.0], device=dev)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)            # all ranks or none
+        if float(ok) == 1.0:
+            fence()
+            reducer0.set_native(comm)
+            step()
+            step()                        # the communicator's first collectives (channel set-up) stay out of the timing
+            fence()
+            ms_n, rank_ms_n, loss_n = timed_region()
+            collective_paths[native] = round(ms_n, 3)
+            if comm.rehearsal:
+                collective_paths['note'] = ('one-GPU rehearsal (W2L_DIST_BACKEND=gloo): the native path ran on one-rank '
+                                            'communicators, averaging nothing')
+            if ms_n < ms and line is not None:
+                collective_paths['kept'] = native
+                line.update(value=round(world * N * T / (ms_n * 1e-3), 1), ms_per_step=round(ms_n, 3),
+                            rank_ms_per_step=[round(v, 3) for v in rank_ms_n], collectives_via=native,
+                            per_gpu_value=round(N * T / (ms_n * 1e-3), 1))
+                line['config']['loss'] = round(float(loss_n.detach()), 4)
+            if solo_ms is not None and ms_n < ms:
+                by = [round(v, 3) for v in gather_objects(dist, world, rank_ms_n[rank] - solo_ms)]
+                if line is not None:
+                    line.update(exposed_comm_ms=max(by), exposed_comm_ms_by_rank=by)
+            elif solo_ms is not None:
+                gather_objects(dist, world, 0.0)          # (keeps the ranks' collective sequences identical)
+        else:
+            collective_paths['native_unavailable'] = why or 'another rank could not create its communicator'
+            if comm is not None:
+                comm.close()
+        watchdog.cancel()
+    emit()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -99,6 +99,21 @@ def test_weight_layout_and_checkpoint_roundtrip(tmp_path):
     m2 = Wav2Letter(_cfg(3, layers=meta['layers']))
     m2.load_state_dict(torch.load(tmp_path / 'ck.pt'))
     assert torch.equal(m2.conv1ds.conv1d_1.conv1.weight, w)
+    # the whole module pickles (torch.save(model)) and deep-copies: the cached engine, the operand packs and the load hook are
+    # left behind, parameters and buffers travel
+    import copy
+    import pickle
+    m2.engine()
+    m2.conv1ds.conv1d_1.conv1.weight._w2l_pack = __import__('wav2letter_pytorch_amd.engine', fromlist=['x'])._Volatile(x=1)
+    for clone in (pickle.loads(pickle.dumps(m2)), copy.deepcopy(m2)):
+        assert '_engine_cache' not in clone.__dict__ or clone.__dict__['_engine_cache'] is None
+        assert getattr(clone.conv1ds.conv1d_1.conv1.weight, '_w2l_pack', None) is None
+        assert torch.equal(clone.conv1ds.conv1d_1.conv1.weight, w)
+        clone.load_state_dict(m2.state_dict())              # the post-load hook came along and still works
+        assert len(clone.engine().units) == 3
+    from wav2letter_pytorch_amd.train import name_to_model
+    assert 'jasper' in name_to_model and set(name_to_model) == {'jasper', 'wav2letter'} and name_to_model.get('nope') is None
+    assert name_to_model['wav2letter'] is Wav2Letter and len(name_to_model) == 2
     # same seed -> same initial values as nn.Conv1d would draw into a contiguous tensor
     torch.manual_seed(3)
     a = Wav2Letter(_cfg(1))

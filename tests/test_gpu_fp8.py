@@ -583,6 +583,7 @@ def test_fused_sgd_keeps_the_e4m3_operands_current(overlap, rescale_every, monke
     # rescale_every = 2: the weight scale is re-derived from amax (engine side) every other step -- the optimizer must then
     # leave the quantisation to the engine for that step and pick the new state up afterwards
     monkeypatch.setattr(E, 'FP8_WEIGHT_RESCALE', rescale_every)
+    monkeypatch.setattr(E, 'FP8_RESCALE_LAG', 2)            # (production: 8) so that a new scale is adopted inside these four steps
     layers = [(128, 11, 2, 1, 0.0), (256, 13, 1, 1, 0.0), (128, 5, 1, 2, 0.0)]
     sd = O.init_wav2letter_state(layers, seed=91)
     model = build_w2l(layers, sd, 'fp8').train()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What bounds the implicit-GEMM K loop: timing experiments on diagnostic builds (never the shipped library).
 
-  make -C wav2letter_pytorch_amd/csrc BUILD=build_abl$V EXTRA=-DW2L_ABLATE=$V OUT=../libw2l_hip_abl$V.so
+  make -C wav2letter_pytorch_amd/csrc BUILD=build_abl$V EXTRA='-include diag/hooks.h -DW2L_ABLATE='$V OUT=../libw2l_hip_abl$V.so
   W2L_LIB=$PWD/wav2letter_pytorch_amd/libw2l_hip_abl$V.so python3 tools/ablate_igemm.py [Cin Cout Kw dil [cfg]]
 
 W2L_ABLATE bits (csrc/conv_igemm.hip, PIPE = 1 loop): 1 = no LDS-DMA is issued, 2 = operand fragments are read from LDS

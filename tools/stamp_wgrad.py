@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a K step of the weight-gradient kernel spends its cycles (diagnostic build, never the shipped library).
 
-  make -C wav2letter_pytorch_amd/csrc BUILD=build_stamp EXTRA=-DW2L_STAMP OUT=../libw2l_hip_stamp.so
+  make -C wav2letter_pytorch_amd/csrc BUILD=build_stamp EXTRA='-include diag/hooks.h -DW2L_STAMP' OUT=../libw2l_hip_stamp.so
   W2L_LIB=$PWD/wav2letter_pytorch_amd/libw2l_hip_stamp.so python3 tools/stamp_wgrad.py [Cin Cout Kw dil [splits [order]]]
 
 The stamp build brackets four segments of every step of the 16x16x32 two-tap kernel with s_memtime (csrc/conv_wgrad.hip,

@@ -39,6 +39,11 @@ def _nothing():
     return None
 
 
+def _drop_engine_after_load(module, incompatible_keys):
+    """load_state_dict post-hook (a module-level function: a lambda here would make every model unpicklable)"""
+    module.invalidate_engine()
+
+
 class EngineSlot(tuple):
     """(key, StackEngine) as cached in a module's ``__dict__``.  An engine holds HIP streams and raw-pointer specs of THIS
     module's tensors: a copy of the module (``copy.deepcopy``, ``torch.save`` of the whole module, pickling for a worker)
@@ -70,7 +75,7 @@ class ConvCTCASR(_Base):
         self.print_decoded_prob = cfg.get('print_decoded_prob', 0)
         self.example_input_array = self.create_example_input_array()
         # load_state_dict(assign=True) swaps Parameter OBJECTS under the engine's specs: rebuild after any load
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_engine())
+        self.register_load_state_dict_post_hook(_drop_engine_after_load)
 
     def create_example_input_array(self):
         """(spectrograms [4, input_size, 200] ~ U[0,1), lengths [4] ~ U{100..199}) -- Lightning's model summary input;

@@ -47,6 +47,40 @@ void w2l_set_error(const char* fmt, ...);
     } while (0)
 #define W2L_CHECK_LAUNCH() W2L_CHECK_HIP(hipGetLastError())
 
+// ---- diagnostic hook points.  Empty here, i.e. in every shipped build; tools/ablate_igemm.py and tools/stamp_wgrad.py build
+// experiment libraries that force-include csrc/diag/hooks.h, which defines bodies for them first. ----
+#ifndef W2L_DIAG_SKIP_DMA
+#define W2L_DIAG_SKIP_DMA(p)
+#endif
+#ifndef W2L_DIAG_SKIP_FRAGS
+#define W2L_DIAG_SKIP_FRAGS(p, stp)
+#endif
+#ifndef W2L_DIAG_SKIP_MFMA
+#define W2L_DIAG_SKIP_MFMA(p)
+#endif
+#ifndef W2L_DIAG_CLK_BEGIN
+#define W2L_DIAG_CLK_BEGIN()
+#define W2L_DIAG_CLK_END(tid)
+#endif
+#ifndef W2L_DIAG_IGEMM_EXPORTS
+#define W2L_DIAG_IGEMM_EXPORTS
+#endif
+#ifndef W2L_DIAG_STAMP_DECL
+#define W2L_DIAG_STAMP_DECL()
+#define W2L_DIAG_STAMP_STEP0()
+#define W2L_DIAG_STAMP_STEP1()
+#define W2L_DIAG_STAMP_STEP2()
+#define W2L_DIAG_STAMP_STEP3()
+#define W2L_DIAG_STAMP_LOOP_BEGIN()
+#define W2L_DIAG_STAMP_STORE(lane, slot_expr)
+#endif
+#ifndef W2L_DIAG_WGRAD_EXPORTS
+#define W2L_DIAG_WGRAD_EXPORTS
+#endif
+#ifndef W2L_DIAG_WGRAD_TAPS
+#define W2L_DIAG_WGRAD_TAPS 2
+#endif
+
 // raise a kernel's dynamic-LDS limit to the full 160 KiB of a gfx950 CU (idempotent, cheap)
 hipError_t w2l_allow_big_lds(const void* kernel);
 

@@ -21,17 +21,6 @@
 #include <mutex>
 #include <tuple>
 
-#if defined(W2L_ABLATE) && (W2L_ABLATE & 8)
-// diagnostic build only: the clock a block's K loop ran at = delta s_memtime / delta s_memrealtime x 100 MHz
-__device__ unsigned long long g_igemm_clk[2 * 4096];
-#define W2L_CLK_AT(c, r)                                                                              \
-    do {                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c), "=s"(r)::"memory"); \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-    } while (0)
-#endif
-
 namespace {
 
 constexpr int BK = 64;                 // channels per K chunk (128-byte LDS rows)
@@ -146,9 +135,7 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
     }
     const int64_t w_tap_bytes = (int64_t)p.Cout * Cin * ESZ;
     auto stage_w = [&](char* dst, int kw, int c) {
-#if defined(W2L_ABLATE) && (W2L_ABLATE & 1)
-        if (p.Kw > 0) return;                  // timing experiment: no LDS-DMA (results are garbage)
-#endif
+        W2L_DIAG_SKIP_DMA(p);
         const char* slab = reinterpret_cast<const char*>(p.w) + kw * w_tap_bytes + c * (BK * 2);   // wave-uniform
 #pragma unroll
         for (int i = 0; i < W_PER_WAVE; ++i) {
@@ -157,9 +144,7 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
         }
     };
     auto stage_x = [&](char* dst, int c) {
-#if defined(W2L_ABLATE) && (W2L_ABLATE & 1)
-        if (p.Kw > 0) return;
-#endif
+        W2L_DIAG_SKIP_DMA(p);
         const int ngrp = xrows >> 3;
         for (int grp = wave; grp < ngrp; grp += NWAVES) {
             int64_t r = xrow0 + grp * 8 + srow;
@@ -270,18 +255,14 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
             const int tsh = b_row0 + kk * d;             // LDS row of this lane's first B tile for this tap
             const int sw0 = ((ch0 ^ (tsh & 7)) << 4);
             const char* B = xb + (tsh << 7) + (ks ? (sw0 ^ CH1_XOR) : sw0);      // chunk 4+fq == (chunk fq) ^ 4
-#if defined(W2L_ABLATE) && (W2L_ABLATE & 2)
-            if (p.Kw > 0 && stp > 0) return;   // timing experiment: fragments are read once only
-#endif
+            W2L_DIAG_SKIP_FRAGS(p, stp);
     #pragma unroll
             for (int mi = 0; mi < MS; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(A + mi * 16 * ROWB);
     #pragma unroll
             for (int ni = 0; ni < NS; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(B + ni * 16 * S * ROWB);
         };
         auto mfma_all = [&](const bf16x8* a, const bf16x8* b) {
-#if defined(W2L_ABLATE) && (W2L_ABLATE & 4)
-            if (p.Kw > 0) return;              // timing experiment: no MFMA
-#endif
+            W2L_DIAG_SKIP_MFMA(p);
     #pragma unroll
             for (int mi = 0; mi < MS; ++mi)
     #pragma unroll
@@ -322,10 +303,7 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
         }
         bf16x8 a0[MS], b0[NS], a1[MS], b1[NS];
         load_frags(0, 0, c, kw, a0, b0);
-#if defined(W2L_ABLATE) && (W2L_ABLATE & 8)
-        unsigned long long clk_c0, clk_r0, clk_c1, clk_r1;
-        W2L_CLK_AT(clk_c0, clk_r0);
-#endif
+        W2L_DIAG_CLK_BEGIN();
         for (int step = 0; step + 1 < nsteps; ++step) {
             load_frags(1, step, c, kw, a1, b1);
             mfma_all(a0, b0);
@@ -344,13 +322,7 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
             kw = kw_n; c = c_n;
             kw_n = kw_nn; c_n = c_nn;
         }
-#if defined(W2L_ABLATE) && (W2L_ABLATE & 8)
-        W2L_CLK_AT(clk_c1, clk_r1);
-        if (tid == 0 && blockIdx.x < 4096) {
-            g_igemm_clk[2 * blockIdx.x] = clk_c1 - clk_c0;
-            g_igemm_clk[2 * blockIdx.x + 1] = clk_r1 - clk_r0;
-        }
-#endif
+        W2L_DIAG_CLK_END(tid);
         load_frags(1, nsteps - 1, c, kw, a1, b1);
         mfma_all(a0, b0);
         mfma_all(a1, b1);
@@ -653,12 +625,7 @@ constexpr size_t kTicketBytes = 64 * 1024;              // head of the split-K w
 // a backward running on an autograd worker thread while another thread tunes never sees a forced index
 static thread_local int g_force_cfg = -1;
 extern "C" void w2l_conv_force_tile_config(int idx) { g_force_cfg = idx; }
-#if defined(W2L_ABLATE) && (W2L_ABLATE & 8)
-extern "C" int w2l_igemm_read_clock(unsigned long long* dst, int n) {
-    W2L_CHECK_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_igemm_clk), sizeof(unsigned long long) * (size_t)(n < 8192 ? n : 8192)));
-    return 0;
-}
-#endif
+W2L_DIAG_IGEMM_EXPORTS
 
 static inline int cfg_xrows(const TileCfg& c, int stride, int Kw, int dil) {
     const int bn = 16 * c.nw * c.ns;

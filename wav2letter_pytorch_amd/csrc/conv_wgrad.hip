@@ -21,19 +21,6 @@
 #include <mutex>
 #include <tuple>
 
-// Diagnostic build only (-DW2L_STAMP, never shipped): where a K step of the 16x16x32 two-tap kernel spends its cycles, per wave.
-// s_memtime stamps around the step's segments, summed in scalar registers, stored once per wave after the loop into a
-// buffer nothing else reads (MI355X guide, "In-kernel stamps").  tools/stamp_wgrad.py builds, runs and prints the shares.
-#ifdef W2L_STAMP
-__device__ unsigned long long g_wgrad_stamps[8 * 8192];
-#define W2L_STAMP_AT(var)                                                                            \
-    do {                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                           \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                \
-        __builtin_amdgcn_sched_barrier(0);                                                           \
-    } while (0)
-#endif
-
 namespace {
 
 constexpr int BM = 128;       // co per block
@@ -41,10 +28,7 @@ constexpr int BNC = 128;      // ci per block
 constexpr int BT = 64;        // t rows per K step
 constexpr int ROWB = 256;     // bytes per LDS row (128 bf16)
 
-#ifndef W2L_KWB
-#define W2L_KWB 2
-#endif
-constexpr int KWB_DEFAULT = W2L_KWB;   // taps per block (1: diagnostic builds only -- the one-tap form keeps 140-153 VGPRs)
+constexpr int KWB_DEFAULT = W2L_DIAG_WGRAD_TAPS;   // taps per 4-wave block: 2 (common.h; a diagnostic build may probe 1)
 
 struct WgradParams {
     const bf16_raw* dy;
@@ -314,9 +298,7 @@ __global__ __launch_bounds__(256 * TG, TG == 1 ? 2 : 1) void conv_wgrad_kernel(W
     //    fragments of step+1 are requested from the other buffers, and all of it hides behind the last 16 MFMAs.
     // NT / LAST are compile-time so that each body is straight-line code with in-place accumulators (the compiler
     // does not move reads across a branch).
-#ifdef W2L_STAMP
-    unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0;
-#endif
+    W2L_DIAG_STAMP_DECL();
     bf16x8 a[4], b[2][4];
     auto load_a1 = [&](int i, int ks) {
 #pragma unroll
@@ -371,29 +353,14 @@ __global__ __launch_bounds__(256 * TG, TG == 1 ? 2 : 1) void conv_wgrad_kernel(W
             const int ks2 = (g + 1) / NT, tp2 = (g + 1) % NT;
             if (!lastg) load_b(b[(g + 1) & 1], tp2, ks2);
             if (lastg && !LAST) {
-#ifdef W2L_STAMP
-                unsigned long long t0, t1, t2, t3;
-                W2L_STAMP_AT(t0);
-                st_sum[0] += t0 - st_prev;                          // groups 0 .. NG-2: fragment reads + MFMAs
-#endif
+                W2L_DIAG_STAMP_STEP0();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step+1's tiles (this wave's part) have landed
-#ifdef W2L_STAMP
-                W2L_STAMP_AT(t1);
-                st_sum[1] += t1 - t0;                               // waiting for this wave's LDS-DMA
-#endif
+                W2L_DIAG_STAMP_STEP1();
                 __syncthreads();                                    // ... everyone's; and nobody reads this step's buffers any more
-#ifdef W2L_STAMP
-                W2L_STAMP_AT(t2);
-                st_sum[2] += t2 - t1;                               // the block barrier
-#endif
+                W2L_DIAG_STAMP_STEP2();
                 toggle();                                           // read pointers -> step+1's buffers
                 if (have_nn) stage(adst, bdst, n_nn, ts_nn);        // step+2 -> this step's buffers
-#ifdef W2L_STAMP
-                W2L_STAMP_AT(t3);
-                st_sum[3] += t3 - t2;                               // pointer toggles + issuing the LDS-DMA pieces
-                st_prev = t3;
-                st_sum[5] += 1;
-#endif
+                W2L_DIAG_STAMP_STEP3();
                 load_b(b[(g + 1) & 1], 0, 0);
             }
 #pragma unroll
@@ -475,9 +442,7 @@ __global__ __launch_bounds__(256 * TG, TG == 1 ? 2 : 1) void conv_wgrad_kernel(W
             for (int i = 0; i < 4; ++i) load_a1(i, 0);
             load_b(b[0], 0, 0);
         }
-#ifdef W2L_STAMP
-        W2L_STAMP_AT(st_prev);
-#endif
+        W2L_DIAG_STAMP_LOOP_BEGIN();
         for (int step = step_begin; step + 1 < step_end; ++step) {
             const int par = (step - step_begin) & 1;
             advance(n, ts);                               // now step+2
@@ -533,15 +498,7 @@ __global__ __launch_bounds__(256 * TG, TG == 1 ? 2 : 1) void conv_wgrad_kernel(W
     if (TG > 1 && ntaps == 0) run_idle();
     else if (KWB == 1 || ntaps == KWB) run(std::integral_constant<int, KWB>{});
     else run(std::integral_constant<int, 1>{});
-#ifdef W2L_STAMP
-    if (lane == 0) {
-        const int slot = (blockIdx.y * gridDim.x + blockIdx.x) * NWV + wave_all;
-        if (slot < 8192) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) g_wgrad_stamps[slot * 8 + i] = st_sum[i];
-        }
-    }
-#endif
+    W2L_DIAG_STAMP_STORE(lane, (blockIdx.y * gridDim.x + blockIdx.x) * NWV + wave_all);
     // the read pointers were toggled once per non-last step: bring them back to buffer 0 for a following segment
     if (step_end > step_begin && ((step_end - step_begin - 1) & 1)) toggle();
     // a piece of a tile (stream-K) is added atomically; a tile this block covered completely is stored
@@ -765,7 +722,9 @@ extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const voi
     // stream-K is the atomic path's alternative to split-K: with a workspace (deterministic slabs) the classic plan runs
     p.streamk = (order & kStreamK) && ws == nullptr ? 1 : 0;
     if (p.streamk) splits = 1;
-    const bool tg2 = (order & kTapGroups2) && Kw > 2;      // (with stream-K: 256 persistent 8-wave blocks, one per CU)
+    // (with stream-K: 256 persistent 8-wave blocks, one per CU -- built for stride 1 only; the plan cache is keyed without the
+    // stride, so a plan measured on a stride-1 layer may reach a strided one: that launch falls back to the 4-wave stream-K kernel)
+    const bool tg2 = (order & kTapGroups2) && Kw > 2 && !(p.streamk && stride != 1);
     const bool m32 = (order & kMfma32) && !p.streamk && !tg2 && stride == 1;
     p.total_steps = N * p.tsteps;
     p.steps_per_split = (p.total_steps + splits - 1) / splits;
@@ -807,7 +766,6 @@ extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const voi
             hipLaunchKernelGGL((conv_wgrad_kernel<1, true, false, 1, true>), grid, block, lds, (hipStream_t)stream, p);
         }
     } else if (tg2 && p.streamk) {
-        W2L_CHECK_ARG(stride == 1, "conv1d_wgrad: the stream-K form of the 8-wave kernel is built for stride 1");
         W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<2, true, true, 2>));
         hipLaunchKernelGGL((conv_wgrad_kernel<2, true, true, 2>), grid, block, lds, (hipStream_t)stream, p);
     } else if (tg2) {
@@ -909,14 +867,7 @@ extern "C" int w2l_conv1d_wgrad_tune(const void* dy, int64_t dy_bstride, const v
                                     reps, nullptr, 0, stream);
 }
 
-#ifdef W2L_STAMP
-// diagnostic build: copy the per-wave stamp sums out (8 words per wave: five segments' cycle sums, the step count, 2 spare)
-extern "C" int w2l_wgrad_read_stamps(unsigned long long* dst, int nwords) {
-    const size_t n = (size_t)(nwords < 8 * 8192 ? nwords : 8 * 8192) * sizeof(unsigned long long);
-    W2L_CHECK_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wgrad_stamps), n));
-    return 0;
-}
-#endif
+W2L_DIAG_WGRAD_EXPORTS
 
 // Tuning-cache (de)serialisation used by w2l_tune_save / w2l_tune_load (runtime.hip).
 void w2l_wgrad_tune_dump(FILE* f) {

@@ -28,13 +28,13 @@ class Decoder(object):
     """Base decoder (decoder.py:11-83): label bookkeeping + WER/CER helpers."""
 
     def __init__(self, labels, blank_index=0):
-        self.labels = label_sets.labels_map[labels] if type(labels) is str else labels
-        self.int_to_char = dict([(i, c) for (i, c) in enumerate(self.labels)])
+        """``labels``: the label sequence itself or the name of one in data.label_sets; index -> character lookups are built
+        once.  A label set without a space gets ``space_index = len(labels)``, an index no frame can take (decoder.py:22-29)."""
+        alphabet = label_sets.labels_map[labels] if isinstance(labels, str) else labels
+        self.labels = alphabet
         self.blank_index = blank_index
-        space_index = len(self.labels)       # out-of-bounds index when there is no space label
-        if ' ' in self.labels:
-            space_index = list(self.labels).index(' ')
-        self.space_index = space_index
+        self.int_to_char = {index: char for index, char in enumerate(alphabet)}
+        self.space_index = next((index for index, char in enumerate(alphabet) if char == ' '), len(alphabet))
 
     def wer(self, s1, s2):
         """word-level edit distance (decoder.py:31-49)"""
@@ -88,18 +88,15 @@ class GreedyDecoder(Decoder):
         return ''.join(chars), torch.IntTensor(offsets.astype(np.int32))
 
     def convert_to_strings(self, sequences, sizes=None, remove_repetitions=False, return_offsets=False):
-        strings = []
-        offsets = [] if return_offsets else None
-        seqs = sequences.cpu().numpy() if torch.is_tensor(sequences) else np.asarray(sequences)
-        for x in range(len(seqs)):
-            seq_len = int(sizes[x]) if sizes is not None else len(seqs[x])
-            string, string_offsets = self.process_string(seqs[x], seq_len, remove_repetitions)
-            strings.append([string])
-            if return_offsets:
-                offsets.append([string_offsets])
-        if return_offsets:
-            return strings, offsets
-        return strings
+        """index rows -> text, one single-element list per utterance (the nesting beam-search decoders fill with n-best lists;
+        decoder.py:89-102); ``sizes[n]`` limits row n to its valid frames"""
+        rows = sequences.cpu().numpy() if torch.is_tensor(sequences) else np.asarray(sequences)
+        decoded = [self.process_string(row, len(row) if sizes is None else int(sizes[n]), remove_repetitions)
+                   for n, row in enumerate(rows)]
+        texts = [[text] for text, _ in decoded]
+        if not return_offsets:
+            return texts
+        return texts, [[frames] for _, frames in decoded]
 
     def decode(self, probs, sizes=None, return_offsets=False):
         """argmax decoding, repeats and blanks removed (decoder.py:121-145).

@@ -196,7 +196,16 @@ class GradReducer:
             native = os.environ.get('W2L_DP_NATIVE', '0') == '1'
         self._comm: Optional[NativeComm] = None
         if native and self.active and torch.cuda.is_available():
-            self._comm = NativeComm.from_process_group(group)
+            comm = NativeComm.from_process_group(group)
+            if comm.rehearsal:
+                # one-rank stand-ins (W2L_DIST_BACKEND=gloo on a shared GPU) average NOTHING across the ranks: fine for
+                # bench.py's plumbing rehearsal, which asks for them explicitly through set_native(), never for a trainer
+                comm.close()
+                import warnings
+                warnings.warn('W2L_DP_NATIVE=1 with W2L_DIST_BACKEND=gloo: RCCL cannot span two ranks on one device; the '
+                              'gradient collectives stay on torch.distributed (gloo)')
+            else:
+                self._comm = comm
 
     def set_native(self, comm: Optional[NativeComm]):
         """route the gradient collectives through ``comm`` (the C ABI's RCCL helpers) from the next step on, or back through

@@ -30,6 +30,21 @@ ACT_NONE, ACT_CLAMP20, ACT_RELU = 0, 1, 2
 PAD_ZERO, PAD_REFLECT = 0, 1
 
 
+def _none():
+    return None
+
+
+class _Volatile(dict):
+    """per-Parameter device state kept in ``Parameter.__dict__`` (operand packs, e4m3 copies, events, pinned buffers): a
+    pickled or deep-copied Parameter gets None in its place and rebuilds the state on first use"""
+
+    def __reduce__(self):
+        return (_none, ())
+
+    def __deepcopy__(self, memo):
+        return None
+
+
 class _nullctx:
     def __enter__(self):
         return None
@@ -230,7 +245,7 @@ def pack_weights(conv: ConvSpec, precise: bool, need_dgrad: bool = True) -> _Pac
     w = conv.weight
     cache = getattr(w, '_w2l_pack', None)          # lives and dies with the Parameter object
     if cache is None:
-        cache = {}
+        cache = _Volatile()
         w._w2l_pack = cache
     hit = cache.get(precise)
     if (hit is not None and hit.version == w._version and hit.fwd_hi.device == w.device
@@ -392,7 +407,9 @@ def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw
 # weight versions without a host sync (_fp8_weights: device-side amax, asynchronous copy, adopted FP8_RESCALE_LAG versions later).
 FP8_ACT_SCALE = {ACT_CLAMP20: 16.0, ACT_RELU: 8.0, ACT_NONE: 8.0}
 FP8_WEIGHT_RESCALE = 256
-FP8_RESCALE_LAG = 2
+FP8_RESCALE_LAG = 8                # weight versions between asking for the amax and adopting the scale it yields: the copy has
+                                   # landed many steps earlier even when the host runs ahead of the GPU, so the event wait
+                                   # below never drains the pipeline, and every data-parallel rank adopts at the same step
 AMAX_SLOTS = 64                    # include/w2l_hip.h W2L_AMAX_SLOTS
 # fp8 mode, data gradients: on e4m3 operands too ('1'), in bf16 ('0'), or (default 'auto') e4m3 only from FP8_DGRAD_MIN_ROWS
 # rows of dy per launch.  The e4m3 data gradient needs two more launches per layer on the backward critical path (dy's
@@ -433,15 +450,15 @@ def _fp8_weights(conv: ConvSpec, pk: '_PackedW', dgrad: bool = False):
         mn, mx = torch.aminmax(pk.fwd_hi)
         scale = _pow2_scale(max(-float(mn), float(mx)))          # host sync: first use only
         dev = pk.fwd_hi.device
-        st = {'q': torch.empty(pk.fwd_hi.shape, dtype=torch.uint8, device=dev),
-              'qd': torch.empty(pk.dgr_hi.shape, dtype=torch.uint8, device=dev), 'scale': scale, 'age': 0, 'version': None,
-              'version_d': None, 'req': None}
+        st = _Volatile({'q': torch.empty(pk.fwd_hi.shape, dtype=torch.uint8, device=dev),
+                        'qd': torch.empty(pk.dgr_hi.shape, dtype=torch.uint8, device=dev), 'scale': scale, 'age': 0,
+                        'version': None, 'version_d': None, 'req': None})
         w.__dict__['_w2l_fp8'] = st
     elif not dgrad and not torch.cuda.is_current_stream_capturing():
         req = st.get('req')
         if req is not None and st['age'] >= FP8_RESCALE_LAG:
             ev, host = req
-            ev.synchronize()                                         # FP8_RESCALE_LAG steps old: returns at once
+            ev.synchronize()                                         # FP8_RESCALE_LAG versions old: returns at once
             st['req'] = None
             scale = _pow2_scale(max(-float(host[0]), float(host[1])))
             if scale != st['scale']:

@@ -51,7 +51,7 @@ class Novograd(Optimizer):
         dev = p.device
         cache = getattr(p, '_w2l_pack', None)
         if cache is None:
-            cache = {}
+            cache = E._Volatile()
             p._w2l_pack = cache
         precise = any(k for k in cache)
         old = cache.get(precise)

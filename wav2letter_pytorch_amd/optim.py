@@ -205,7 +205,7 @@ class FusedSGD(torch.optim.SGD):
         dev = p.device
         cache = getattr(p, '_w2l_pack', None)
         if cache is None:
-            cache = {}
+            cache = E._Volatile()
             p._w2l_pack = cache
         precise = any(k for k in cache)                              # keep hi/lo pairs alive only if fp32 mode is in use
         old = cache.get(precise)

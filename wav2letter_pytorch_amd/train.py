@@ -23,14 +23,44 @@ from .launch import spawn_ranks, under_launcher
 
 
 class _Models(dict):
-    """``name_to_model`` of the reference's train.py:15-19, filled on first lookup"""
+    """``name_to_model`` of the reference's train.py:15-19.  The model classes pull in torch and the HIP library, which a
+    launch parent must not map, so the table fills itself the first time ANY read touches it -- lookups, ``in``, ``get``,
+    iteration, ``len`` -- and behaves like the reference's plain dict from then on."""
+
+    def _fill(self):
+        if not dict.__len__(self):
+            from . import Jasper, Wav2Letter
+            dict.update(self, jasper=Jasper, wav2letter=Wav2Letter)
+        return self
 
     def __missing__(self, key):
-        from . import Jasper, Wav2Letter
-        self.update(jasper=Jasper, wav2letter=Wav2Letter)
-        if key not in self:
-            raise KeyError(key)
-        return self[key]
+        if dict.__contains__(self._fill(), key):
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self._fill(), key)
+
+    def __iter__(self):
+        return dict.__iter__(self._fill())
+
+    def __len__(self):
+        return dict.__len__(self._fill())
+
+    def get(self, key, default=None):
+        return dict.get(self._fill(), key, default)
+
+    def keys(self):
+        return dict.keys(self._fill())
+
+    def values(self):
+        return dict.values(self._fill())
+
+    def items(self):
+        return dict.items(self._fill())
+
+    def __repr__(self):
+        return dict.__repr__(self._fill())
 
 
 name_to_model = _Models()
