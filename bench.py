@@ -68,13 +68,13 @@ def cpu_baseline(budget_s=20.0):
 
 def csrc_fingerprint():
     """sha256 over the sources of the kernels whose counters profiles/*_pmc_bench.json holds -- the implicit-GEMM and the
-    weight-gradient kernel (conv_igemm.hip, conv_wgrad.hip, common.h) and the Makefile's flags: the stamp of that file, so
+    weight-gradient kernels (conv_igemm.hip, conv_wgrad.hip, conv_wgrad_kernel.h, conv_wgrad3_dev.hip, common.h) and the Makefile's flags: the stamp of that file, so
     that counters collected on other kernels are never quoted (tools/prof_summary.py writes the same stamp).  Entry points
     added elsewhere in the library do not change what these two kernels read and write."""
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(ROOT, 'wav2letter_pytorch_amd', 'csrc')
-    for name in ('Makefile', 'common.h', 'conv_igemm.hip', 'conv_wgrad.hip'):
+    for name in ('Makefile', 'common.h', 'conv_igemm.hip', 'conv_wgrad.hip', 'conv_wgrad_kernel.h', 'conv_wgrad3_dev.hip'):
         h.update(name.encode())
         h.update(open(os.path.join(src, name), 'rb').read())
     return h.hexdigest()[:16]

@@ -160,9 +160,11 @@ int w2l_wgrad_needs_zero_ws(int N, int Cin, int Cout, int Tout, int Kw, int64_t 
 int64_t w2l_wgrad_workspace_bytes(int Cin, int Cout, int Kw);
 
 /* Testing / profiling hook: pin the split count (0 = automatic) and the plan order (-1 = automatic; bit 0 = block order,
- * bit 1 = stream-K decomposition, bit 2 = two tap groups per 8-wave block, bit 3 = 32x32x16 MFMA tiles; a combination the
- * shape does not admit falls back to the nearest built variant) for launches made by the calling thread (thread-local,
- * like w2l_conv_force_tile_config). */
+ * bit 1 = stream-K decomposition, bit 2 = two tap groups per 8-wave block, bit 3 = 32x32x16 MFMA tiles, bit 4 = THREE taps
+ * per wave with the 192 accumulator registers in AGPRs (stride 1, dilation <= 4; alone: two 4-wave blocks per CU, with bit
+ * 2: one 8-wave block of six taps per CU -- the kernels of csrc/conv_wgrad3_dev.hip, a code object of their own embedded in
+ * the library); a combination the shape does not admit falls back to the nearest built variant) for launches made by the
+ * calling thread (thread-local, like w2l_conv_force_tile_config). */
 void w2l_wgrad_force_plan(int splits, int order);
 
 /* Autotune of the split-K factor and block order, like w2l_conv1d_igemm_tune (SYNCHRONISING, warm-up only); dw_scratch is a

@@ -212,8 +212,9 @@ def test_conv_igemm_every_configuration(L, with_stats):
 
 @pytest.mark.parametrize('Kw,s,d', [(5, 1, 2), (6, 1, 1), (7, 1, 2), (8, 1, 1), (11, 2, 1)])
 def test_conv_wgrad_every_plan(L, Kw, s, d):
-    """split counts x both block orders x {one tap group, two tap groups, 32x32x16 MFMA fragments (order bit 3; stride 1)}
-    per block (the autotuner's search space).  Tap counts
+    """split counts x both block orders x {one tap group, two tap groups, 32x32x16 MFMA fragments (order bit 3; stride 1),
+    three taps per block with the accumulators in AGPRs (order bit 4: the code object of conv_wgrad3_dev.hip; its last tap
+    group holds 2 taps at Kw = 5 and 8, 3 at Kw = 6, 1 at Kw = 7)} per block (the autotuner's search space).  Tap counts
     4k+1 .. 4k+4: with two tap groups (the 8-wave kernel, order bit 2) the last block then has an idle tap group and a
     one-tap wave (Kw = 5), an idle tap group (6), a one-tap second group (7), or is full (8); stride 2 takes the other
     instantiation"""
@@ -232,7 +233,8 @@ def test_conv_wgrad_every_plan(L, Kw, s, d):
     F.conv1d(F.pad(bf(x), (pl, pr), mode='reflect'), wr, None, stride=s, dilation=d).backward(bf(dy))
     ws = torch.zeros(int(L.lib.w2l_wgrad_workspace_bytes(Cin, Cout, Kw)), dtype=torch.uint8, device='cuda')
     for splits in (1, 2, 3, 5, 18):
-        for order in (0, 1, 4, 5, 8, 9):
+        # 16, 17: three taps per block, AGPR accumulators (stride 1; else the two-tap kernel); 20, 21: two such tap groups (8 waves)
+        for order in (0, 1, 4, 5, 8, 9, 16, 17, 20, 21):
             # (a) without a workspace: fp32 atomics into a zero-filled dw
             dw = torch.zeros(Kw, Cout, Cin, device='cuda')
             L.lib.w2l_wgrad_force_plan(splits, order)
@@ -266,7 +268,8 @@ def test_conv_wgrad_every_plan(L, Kw, s, d):
                 L.lib.w2l_wgrad_force_plan(0, -1)
     # stream-K decomposition (order bit 1): persistent blocks cut the (tile, step) space into equal ranges that straddle
     # tile boundaries (18 tiles x 18 steps over 20 blocks here); whole tiles are stored, pieces are added atomically
-    for order in (2, 3) + ((6, 7) if s == 1 and Kw > 2 else ()):          # 6, 7: the 8-wave (two tap groups) stream-K form
+    # 6, 7: the 8-wave (two tap groups) stream-K form; 18: stream-K asked of the three-tap form -> the two-tap stream-K kernel
+    for order in (2, 3) + ((6, 7, 18) if s == 1 and Kw > 2 else ()):
         L.lib.w2l_wgrad_force_plan(0, order)
         try:
             assert L.lib.w2l_wgrad_needs_zero(N, Cin, Cout, Tout, Kw) == 1

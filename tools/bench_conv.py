@@ -51,6 +51,7 @@ def main():
     ap.add_argument('--warm-s', type=float, default=0.0, help='seconds of back-to-back launches before every timing')
     ap.add_argument('--deterministic', action='store_true', help='weight gradients through slabs + ticket (W2L_DETERMINISTIC=1 path)')
     ap.add_argument('--no-splitk', action='store_true', help='with --tune: measure without the split-K configurations')
+    ap.add_argument('--orders', default=None, help='with --wgrad-plans: comma-separated plan orders to time instead of all')
     ap.add_argument('--wgrad-plans', action='store_true',
                     help='per layer: the best forced split count of every weight-gradient plan class (block order x tap groups, stream-K)')
     ap.add_argument('--fp8', action='store_true', help='also time the e4m3 weight-gradient kernel (w2l_conv1d_wgrad_fp8) on each layer')
@@ -110,7 +111,8 @@ def main():
 
         if args.wgrad_plans:
             res = []
-            for order in (0, 1, 4, 5, 8, 9, 2, 3, 6, 7):    # bit 0 block order, 2 two tap groups, 3 32x32x16 MFMA, 1 stream-K (6, 7: both)
+            # bit 0 block order, 2 two tap groups, 3 32x32x16 MFMA, 1 stream-K (6, 7: both), 4 three taps per block (AGPR accumulators)
+            for order in ([int(v) for v in args.orders.split(',')] if args.orders else (0, 1, 4, 5, 8, 9, 16, 17, 20, 21, 2, 3, 6, 7)):
                 best = (float('inf'), 0)
                 for sp in ((1,) if order & 2 else (1, 2, 3, 4, 5, 6, 8, 10, 12, 16)):
                     L.lib.w2l_wgrad_force_plan(sp, order)
