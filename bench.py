@@ -492,6 +492,8 @@ def main():
     model._overlap_wgrad = False      # serialise the side stream so per-launch durations are not shared-GPU times
     for _ in range(3):
         eager_step()                  # (the captured graph carries no timing events)
+    if hasattr(opt, 'join'):
+        opt.join()                    # the last step's deferred weight gradients are launched (and timed) here
     torch.cuda.synchronize()
     model._overlap_wgrad = not args.serial_wgrad
     if rank == 0:

@@ -17,8 +17,24 @@ for d in default serial; do
   cp $f $OUT/${d}_kernel_stats.csv
   python3 tools/prof_summary.py stats $f > $OUT/${d}_kernel_families.txt
 done
-# the overlapped step as a timeline: MFMA-busy time, time with only HBM-bound kernels running, idle (tools/timeline.py)
+# the overlapped step as a timeline: MFMA-busy time, time with only HBM-bound kernels running, idle (tools/timeline.py) --
+# once from the rocprofv3 trace (the host is ~3x slower under the profiler: bubbles at the step boundary that the real run
+# does not have) and once from HIP events around every launch with no profiler attached (bench.py --event-trace)
 python3 tools/timeline.py $(ls $OUT/prof_default/*/*kernel_trace.csv | head -1) --steps 6 --from 4 > $OUT/step_timeline.txt 2>&1
+for spec in 0 6; do
+  python3 bench.py --steps 6 --warmup 5 --no-cpu-baseline --no-live-traffic --defer-wgrad=$spec --event-trace $OUT/event_trace_defer$spec.csv 2> /dev/null
+  python3 tools/timeline.py $OUT/event_trace_defer$spec.csv --steps 4 --from 1 --gaps > $OUT/step_timeline_events_defer$spec.txt 2>&1
+  rm -f $OUT/event_trace_defer$spec.csv
+done
+# same-box A/B of this round's two step-level changes: deferred weight gradients (0 vs 6 top units) and the three-tap AGPR
+# weight-gradient kernels (W2L_WGRAD_NO_TAPS3=1 keeps them out of the measured selection; separate tune caches)
+for rep in 1 2; do
+  for v in "0 1" "0 0" "6 1" "6 0"; do
+    set -- $v
+    W2L_TUNE_CACHE=$PWD/$OUT/tune_ab_$2.txt $( [ "$2" = 1 ] && echo env W2L_WGRAD_NO_TAPS3=1 ) python3 bench.py --no-cpu-baseline --no-live-traffic --defer-wgrad=$1 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('defer_wgrad=$1 no_taps3=$2 ms_per_step', d['ms_per_step'], 'wgrad TFLOP/s (serialised pass)', d['roofline']['wgrad_kernel']['achieved'])"
+  done
+done > $OUT/step_ab.txt 2>&1
+rm -f $OUT/tune_ab_0.txt $OUT/tune_ab_1.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_bench_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done

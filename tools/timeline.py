@@ -12,10 +12,12 @@ import csv
 import sys
 from collections import defaultdict
 
-MFMA = ('conv_igemm', 'conv_wgrad')
+MFMA = ('conv_igemm', 'conv_wgrad')          # (w2l_wgrad3* -- the three-tap code object's kernels -- count as conv_wgrad)
 
 
 def family(name):
+    if 'w2l_wgrad3' in name:
+        return 'conv_wgrad'
     for key in ('conv_igemm_fp8', 'conv_wgrad_fp8', 'conv_igemm', 'conv_wgrad', 'bn_act_fwd', 'bn_act_bwd_reduce', 'bn_act_bwd_apply',
                 'bn_bwd_finalize', 'bn_finalize', 'sgd_pack', 'ctc_', 'log_softmax', 'nct_to_ntc', 'pad_cast', 'quantize', 'dw_',
                 'probe_', 'Cijk', 'ncclDevKernel', 'rccl'):
