@@ -56,8 +56,11 @@ def main():
                     help='per layer: the best forced split count of every weight-gradient plan class (block order x tap groups, stream-K)')
     ap.add_argument('--fp8', action='store_true', help='also time the e4m3 weight-gradient kernel (w2l_conv1d_wgrad_fp8) on each layer')
     ap.add_argument('--tune', action='store_true', help='let the library measure and pick its configurations first')
+    ap.add_argument('--tune-cache', default=None, help='with --tune: load the measured plans from this file if it exists (no measuring launches then) and save them to it afterwards')
     args = ap.parse_args()
     global WARM_S
+    if args.tune_cache and os.path.exists(args.tune_cache):
+        L.lib.w2l_tune_load(args.tune_cache.encode())
     WARM_S = args.warm_s
     N = args.n
     uniq = []
@@ -185,6 +188,8 @@ def main():
                 tot[k][1] += m * flops
         print(f'{cin:5d} {cout:5d} {kw:3d} {s} {d} | {tf:8.3f} {flops / tf / 1e9:6.0f} | {td:8.3f} {flops / td / 1e9:6.0f} | '
               f'{tw:8.3f} {flops / tw / 1e9:6.0f}   x{m}' + (f' | wgrad e4m3 {tw8:8.3f} {flops / tw8 / 1e9:6.0f}' if tw8 == tw8 else ''))
+    if args.tune_cache:
+        L.check(L.lib.w2l_tune_save(args.tune_cache.encode()), 'w2l_tune_save')
     for k, (t, f) in tot.items():
         if t:
             print(f'{k}: {t:.3f} ms/step-equivalent, {f / t / 1e9:.0f} TFLOP/s')
