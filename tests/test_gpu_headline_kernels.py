@@ -147,6 +147,21 @@ def test_headline_layer_kernels_exact(L, shape):
     assert worst['wgrad'] < 2e-5, ('weight gradient', worst['wgrad'])
     if coutp > cout:
         assert not bool(dw[:, cout:].abs().max() > 0)
+    # the three-tap kernels with their accumulators in AGPRs (plan order bit 4; csrc/conv_wgrad3_dev.hip), whatever the measured
+    # selection took above: the 4-wave and the 8-wave (six taps per block) form, unsplit and split, at this layer's real size --
+    # their MFMAs are inline asm, so every hazard the compiler would have padded is this kernel's own business
+    if stride == 1 and kw >= 3 and dil <= 4:
+        for order, splits in ((16, 1), (17, 3), (20, 1), (21, 2)):
+            L.lib.w2l_wgrad_force_plan(splits, order)
+            try:
+                for rep in range(2):
+                    dw3 = torch.zeros(kw, coutp, cin, device='cuda') if splits > 1 else torch.full((kw, coutp, cin), float('nan'), device='cuda')
+                    L.check(L.lib.w2l_conv1d_wgrad_ws(*wargs, L.ptr(dw3), *wdims, 0, None, 0, st))
+                    torch.cuda.synchronize()
+                    e3 = _err(dw3[:, :cout].double(), refw)
+                    assert e3 < 2e-5, ('three-tap weight gradient', order, splits, rep, e3)
+            finally:
+                L.lib.w2l_wgrad_force_plan(0, -1)
     del refw, dw, scratch
 
     # ---------------------------------------------------------------- data gradient (stride-1 layers; layer 0 has none in training)
