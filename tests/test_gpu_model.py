@@ -370,9 +370,14 @@ def test_jasper_separable_golden(precision):
         check_fixture_grads(model, z)
 
 
-def test_trainer_fit_loop_and_checkpoint(tmp_path):
+@pytest.mark.parametrize('defer', ['0', '2'])
+def test_trainer_fit_loop_and_checkpoint(tmp_path, defer, monkeypatch):
     """training_step / validation_step / configure_optimizers through the minimal Trainer (train.py:34-37 flow):
-    loss decreases on a fixed batch, metrics carry the reference's log keys, the checkpoint reloads"""
+    loss decreases on a fixed batch, metrics carry the reference's log keys, the checkpoint reloads.  ``defer`` = 2: the
+    weight gradients of both conv units are held back for the next forward pass (W2L_DEFER_WGRAD): validation and the
+    checkpoint after each epoch must see every update of the epoch (Trainer joins the optimizer, which flushes), and the
+    two runs must end on the same parameters."""
+    monkeypatch.setenv('W2L_DEFER_WGRAD', defer)
     from oracle import w2l_oracle as O
     from wav2letter_pytorch_amd.trainer import Trainer
     layers = [(128, 11, 2, 1, 0.0), (128, 11, 1, 1, 0.0)]
@@ -396,6 +401,60 @@ def test_trainer_fit_loop_and_checkpoint(tmp_path):
     m2.load_state_dict(state)
     for (k, a), (_, b) in zip(model.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a.cpu(), b.cpu()), k
+    assert model.engine().defer_wgrad == int(defer) and not model.engine()._deferred
+    final = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items() if v.dtype.is_floating_point}
+    other = _TRAINER_RUNS.setdefault('final', final)
+    for k, v in final.items():                    # (second parametrisation: same end state as the first)
+        assert scale_err(v, other[k]) < 1e-4, k
+
+
+_TRAINER_RUNS = {}
+
+
+def test_deferred_weight_gradients_fp8_and_jasper():
+    """the deferred mode on the other two engine paths: (a) ``precision: fp8`` with e4m3 weight gradients -- the held-back
+    launch keeps dy's e4m3 copy and its device-side scale alive until the next forward pass; (b) a Jasper stack whose top
+    units carry a residual 1x1 branch (both convolutions of the last unit are deferred).  Same parameters after three steps as
+    the plain FusedSGD step on an identical model."""
+    from gpu_helpers import build_jasper
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd import engine as E
+    from wav2letter_pytorch_amd.optim import FusedSGD
+    kw = dict(lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-3)
+
+    def run(models, batch):
+        x, il, tg, tl = batch
+        opts = []
+        for i, m in enumerate(models):
+            o = FusedSGD.from_sgd(torch.optim.SGD(m.parameters(), **kw))
+            o.overlap = True
+            if i == 0:
+                o.defer_wgrad(m, 2)
+            opts.append(o)
+        for it in range(3):
+            for m, o in zip(models, opts):
+                o.zero_grad(set_to_none=True)
+                out, ol = m(x.cuda(), il)
+                m.criterion(out.transpose(0, 1), tg, ol, tl).backward()
+                o.step()
+        for o in opts:
+            o.join()
+        assert models[0].engine().defer_wgrad == 2
+        for (k, pa), (_, pb) in zip(models[0].named_parameters(), models[1].named_parameters()):
+            assert scale_err(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()) < 1e-4, k
+
+    layers = [(128, 11, 2, 1, 0.0), (256, 13, 1, 1, 0.0), (128, 5, 1, 2, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=91)
+    E.FP8_DGRAD = E.FP8_WGRAD = '1'
+    try:
+        run([build_w2l(layers, sd, 'fp8').train() for _ in range(2)], O.synthetic_batch(4, 300, seed=92, s_lo=8, s_hi=25))
+    finally:
+        E.FP8_DGRAD = E.FP8_WGRAD = 'auto'
+    z = load('jasper_dense.npz')
+    meta = ast.literal_eval(str(z['meta']))
+    jsd = {k[3:]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith('p0/')}
+    il, tg, tl = (torch.from_numpy(z[k]) for k in ('in_lens', 'targets', 'target_lens'))
+    run([build_jasper(meta['blocks'], jsd, 'bf16').train() for _ in range(2)], (torch.from_numpy(z['x']), il, tg, tl))
 
 
 @pytest.mark.parametrize('case', ['w2l_ml3', 'w2l_mix5', 'jasper_dense', 'jasper_sep2'])

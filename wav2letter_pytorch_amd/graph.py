@@ -36,6 +36,8 @@ class GraphedTrainStep:
         model._dropout_counter = self.counter
         self.n_units = len(list(model.conv1ds.children()))
         if hasattr(optimizer, 'overlap'):
+            if hasattr(optimizer, 'defer_wgrad'):
+                optimizer.defer_wgrad(model, 0)  # a graph holds ONE step: nothing of it may be left for the next forward pass
             if hasattr(optimizer, 'join'):
                 optimizer.join()
             optimizer.overlap = False            # inside a graph the updates are a branch of the same step
