@@ -17,7 +17,9 @@
 // reflect (wav2letter.py:28-34) or zero halo, so the hot loop has no padding logic.
 #include "common.h"
 #include "../../include/w2l_hip.h"
+#include <algorithm>
 #include <map>
+#include <vector>
 #include <mutex>
 #include <tuple>
 
@@ -864,11 +866,26 @@ extern "C" int w2l_conv1d_igemm_tune_ws(const void* xp, int64_t x_bstride, int64
     W2L_CHECK_HIP(hipEventCreate(&e0));
     W2L_CHECK_HIP(hipEventCreate(&e1));
     hipStream_t st = (hipStream_t)stream;
-    int best = -1;
-    float best_ms = 1e30f;
     const int saved = g_force_cfg;
     if (reps < 1) reps = 1;
     if (splitk_ws) (void)hipMemsetAsync(splitk_ws, 0, kTicketBytes, st);     // tickets start from zero whatever ran before
+    // time `n` back-to-back launches of candidate i after one warm-up launch (which also validates it); < 0: it did not run
+    auto time_cfg = [&](int i, int n) -> float {
+        g_force_cfg = i;
+        int rc = w2l_conv1d_igemm_ws(xp, x_bstride, x_rows_total, w, y, y_f32, 0, bias, stats_partial, N, Cin, Cout, Tout, Kw,
+                                     stride, dil, splitk_ws, splitk_ws_bytes, stream);
+        if (rc != 0) return -1.f;
+        (void)hipEventRecord(e0, st);
+        for (int r = 0; r < n; ++r)
+            w2l_conv1d_igemm_ws(xp, x_bstride, x_rows_total, w, y, y_f32, 0, bias, stats_partial, N, Cin, Cout, Tout, Kw,
+                                stride, dil, splitk_ws, splitk_ws_bytes, stream);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.f;
+        return ms;
+    };
+    std::vector<std::pair<float, int>> timed;
     for (int i = 0; i < kBaseCfgs * kNumSplits; ++i) {
         if (!cfg_feasible(i, Kw, stride, dil, need128)) continue;
         const int ci = i % kNumCfgs, splits = kSplits[i / kBaseCfgs];
@@ -886,19 +903,25 @@ extern "C" int w2l_conv1d_igemm_tune_ws(const void* xp, int64_t x_bstride, int64
             const double util = (double)blocks / (double)(((blocks + slots - 1) / slots) * slots);
             if (util > 0.92 || blocks * splits > 6 * slots || (Cin / BK) * Kw / splits < 8) continue;
         }
-        g_force_cfg = i;
-        int rc = w2l_conv1d_igemm_ws(xp, x_bstride, x_rows_total, w, y, y_f32, 0, bias, stats_partial, N, Cin, Cout, Tout, Kw,
-                                     stride, dil, splitk_ws, splitk_ws_bytes, stream);   // warm-up (also validates the launch)
-        if (rc != 0) continue;
-        (void)hipEventRecord(e0, st);
-        for (int r = 0; r < reps; ++r)
-            w2l_conv1d_igemm_ws(xp, x_bstride, x_rows_total, w, y, y_f32, 0, bias, stats_partial, N, Cin, Cout, Tout, Kw,
-                                stride, dil, splitk_ws, splitk_ws_bytes, stream);
-        (void)hipEventRecord(e1, st);
-        if (hipEventSynchronize(e1) != hipSuccess) continue;
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
-        if (ms < best_ms) { best_ms = ms; best = i; }
+        const float ms = time_cfg(i, reps);
+        if (ms >= 0.f) timed.emplace_back(ms, i);
+    }
+    // the first pass ranks ~50 candidates on `reps` launches each -- the clock the chip holds drifts over such a sweep by more
+    // than the best candidates differ --, so the three fastest are timed again, interleaved, on twice the launches
+    std::sort(timed.begin(), timed.end());
+    int best = timed.empty() ? -1 : timed[0].second;
+    const int finalists = timed.size() < 3 ? (int)timed.size() : 3;
+    if (finalists > 1) {
+        float total[3] = {0.f, 0.f, 0.f};
+        for (int round = 0; round < 2; ++round)
+            for (int k = 0; k < finalists; ++k) {
+                const float ms = time_cfg(timed[k].second, 2 * reps);
+                total[k] += ms >= 0.f ? ms : 1e30f;
+            }
+        int kb = 0;
+        for (int k = 1; k < finalists; ++k)
+            if (total[k] < total[kb]) kb = k;
+        best = timed[kb].second;
     }
     g_force_cfg = saved;
     (void)hipEventDestroy(e0);
