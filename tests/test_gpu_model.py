@@ -422,7 +422,7 @@ def test_deferred_weight_gradients_fp8_and_jasper():
     from wav2letter_pytorch_amd.optim import FusedSGD
     kw = dict(lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-3)
 
-    def run(models, batch):
+    def run(models, batch, tol=1e-4):
         x, il, tg, tl = batch
         opts = []
         for i, m in enumerate(models):
@@ -441,13 +441,16 @@ def test_deferred_weight_gradients_fp8_and_jasper():
             o.join()
         assert models[0].engine().defer_wgrad == 2
         for (k, pa), (_, pb) in zip(models[0].named_parameters(), models[1].named_parameters()):
-            assert scale_err(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()) < 1e-4, k
+            assert scale_err(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()) < tol, k
 
     layers = [(128, 11, 2, 1, 0.0), (256, 13, 1, 1, 0.0), (128, 5, 1, 2, 0.0)]
     sd = O.init_wav2letter_state(layers, seed=91)
     E.FP8_DGRAD = E.FP8_WGRAD = '1'
     try:
-        run([build_w2l(layers, sd, 'fp8').train() for _ in range(2)], O.synthetic_batch(4, 300, seed=92, s_lo=8, s_hi=25))
+        # (fp8: the two models' split weight gradients add their pieces in different orders -- fp32 atomics --, and a last-bit
+        # difference in a weight can move its e4m3 copy by a whole step of 1/8: measured 0.5e-4 .. 1.2e-4 of scale after three
+        # steps, run to run; the bf16 Jasper leg below stays at 1e-4)
+        run([build_w2l(layers, sd, 'fp8').train() for _ in range(2)], O.synthetic_batch(4, 300, seed=92, s_lo=8, s_hi=25), tol=5e-4)
     finally:
         E.FP8_DGRAD = E.FP8_WGRAD = 'auto'
     z = load('jasper_dense.npz')
