@@ -182,6 +182,7 @@ def main():
                     help='wav2letter = the headline workload; jasper10x5 = BASELINE config 4 (secondary)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp8'],
                     help='fp8 = forward, data-gradient and weight-gradient convolutions on e4m3 operands (BASELINE config 5)')
+    ap.add_argument('--ragged', action='store_true', help='input lengths U{T/2..T} instead of T for every utterance (SURVEY 8d: the second run)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-live-traffic', action='store_true',
                     help='do not start the two rocprofv3 --pmc child passes that measure roofline.traffic (the committed '
@@ -248,7 +249,7 @@ def main():
     else:
         model = Wav2Letter(w2l_cfg(args.mid_layers, precision=args.dtype)).to(dev).train()
     N, T = args.batch, args.frames
-    x, il, tg, tl = synthetic_batch(N, T, seed=1234 + rank)
+    x, il, tg, tl = synthetic_batch(N, T, seed=1234 + rank, ragged=args.ragged)
     x = x.to(dev)
     tg_d, tl_d = tg.to(dev), tl.to(dev)
     ol = model.compute_output_lengths(il).to(dev)
@@ -611,7 +612,8 @@ def main():
             'config': {'workload': ('Jasper 10x5 (13 dense blocks, repeat 5, 322 M params), ' if args.model == 'jasper10x5' else '')
                                    + f'Wav2Letter mid_layers={args.mid_layers} (configuration/model/wav2letter.yaml table), ' * (args.model == 'wav2letter')
                                    +
-                                   f'N={N}/GPU x T={T} x 64 mel, dropout on, fwd+CTC+bwd'
+                                   f'N={N}/GPU x T={T} x 64 mel' + (' (ragged: lengths U{T/2..T}, frames counted at T)' if args.ragged else '')
+                                   + ', dropout on, fwd+CTC+bwd'
                                    + ('' if args.no_optimizer else '+fused SGD(nesterov) step')
                                    + (', step replayed as a hipGraph' if args.graph else ''),
                        'global_batch': world * N, 'frames': T, 'parallelism': f'dp{world}',

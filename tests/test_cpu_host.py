@@ -440,3 +440,17 @@ def test_visible_gpu_count_needs_no_hip(monkeypatch):
         monkeypatch.delenv(var, raising=False)
     n = launch.visible_gpu_count()
     assert n is None or n >= 0
+
+
+def test_synthetic_batch_ragged_layout():
+    """SURVEY 8d's second measurement run: input lengths U{T/2..T} with the longest at T, spectrograms zero beyond their length
+    (the collator's right padding, data_loader.py:149-158), every CTC alignment feasible; the full-length batch is unchanged
+    by the option's existence"""
+    from wav2letter_pytorch_amd.defaults import synthetic_batch
+    x, il, tg, tl = synthetic_batch(16, 400, seed=5, ragged=True)
+    assert int(il.max()) == 400 and int(il.min()) >= 200 and len(set(il.tolist())) > 4
+    for n in range(16):
+        assert not x[n, :, int(il[n]):].any() and x[n, :, :int(il[n])].abs().sum() > 0
+        assert 2 * int(tl[n]) <= int(il[n]) // 2 and not tg[n, int(tl[n]):].any() and (tg[n, :int(tl[n])] > 0).all()
+    xf, ilf, tgf, tlf = synthetic_batch(16, 400, seed=5)
+    assert (ilf == 400).all() and torch.equal(xf[:, :, :200], synthetic_batch(16, 400, seed=5)[0][:, :, :200])

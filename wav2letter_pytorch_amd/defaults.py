@@ -60,14 +60,20 @@ def root_config(model: str = 'wav2letter', **model_kw):
 
 
 def synthetic_batch(N: int, T: int, n_mel: int = 64, seed: int = 1234, s_lo: int = 80, s_hi: int = 160, scaling: int = 2,
-                    n_labels: int = 29):
+                    n_labels: int = 29, ragged: bool = False):
     """Synthetic training batch in _collator's layout: N(0,1) spectrograms [N, n_mel, T] at full length,
     int32 targets U{1..n_labels-1} zero-padded to the longest, target lengths U{s_lo..s_hi} capped so that every CTC
-    alignment is feasible (T' >= 2 S)."""
+    alignment is feasible (T' >= 2 S).  ``ragged`` (SURVEY 8d's second run): input lengths U{T/2..T} with the longest
+    utterance at T, spectrograms zero beyond their length as data_loader.py:149-158 pads them."""
     import torch
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, n_mel, T, generator=g)
     in_lens = torch.full((N,), T, dtype=torch.int32)
+    if ragged:
+        in_lens = torch.randint(T // 2, T + 1, (N,), generator=g, dtype=torch.int32)
+        in_lens[int(torch.argmax(in_lens))] = T
+        for n in range(N):
+            x[n, :, int(in_lens[n]):] = 0.0
     tl = torch.randint(s_lo, s_hi + 1, (N,), generator=g, dtype=torch.int32)
     tl = torch.minimum(tl, (in_lens // scaling // 2).to(torch.int32)).clamp(min=1)
     tg = torch.randint(1, n_labels, (N, int(tl.max())), generator=g, dtype=torch.int32)
