@@ -66,6 +66,35 @@ def cpu_baseline(budget_s=20.0):
                       f'torch CPU ops on {cores} threads of {os.cpu_count()} host cores'}
 
 
+def cpu_baseline_jasper(budget_s=25.0):
+    """the same for the secondary workload (N=2 for Jasper): the oracle's Jasper 10x5 step, fp32, torch CPU ops"""
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd import Jasper
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    cfg = jasper10x5_cfg()
+    blocks = [dict(b) for b in cfg.jasper_blocks]
+    torch.manual_seed(0)
+    sd = {k: v.detach().clone() for k, v in Jasper(cfg).state_dict().items()}       # the module only initialises the weights
+    N, T = 2, 1000
+    x, il, tg, tl = O.synthetic_batch(N, T, seed=1234)
+    t0 = time.perf_counter()
+    O.jasper_step(x, il, tg, tl, sd, blocks)
+    warm = time.perf_counter() - t0
+    nsteps = max(1, min(5, int(budget_s / max(warm, 1e-3))))
+    times = []
+    for _ in range(nsteps):
+        t0 = time.perf_counter()
+        O.jasper_step(x, il, tg, tl, sd, blocks)
+        times.append(time.perf_counter() - t0)
+    best, mean = min(times), sum(times) / len(times)
+    return {'value': round(N * T / best, 1), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'mean_value': round(N * T / mean, 1),
+            'sample': f'Jasper 10x5 fp32 N={N} T={T} (no dropout in this configuration): {nsteps} timed step(s) after 1 warm-up, '
+                      f'best step {best:.3f}s (value), mean step {mean:.3f}s (mean_value), torch CPU ops on {cores} threads of '
+                      f'{os.cpu_count()} host cores'}
+
+
 def csrc_fingerprint():
     """sha256 over the sources of the kernels whose counters profiles/*_pmc_bench.json holds -- the implicit-GEMM and the
     weight-gradient kernels (conv_igemm.hip, conv_wgrad.hip, conv_wgrad_kernel.h, conv_wgrad3_dev.hip, common.h) and the Makefile's flags: the stamp of that file, so
@@ -601,8 +630,8 @@ def main():
 
     if rank == 0:
         cpu = None
-        if world == 1 and not args.no_cpu_baseline and args.model == 'wav2letter':
-            cpu = cpu_baseline()
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline() if args.model == 'wav2letter' else cpu_baseline_jasper()
         line = {
             'metric': (f'audio-frames/sec/GPU (fwd+bwd+CTC), Wav2Letter 64-mel x 1000-frame {args.dtype}' if args.model == 'wav2letter'
                        else f'audio-frames/sec/GPU (fwd+bwd+CTC), Jasper 10x5 {args.dtype} (secondary workload)'),

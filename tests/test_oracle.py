@@ -86,6 +86,26 @@ def test_jasper_end_to_end_matches_reference(case):
     np.testing.assert_allclose(out_eval.detach().numpy(), z['out_eval'], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('case', ['jasper_sep2', 'jasper_dense', 'jasper_nomask'])
+def test_jasper_step_matches_reference(case):
+    """O.jasper_step (bench.py's CPU baseline for the Jasper workload) against the reference-generated fixtures: loss,
+    log-probs, output lengths, every parameter gradient, the BatchNorm buffers after the step"""
+    z = load(case + '.npz')
+    meta = meta_of(z)
+    sd = sd_from(z)
+    r = O.jasper_step(torch.from_numpy(z['x']), torch.from_numpy(z['in_lens']), torch.from_numpy(z['targets']),
+                      torch.from_numpy(z['target_lens']), sd, meta['blocks'])
+    np.testing.assert_allclose(r['log_probs'].numpy(), z['log_probs'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(r['out_lens'].numpy(), z['out_lens'])
+    assert abs(float(r['loss']) - float(z['loss'])) < 1e-4 * max(1.0, abs(float(z['loss'])))
+    for k, g in r['grads'].items():
+        ref = z['g/' + k]
+        assert np.abs(g.numpy() - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-6) + 2e-5, k
+    for k in z.files:
+        if k.startswith('p1/') and 'running_' in k:
+            np.testing.assert_allclose(sd[k[3:]].numpy(), z[k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
 def test_conv1dblock_ops_numpy_restatement():
     z = load('ops_conv1dblock.npz')
     for tag in ['asym_s2', 'dil2', 'k1', 'even_k13']:
