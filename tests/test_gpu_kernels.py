@@ -210,14 +210,15 @@ def test_conv_igemm_every_configuration(L, with_stats):
     assert split_ran >= 100, split_ran
 
 
-@pytest.mark.parametrize('Kw,s,d', [(5, 1, 2), (6, 1, 1), (7, 1, 2), (8, 1, 1), (11, 2, 1)])
+@pytest.mark.parametrize('Kw,s,d', [(5, 1, 2), (6, 1, 1), (7, 1, 2), (8, 1, 1), (11, 2, 1), (7, 1, 3), (7, 1, 4), (7, 1, 5)])
 def test_conv_wgrad_every_plan(L, Kw, s, d):
     """split counts x both block orders x {one tap group, two tap groups, 32x32x16 MFMA fragments (order bit 3; stride 1),
     three taps per block with the accumulators in AGPRs (order bit 4: the code object of conv_wgrad3_dev.hip; its last tap
     group holds 2 taps at Kw = 5 and 8, 3 at Kw = 6, 1 at Kw = 7)} per block (the autotuner's search space).  Tap counts
     4k+1 .. 4k+4: with two tap groups (the 8-wave kernel, order bit 2) the last block then has an idle tap group and a
     one-tap wave (Kw = 5), an idle tap group (6), a one-tap second group (7), or is full (8); stride 2 takes the other
-    instantiation"""
+    instantiation; dilation 3 and 4 fill the three-tap kernels' static LDS windows (72 / 88 rows) to the last row, dilation 5
+    is beyond them: those plans take the two-tap kernels"""
     N, Cin, Cout, T, pl, pr = 3, 192, 320, 333, 4, 4
     x, w, b = conv_inputs(N, Cin, Cout, Kw, T, pl, pr, 12)
     xp = to_ntc_padded(x, pl, pr, 1)
