@@ -228,9 +228,12 @@ def main():
     ap.add_argument('--early-collective', action='store_true',
                     help='with --force-dp: run one collective before the first step, as the parameter broadcast of a multi-rank run '
                          'does (the communicator and its streams then exist before the engine creates its side streams)')
-    ap.add_argument('--no-collective-ab', action='store_true',
-                    help='data-parallel runs: skip the in-run A/B of the two collective paths (torch.distributed vs the C ABI\'s '
-                         'RCCL helpers) and keep torch.distributed (or what W2L_DP_NATIVE says)')
+    ap.add_argument('--collective-ab', action='store_true',
+                    help='data-parallel runs: after the complete record, time the same region once more with the gradient '
+                         'collectives through the C ABI\'s RCCL helpers and keep the faster path.  OPT-IN: that path has never run '
+                         'more than one rank, so the leg runs under a watchdog that prints the record in hand and ends the '
+                         'process with exit code 3 ("record valid, native leg abandoned") should a collective never return')
+    ap.add_argument('--no-collective-ab', action='store_true', help='(the default since round 5; kept for old command lines)')
     ap.add_argument('--serial-wgrad', action='store_true', help='keep weight gradients on the main stream (clean per-kernel durations for profiling)')
     ap.add_argument('--trace-steps', action='store_true', help='per-step host-enqueue vs GPU time (stderr), then exit')
     ap.add_argument('--event-trace', default=None, metavar='CSV',
@@ -682,12 +685,13 @@ def main():
     # (ProcessGroupNCCL: its own internal stream, the one stream of the step streams.py cannot probe).  Now the same timed
     # region once more through the C ABI's RCCL helpers (NativeComm: a collective is a launch on the reducer's probed stream);
     # if that is faster it becomes the record.  RCCL through this path has never run more than one rank, so the leg is bounded:
-    # the communicator is created on a helper thread with a deadline, and a watchdog prints the record already in hand and
-    # ends the process (exit code 0: the timed region it reports did complete) should a native collective never return.  The
+    # the leg is opt-in (--collective-ab), the communicator is created on a helper thread with a deadline, and a watchdog prints
+    # the record already in hand and ends the process with exit code 3 should a native collective never return.  The
     # two communicators never have work in flight together: every switch sits between two fences (device sync + barrier).
     reducer0 = getattr(model, 'grad_reducer', None)
     forced_native = os.environ.get('W2L_DP_NATIVE')
-    if (reducer0 is not None and reducer0.active and not args.no_collective_ab and not args.graph and forced_native is None):
+    if (reducer0 is not None and reducer0.active and args.collective_ab and not args.no_collective_ab and not args.graph
+            and forced_native is None):
         import threading
         leg_s = float(os.environ.get('W2L_AB_TIMEOUT', '150'))
         native, via_torch = 'w2l_rccl_* (C ABI)', 'torch.distributed'
@@ -698,7 +702,7 @@ def main():
         def give_up():
             collective_paths['native_unavailable'] = f'the native-collective leg did not finish within {leg_s:.0f} s: abandoned'
             emit()
-            os._exit(0)
+            os._exit(3)       # never 0: a rank stuck in a collective is not a clean exit, whatever it printed first
 
         watchdog = threading.Timer(leg_s, give_up)
         watchdog.daemon = True

@@ -779,7 +779,7 @@ def test_bench_self_launch_two_ranks(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     env['W2L_DIST_BACKEND'] = 'gloo'
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--mid-layers', '2',
-           '--batch', '2', '--frames', '200', '--no-cpu-baseline', '--defer-wgrad', '1']
+           '--batch', '2', '--frames', '200', '--no-cpu-baseline', '--defer-wgrad', '1', '--collective-ab']
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]

@@ -196,6 +196,7 @@ def trace_launches(enable: bool, capacity: int = 4096):
     ``capacity`` launches are created up front (hipEventCreate costs more than the launch it brackets)"""
     if enable and _trace['rows'] is None:
         _trace['rows'] = []
+    if enable and not _trace['saved']:           # (re-)wrap whenever the entry points are not wrapped, whatever rows holds
         _trace['pool'] = [torch.cuda.Event(enable_timing=True) for _ in range(2 * capacity)]
         for name, label in TRACE_NAMES.items():
             fn = getattr(lib, name)
@@ -212,7 +213,7 @@ def trace_launches(enable: bool, capacity: int = 4096):
                 return rc
 
             setattr(lib, name, wrapper)
-    elif not enable and _trace['rows'] is not None:
+    elif not enable:
         for name, fn in _trace['saved'].items():
             setattr(lib, name, fn)
         _trace['saved'] = {}
@@ -222,6 +223,7 @@ def trace_dump(path: str) -> int:
     """write the recorded launches as a rocprofv3-style kernel trace (csv) and forget them; returns the row count.
     The device must be idle (torch.cuda.synchronize()) -- event times are read back."""
     rows, _trace['rows'] = _trace['rows'] or [], None
+    _trace['pool'] = []
     if not rows:
         return 0
     origin = rows[0][2]

@@ -104,7 +104,13 @@ class ConvCTCASR(_Base):
     def invalidate_engine(self):
         """drop the cached StackEngine (call after replacing a Parameter / buffer OBJECT by hand; ``module.to()`` and
         friends do it themselves, in-place updates -- optimizers, load_state_dict -- never need it)"""
-        self.__dict__.pop('_engine_cache', None)
+        hit = self.__dict__.pop('_engine_cache', None)
+        eng = hit[1] if hit is not None else None
+        if eng is not None and getattr(eng, '_deferred', None):
+            # weight gradients held back for the next forward pass (optim.FusedSGD.defer_wgrad) live in the engine: a stepped
+            # batch's updates are applied before the engine goes (the optimizer only holds engines weakly)
+            eng.flush_deferred()
+            eng.join_side()
 
     def _cached_engine(self, build: Callable[[], 'object']):
         """The StackEngine of this module tree, built once and kept until the module is moved / cast (``_apply``) or

@@ -138,9 +138,10 @@ static size_t wgrad_ws_need(int Cin, int Cout, int Kw, int splits) {
     const size_t tiles_mn = (size_t)((Cout + BM - 1) / BM) * ((Cin + BNC - 1) / BNC);
     size_t taps = 1;
     if (Kw > 1) {
+        // (2, 4, 3 and 6 taps per block: the two-tap kernel, its two-tap-group form, the three-tap kernel and its two-tap-group form)
         const size_t t2 = (size_t)((Kw + 1) / 2) * 2, t4 = (size_t)((Kw + 3) / 4) * 4, t3 = (size_t)((Kw + 2) / 3) * 3;
-        taps = t2 > t4 ? t2 : t4;
-        taps = taps > t3 ? taps : t3;
+        const size_t t6 = (size_t)((Kw + 5) / 6) * 6;
+        taps = std::max(std::max(t2, t4), std::max(t3, t6));
     }
     return kWgradTicketBytes + tiles_mn * taps * splits * BM * BNC * sizeof(float);
 }

@@ -1190,7 +1190,11 @@ class StackEngine:
         elif ui not in k and ui - n not in k:           # an explicit set of unit indices (negative: counted from the top)
             return False
         w = conv.weight
-        # a gradient that autograd would ADD to an existing .grad (accumulation steps) is computed now
+        # a gradient that autograd would ADD to an existing .grad (accumulation steps) is computed now; so is a second
+        # gradient of a weight whose first one is still held back (two backward passes before one step(): the optimizer
+        # adds the held one to .grad at step() -- one update with the sum, as torch.optim.SGD would make)
+        if any(r['conv'].weight is w for r in self._deferred):
+            return False
         return (w.is_cuda and w.grad is None and not torch.cuda.is_current_stream_capturing() and opt.accepts(w))
 
     def flush_deferred(self):
@@ -1213,12 +1217,7 @@ class StackEngine:
 
         live = [r for r in recs if opt is not None and opt.stepped(r['token'])]
         stale = [r for r in recs if not (opt is not None and opt.stepped(r['token']))]
-        for r in stale:                    # nobody stepped: plain gradients, on the caller's stream
-            self._wgrad_now(r['conv'], r['pk'], r['dy_hi'], r['dy_lo'], r['halo'], r['Tout'], r['src'], {}, f8=r['f8'], sink=sink)
-            w, g, _, work = pending.pop()
-            if work is not None:
-                work.finish()
-            w.grad = g if w.grad is None else w.grad + g
+        self._materialize(stale)           # nobody stepped (and nobody called zero_grad): plain gradients, accumulated
         if not live:
             return
         fork = None
@@ -1243,6 +1242,36 @@ class StackEngine:
                     opt.apply(w, g)
         if fork is not None:
             self._side_used = True
+
+    def _materialize(self, recs):
+        """held-back gradients computed NOW, on the caller's stream, and added to ``param.grad`` as autograd would have"""
+        pending = []
+
+        def sink(w, g, storage):
+            pending.append((w, g, storage, self.grad_reduce_start(storage) if self.grad_reduce_start is not None else None))
+
+        for r in recs:
+            self._wgrad_now(r['conv'], r['pk'], r['dy_hi'], r['dy_lo'], r['halo'], r['Tout'], r['src'], {}, f8=r['f8'], sink=sink)
+            w, g, _, work = pending.pop()
+            if work is not None:
+                work.finish()
+            w.grad = g if w.grad is None else w.grad + g
+
+    def drop_unstepped(self):
+        """optimizer.zero_grad(): gradients held back by a backward pass that no step() followed are discarded with the
+        rest (a skipped step must not resurface in the next one); those of a stepped batch stay -- they are that step's
+        update, still to be applied"""
+        opt = self.deferred
+        self._deferred = [r for r in self._deferred if opt is not None and opt.stepped(r['token'])]
+
+    def settle_before_step(self):
+        """optimizer.step(): a held-back gradient whose weight ALSO has a ``.grad`` (a second backward pass ran before this
+        step) joins it now, so that the weight gets ONE update with the summed gradient"""
+        opt = self.deferred
+        both = [r for r in self._deferred if r['conv'].weight.grad is not None and not (opt is not None and opt.stepped(r['token']))]
+        if both:
+            self._deferred = [r for r in self._deferred if not any(r is b for b in both)]
+            self._materialize(both)
 
     def join_side(self):
         """the current stream waits for the weight-gradient stream (deferred gradients and their updates run there)"""

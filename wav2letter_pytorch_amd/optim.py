@@ -21,6 +21,7 @@ consumes the gradient directly); ``join()`` flushes whatever is pending."""
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 
@@ -74,9 +75,22 @@ class FusedSGD(torch.optim.SGD):
         model._deferred_opt = self if units else None
 
     def _register_engine(self, eng):
-        engines = self._deferred_state()['engines']
-        if not any(e is eng for e in engines):
-            engines.append(eng)
+        # weak references: a model that rebuilds its engine (module.to(), load_state_dict of replaced tensors) must not keep
+        # every dead engine -- its streams and held tensors -- alive through the optimizer
+        st = self._deferred_state()
+        st['engines'] = [r for r in st['engines'] if r() is not None]
+        if not any(r() is eng for r in st['engines']):
+            st['engines'].append(weakref.ref(eng))
+
+    def _engines(self):
+        return [e for e in (r() for r in self._deferred_state()['engines']) if e is not None]
+
+    def zero_grad(self, set_to_none: bool = True):
+        """torch's zero_grad, plus: weight gradients held back by a backward pass that no step() followed are dropped with
+        the rest (a skipped step -- non-finite loss guard, manual skip -- must not leak into the next one)"""
+        for eng in self._engines():
+            eng.drop_unstepped()
+        return super().zero_grad(set_to_none=set_to_none)
 
     def accepts(self, p) -> bool:
         """would step() take this parameter through the fused conv-weight update?"""
@@ -110,7 +124,7 @@ class FusedSGD(torch.optim.SGD):
     def join(self):
         """make the current stream wait for every update of the last step: deferred weight gradients are launched and
         applied first, then the weight-gradient stream and the optimizer's side stream are joined"""
-        for eng in self._deferred_state()['engines']:
+        for eng in self._engines():
             eng.flush_deferred()
             eng.join_side()
         self._join_updates()
@@ -145,6 +159,8 @@ class FusedSGD(torch.optim.SGD):
             with torch.enable_grad():
                 loss = closure()
         self._join_updates()         # (normally a no-op: the forward pass has already waited for every event)
+        for eng in self._engines():  # a weight with BOTH a held-back gradient and a .grad gets one update with their sum
+            eng.settle_before_step()
         st = self._side_state()
         dst = self._deferred_state()
         dst['seq'] += 1              # gradients deferred by the backward pass just run now count as "stepped"

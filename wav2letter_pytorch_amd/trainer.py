@@ -90,19 +90,22 @@ class Trainer:
         optimizers, schedulers = model.configure_optimizers()
         opt = optimizers[0]
         model._optimizers = opt
-        if hasattr(opt, 'overlap'):          # optim.FusedSGD: weight updates stream under the next forward pass
-            opt.overlap = True
-            # ... and the top units' weight gradients run beside it (W2L_DEFER_WGRAD=k, 0 = off; default: 4 of a deep stack)
-            n_units = len(model.engine().units) if hasattr(model, 'engine') else 0
-            k = int(os.environ.get('W2L_DEFER_WGRAD', min(4, n_units // 4)))
-            if k and hasattr(opt, 'defer_wgrad'):
-                opt.defer_wgrad(model, k)
         join = getattr(opt, 'join', lambda: None)
         first_epoch = 0
         ckpt_path = ckpt_path or self.resume_from_checkpoint
         if ckpt_path:
             first_epoch = self._restore(ckpt_path, model, optimizers, schedulers)
             self._say(f'resumed from {ckpt_path}: epoch {first_epoch}, step {self.global_step}')
+        if hasattr(opt, 'overlap'):          # optim.FusedSGD: weight updates stream under the next forward pass
+            opt.overlap = True
+            # ... and the top units' weight gradients run beside it (W2L_DEFER_WGRAD=k, 0 = off; default: 4 of a deep stack).
+            # While a gradient is held back ``p.grad`` of that weight is None at step() ("Deferred weight
+            # gradients"): set W2L_DEFER_WGRAD=0 for anything that reads gradients between backward() and step().
+            # (after the restore: load_state_dict drops the step engine, which is what counts the units)
+            n_units = len(model.engine().units) if hasattr(model, 'engine') else 0
+            k = int(os.environ.get('W2L_DEFER_WGRAD', min(4, n_units // 4)))
+            if k and hasattr(opt, 'defer_wgrad'):
+                opt.defer_wgrad(model, k)
         done = self.max_steps is not None and self.global_step >= self.max_steps
         for epoch in range(first_epoch, self.max_epochs):
             if done:
