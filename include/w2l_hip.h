@@ -159,7 +159,27 @@ int w2l_conv1d_wgrad_tune_ws(const void* dy, int64_t dy_bstride, const void* xp,
 int w2l_wgrad_needs_zero_ws(int N, int Cin, int Cout, int Tout, int Kw, int64_t ws_bytes);
 int64_t w2l_wgrad_workspace_bytes(int Cin, int Cout, int Kw);
 
-/* Testing / profiling hook: pin the split count (0 = automatic) and the plan order (-1 = automatic; bit 0 = block order,
+/* Dealt stream-K (round 5; plan order bit 5, the plan's split field = the number of ranges G): the (tile, K step) space of
+ * the launch is cut into G equal ranges, one per resident block slot (512 / 256), so the chip is full whatever the tile
+ * count.  A range crosses at most one tile boundary; each of its one or two segments is a block of its own (the kernel stays
+ * the one-segment kernel): the first G blocks take the first segments, the following blocks the second segments LONGEST FIRST,
+ * so the slot that frees first gets the longest remainder.  Partial tiles go through fp32 slabs of the caller's workspace,
+ * the last arriver of a tile sums them in range order: no atomics, no zero-filled dw, bit-reproducible.  The plan needs
+ * w2l_wgrad_dealt_workspace_bytes(); a launch without it (or of a shape without a dealt form) falls back to an atomic split.
+ * w2l_conv1d_wgrad_tune_x = w2l_conv1d_wgrad_tune_ws with flags: bit 0 = classic split / stream-K plans are measured and run
+ * with fp32 atomics although a workspace is given (plan order bit 6) -- the workspace then only serves dealt plans.
+ * w2l_wgrad_needs_zero_x: must dw be zero-filled for this launch?  Exact (w2l_wgrad_needs_zero_ws assumes stride 1, dilation 1).
+ * w2l_wgrad_dealt_segments (host only, testing): the blocks of a dealt launch in launch order, six ints each (range, tile,
+ * first step, end step, place among the tile's segments, number of them); returns the block count, -1: no dealt form. */
+int64_t w2l_wgrad_dealt_workspace_bytes(int Cin, int Cout, int Kw);
+int w2l_conv1d_wgrad_tune_x(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride, int64_t x_rows_total,
+                            float* dw_scratch, int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int reps,
+                            void* ws, int64_t ws_bytes, int flags, void* stream);
+int w2l_wgrad_needs_zero_x(int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int64_t ws_bytes);
+int w2l_wgrad_dealt_segments(int tiles, int steps, int ranges, int* out, int max_blocks);
+
+/* Testing / profiling hook: pin the split count (0 = automatic; a dealt plan: the range count) and the plan order (-1 =
+ * automatic; bit 5 = dealt stream-K, bit 6 = atomics although a workspace is given, see above; bit 0 = block order,
  * bit 1 = stream-K decomposition, bit 2 = two tap groups per 8-wave block, bit 3 = 32x32x16 MFMA tiles, bit 4 = THREE taps
  * per wave with the 192 accumulator registers in AGPRs (stride 1, dilation <= 4; alone: two 4-wave blocks per CU, with bit
  * 2: one 8-wave block of six taps per CU -- the kernels of csrc/conv_wgrad3_dev.hip, a code object of their own embedded in

@@ -454,3 +454,55 @@ def test_synthetic_batch_ragged_layout():
         assert 2 * int(tl[n]) <= int(il[n]) // 2 and not tg[n, int(tl[n]):].any() and (tg[n, :int(tl[n])] > 0).all()
     xf, ilf, tgf, tlf = synthetic_batch(16, 400, seed=5)
     assert (ilf == 400).all() and torch.equal(xf[:, :, :200], synthetic_batch(16, 400, seed=5)[0][:, :, :200])
+
+
+@pytest.mark.parametrize('tiles,S,G', [(175, 256, 512), (324, 256, 512), (490, 256, 512), (245, 256, 256), (96, 256, 512),
+                                       (512, 256, 512), (1, 24, 7), (18, 18, 20), (100, 2000, 512), (36, 15, 256), (7, 3, 8)])
+def test_dealt_stream_k_decomposition_covers_every_step_once(tiles, S, G):
+    """the dealt stream-K plan of the weight gradient (include/w2l_hip.h: w2l_wgrad_dealt_segments runs the SAME arithmetic as
+    the kernel and the launcher, csrc/conv_wgrad_kernel.h dealt_segment): every (tile, K step) belongs to exactly one block, the
+    blocks of a tile are numbered 0 .. n-1 in step order (the order the last arriver sums their slabs in), the first G blocks
+    are the ranges' first segments, the following ones the second segments, longest first, and every slot's two segments add
+    up to one range"""
+    import ctypes as C
+    from wav2letter_pytorch_amd import _lib
+    buf = (C.c_int * (6 * 2 * G))()
+    n = _lib.lib.w2l_wgrad_dealt_segments(tiles, S, G, buf, 2 * G)
+    assert G <= n <= 2 * G
+    rows = np.array(buf[:6 * n]).reshape(n, 6)
+    assert (rows[:G, 0] >= 0).all()
+    # second segments are dealt per XCD (block G + j runs where blocks j % 8 ran, and takes one of THEIR ranges' second
+    # segments, longest first; -1 = a padding position: that XCD has none left)
+    q, rem = G >> 3, G & 7
+    xcd_of = {}
+    for x in range(8):
+        base = x * (q + 1) if x < rem else rem * (q + 1) + (x - rem) * q
+        for r in range(base, base + (q + 1 if x < rem else q)):
+            xcd_of[r] = x
+    for x in range(8):
+        mine = rows[G + x::8]
+        mine = mine[mine[:, 0] >= 0]
+        assert all(xcd_of[int(r)] == x for r in mine[:, 0])
+        ln = mine[:, 3] - mine[:, 2]
+        assert (ln[:-1] >= ln[1:]).all() and (mine[:, 2] == 0).all()
+    rows = rows[rows[:, 0] >= 0]
+    cover = np.zeros((tiles, S), dtype=np.int32)
+    per_tile = {}
+    for r, t, s0, s1, place, cnt in rows:
+        assert 0 <= t < tiles and 0 <= s0 < s1 <= S and 0 <= place < cnt
+        cover[t, s0:s1] += 1
+        per_tile.setdefault(int(t), []).append((int(s0), int(place), int(cnt), int(r)))
+    assert (cover == 1).all()
+    for t, segs in per_tile.items():
+        segs.sort()
+        assert [p for _, p, _, _ in segs] == list(range(len(segs))) and all(c == len(segs) for _, _, c, _ in segs)
+        assert [r for _, _, _, r in segs] == list(range(segs[0][3], segs[0][3] + len(segs)))     # consecutive ranges: slab r + t
+    # first segments of all G ranges (each range once), then second segments by descending length
+    assert sorted(rows[:G, 0]) == list(range(G))
+    length = {}
+    for r, t, s0, s1, _, _ in rows:
+        length[int(r)] = length.get(int(r), 0) + int(s1 - s0)
+    W = tiles * S
+    assert all(length[r] == W * (r + 1) // G - W * r // G for r in range(G))
+    # no dealt form: more tiles than ranges, or fewer steps than ranges
+    assert _lib.lib.w2l_wgrad_dealt_segments(G + 1, S, G, buf, 2 * G) == -1

@@ -230,6 +230,7 @@ def test_conv_wgrad_every_plan(L, Kw, s, d):
     dyp = to_ntc_padded(dy, hb, ha, 0, Cout)
     drows = dyp.shape[1]
     dyh, xh = dyp.to(torch.bfloat16).cuda(), xp.to(torch.bfloat16).cuda()
+    dyh_neg = dyh * 2          # (a power of two: exact; a sign flip is not -- the matrix cores do not round symmetrically)
     wr = bf(w).requires_grad_(True)
     F.conv1d(F.pad(bf(x), (pl, pr), mode='reflect'), wr, None, stride=s, dilation=d).backward(bf(dy))
     ws = torch.zeros(int(L.lib.w2l_wgrad_workspace_bytes(Cin, Cout, Kw)), dtype=torch.uint8, device='cuda')
@@ -259,6 +260,14 @@ def test_conv_wgrad_every_plan(L, Kw, s, d):
                     outs.append(dw2)
                 assert torch.equal(outs[0], outs[1]) and not ws[:65536].any(), (splits, order)
                 assert relerr(outs[0].cpu().permute(1, 2, 0), wr.grad) < 2e-3, (splits, order)
+                # the same plan and workspace on OTHER data: a slab line left in a cache by the launch before would show (the
+                # slabs are stored and loaded past the non-coherent caches: sc1); dy * 2 is exact, so is the result
+                dw3 = torch.full((Kw, Cout, Cin), float('nan'), device='cuda')
+                L.check(L.lib.w2l_conv1d_wgrad_ws(C.c_void_p(dyh_neg.data_ptr() + hb * Cout * 2), drows * Cout, L.ptr(xh),
+                                                  rows * Cin, N * rows, L.ptr(dw3), N, Cin, Cout, Tout, Kw, s, d, 0, L.ptr(ws),
+                                                  ws.numel(), L.stream_ptr()))
+                torch.cuda.synchronize()
+                assert torch.equal(dw3, outs[0] * 2), (splits, order)
                 # accumulate = 1 adds to what is there
                 L.check(L.lib.w2l_conv1d_wgrad_ws(C.c_void_p(dyh.data_ptr() + hb * Cout * 2), drows * Cout, L.ptr(xh), rows * Cin,
                                                   N * rows, L.ptr(outs[1]), N, Cin, Cout, Tout, Kw, s, d, 1, L.ptr(ws), ws.numel(),
@@ -267,6 +276,61 @@ def test_conv_wgrad_every_plan(L, Kw, s, d):
                 assert relerr(outs[1].cpu().permute(1, 2, 0), 2 * wr.grad) < 2e-3, (splits, order)
             finally:
                 L.lib.w2l_wgrad_force_plan(0, -1)
+    # dealt stream-K (order bit 5; the split field is the range count G): the (tile, step) space cut into G ranges whose one or
+    # two segments are blocks of their own, partial tiles through slabs + ticket -- stores over a NaN-filled dw, twice:
+    # bit-identical, tickets back at zero.  G = 40 / 97 / 256 against 6 .. 36 tiles x 18 steps: ranges shorter and longer than a
+    # tile's third, one-step segments, whole tiles; a form without a dealt geometry here (fewer steps than ranges, more
+    # tiles than ranges) must say so through w2l_wgrad_needs_zero_x and run its atomic fallback correctly
+    dws = torch.zeros(max(1 << 20, int(L.lib.w2l_wgrad_dealt_workspace_bytes(Cin, Cout, Kw))), dtype=torch.uint8, device='cuda')
+    dealt_ran = 0
+    for G in (40, 97, 256):
+        for order in (32, 33, 36, 37, 40, 41, 48, 49, 52, 53):
+            L.lib.w2l_wgrad_force_plan(G, order)
+            try:
+                zero = L.lib.w2l_wgrad_needs_zero_x(N, Cin, Cout, Tout, Kw, s, d, ws.numel())
+                assert L.lib.w2l_wgrad_needs_zero(N, Cin, Cout, Tout, Kw) == 1          # no workspace: the atomic fallback
+                outs = []
+                for rep in range(2):
+                    dw2 = torch.zeros(Kw, Cout, Cin, device='cuda') if zero else torch.full((Kw, Cout, Cin), float('nan'), device='cuda')
+                    L.check(L.lib.w2l_conv1d_wgrad_ws(C.c_void_p(dyh.data_ptr() + hb * Cout * 2), drows * Cout, L.ptr(xh),
+                                                      rows * Cin, N * rows, L.ptr(dw2), N, Cin, Cout, Tout, Kw, s, d, 0, L.ptr(ws),
+                                                      ws.numel(), L.stream_ptr()))
+                    torch.cuda.synchronize()
+                    outs.append(dw2)
+                assert relerr(outs[0].cpu().permute(1, 2, 0), wr.grad) < 2e-3, (G, order, zero)
+                assert not ws[:65536].any(), (G, order)
+                if not zero:
+                    dealt_ran += 1
+                    assert torch.equal(outs[0], outs[1]), (G, order)
+                    dw3 = torch.full((Kw, Cout, Cin), float('nan'), device='cuda')       # other data, same slabs: nothing stale
+                    L.check(L.lib.w2l_conv1d_wgrad_ws(C.c_void_p(dyh_neg.data_ptr() + hb * Cout * 2), drows * Cout, L.ptr(xh),
+                                                      rows * Cin, N * rows, L.ptr(dw3), N, Cin, Cout, Tout, Kw, s, d, 0, L.ptr(ws),
+                                                      ws.numel(), L.stream_ptr()))
+                    torch.cuda.synchronize()
+                    assert torch.equal(dw3, outs[0] * 2), (G, order)
+                    L.check(L.lib.w2l_conv1d_wgrad_ws(C.c_void_p(dyh.data_ptr() + hb * Cout * 2), drows * Cout, L.ptr(xh), rows * Cin,
+                                                      N * rows, L.ptr(outs[1]), N, Cin, Cout, Tout, Kw, s, d, 1, L.ptr(ws), ws.numel(),
+                                                      L.stream_ptr()))
+                    torch.cuda.synchronize()
+                    assert relerr(outs[1].cpu().permute(1, 2, 0), 2 * wr.grad) < 2e-3, (G, order)
+                # the workspace sized for the dealt plans of this layer (what the step engine passes by default) is enough
+                # for every dealt form of G <= 256 ranges of it
+                if not zero and G <= 256:
+                    assert L.lib.w2l_wgrad_needs_zero_x(N, Cin, Cout, Tout, Kw, s, d, dws.numel()) == 0, (G, order)
+            finally:
+                L.lib.w2l_wgrad_force_plan(0, -1)
+    assert dealt_ran >= 12, dealt_ran
+    # bit 6: a classic split adds atomically although a workspace is given (the default mode's classic plans)
+    L.lib.w2l_wgrad_force_plan(3, 64 | 1)
+    try:
+        assert L.lib.w2l_wgrad_needs_zero_x(N, Cin, Cout, Tout, Kw, s, d, ws.numel()) == 1
+        dw = torch.zeros(Kw, Cout, Cin, device='cuda')
+        L.check(L.lib.w2l_conv1d_wgrad_ws(C.c_void_p(dyh.data_ptr() + hb * Cout * 2), drows * Cout, L.ptr(xh), rows * Cin, N * rows,
+                                          L.ptr(dw), N, Cin, Cout, Tout, Kw, s, d, 0, L.ptr(ws), ws.numel(), L.stream_ptr()))
+        torch.cuda.synchronize()
+        assert relerr(dw.cpu().permute(1, 2, 0), wr.grad) < 2e-3
+    finally:
+        L.lib.w2l_wgrad_force_plan(0, -1)
     # stream-K decomposition (order bit 1): persistent blocks cut the (tile, step) space into equal ranges that straddle
     # tile boundaries (18 tiles x 18 steps over 20 blocks here); whole tiles are stored, pieces are added atomically
     # 6, 7: the 8-wave (two tap groups) stream-K form; 18: stream-K asked of the three-tap form -> the two-tap stream-K kernel
@@ -283,6 +347,42 @@ def test_conv_wgrad_every_plan(L, Kw, s, d):
                 assert relerr(dw.cpu().permute(1, 2, 0), rep * wr.grad) < 2e-3, (order, rep)
         finally:
             L.lib.w2l_wgrad_force_plan(0, -1)
+
+
+@pytest.mark.parametrize('order', [0, 4, 16, 20, 21])
+def test_conv_wgrad_workspace_holds_the_largest_split(L, order):
+    """w2l_wgrad_workspace_bytes must cover the slabs of EVERY block form at the largest split count the tuner tries (32):
+    the six-tap form (order 20 / 21) rounds 7 taps up to 12, more than the two-, three- and four-tap forms.  The workspace is
+    carved out of a larger buffer whose tail is a sentinel: nothing may be written past the reported size."""
+    N, Cin, Cout, Kw, T, s, d = 8, 128, 128, 7, 1000, 1, 1           # 8 x 16 steps: 32 ranges of 4 (what the tuner tries from 128 steps)
+    x, w, b = conv_inputs(N, Cin, Cout, Kw, T, 3, 3, 21)
+    xp = to_ntc_padded(x, 3, 3, 1)
+    rows = xp.shape[1]
+    Tout = rows - (Kw - 1) * d
+    dy = torch.randn(N, Cout, Tout, generator=torch.Generator().manual_seed(22))
+    hb = (Kw - 1) * d
+    ha = max(hb, (Tout + 63) // 64 * 64 - Tout)
+    dyp = to_ntc_padded(dy, hb, ha, 0, Cout)
+    drows = dyp.shape[1]
+    dyh, xh = dyp.to(torch.bfloat16).cuda(), xp.to(torch.bfloat16).cuda()
+    wr = bf(w).requires_grad_(True)
+    F.conv1d(F.pad(bf(x), (3, 3), mode='reflect'), wr, None).backward(bf(dy))
+    need = int(L.lib.w2l_wgrad_workspace_bytes(Cin, Cout, Kw))
+    guard = 8 << 20
+    buf = torch.zeros(need + guard, dtype=torch.uint8, device='cuda')
+    buf[need:] = 0xA5
+    assert N * ((Tout + 63) // 64) >= 4 * 32
+    L.lib.w2l_wgrad_force_plan(32, order)
+    try:
+        assert L.lib.w2l_wgrad_needs_zero_ws(N, Cin, Cout, Tout, Kw, need) == 0       # the slab path, not atomics
+        dw = torch.full((Kw, Cout, Cin), float('nan'), device='cuda')
+        L.check(L.lib.w2l_conv1d_wgrad_ws(C.c_void_p(dyh.data_ptr() + hb * Cout * 2), drows * Cout, L.ptr(xh), rows * Cin, N * rows,
+                                          L.ptr(dw), N, Cin, Cout, Tout, Kw, s, d, 0, L.ptr(buf), need, L.stream_ptr()))
+        torch.cuda.synchronize()
+    finally:
+        L.lib.w2l_wgrad_force_plan(0, -1)
+    assert relerr(dw.cpu().permute(1, 2, 0), wr.grad) < 2e-3
+    assert bool((buf[need:] == 0xA5).all()), 'slabs written past the reported workspace size'
 
 
 @pytest.mark.parametrize('case', [c for c in CONV_CASES if c[4] == 1])

@@ -298,6 +298,69 @@ def test_deferred_weight_gradients_match_plain_sgd(k):
     assert ma.engine().defer_wgrad == 0
 
 
+def test_deferred_weight_gradients_skipped_step_and_double_backward():
+    """the two ways a held-back gradient could leak (round-4 advisor finding): (1) backward, NO step (a non-finite-loss guard),
+    optimizer.zero_grad(), next batch: the skipped batch's top-layer gradients must be gone -- zero_grad drops them --, not
+    resurface in the next step; (2) forward, forward, backward, backward, step: the first backward defers, the second must not
+    (its gradient goes to .grad) and step() adds the held one to it: ONE momentum update with the summed gradient.  Both
+    against torch.optim.SGD on an identical model without deferral."""
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd.optim import FusedSGD
+    layers = [(128, 11, 2, 1, 0.0), (128, 13, 1, 2, 0.0), (192, 5, 1, 1, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=15)
+    ma = build_w2l(layers, sd, 'bf16').train()
+    mb = build_w2l(layers, sd, 'bf16').train()
+    kw = dict(lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-3)
+    oa = FusedSGD.from_sgd(torch.optim.SGD(ma.parameters(), **kw))
+    oa.overlap = True
+    oa.defer_wgrad(ma, 2)
+    ob = torch.optim.SGD(mb.parameters(), **kw)
+    xa, il, tg, tl = O.synthetic_batch(2, 160, seed=21, s_lo=5, s_hi=15)
+    xb = O.synthetic_batch(2, 160, seed=22, s_lo=5, s_hi=15)[0]
+    top = [b.conv1.weight for b in list(ma.conv1ds.children())[:-1]][-2:]
+
+    def fb(m, x):
+        out, ol = m(x.cuda(), il)
+        m.criterion(out.transpose(0, 1), tg, ol, tl).backward()
+
+    def same(tol=5e-5):
+        oa.join()
+        for (name, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert scale_err(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()) < tol, name
+
+    for m, o in ((ma, oa), (mb, ob)):          # one ordinary step so that momentum buffers exist
+        o.zero_grad(set_to_none=True)
+        fb(m, xa)
+        o.step()
+    # (1) a skipped step
+    for m, o in ((ma, oa), (mb, ob)):
+        o.zero_grad(set_to_none=True)
+        fb(m, xb)                              # ... the loss is "not finite": no step
+        if m is ma:
+            assert len(ma.engine()._deferred) == 2 and all(w.grad is None for w in top)
+        o.zero_grad(set_to_none=True)
+        if m is ma:
+            assert not ma.engine()._deferred   # dropped with the other gradients
+        fb(m, xa)
+        o.step()
+    same()
+    # (2) two backward passes before one step
+    for m, o in ((ma, oa), (mb, ob)):
+        o.zero_grad(set_to_none=True)
+        o1, l1 = m(xa.cuda(), il)
+        o2, l2 = m(xb.cuda(), il)
+        m.criterion(o1.transpose(0, 1), tg, l1, tl).backward()
+        if m is ma:
+            assert len(ma.engine()._deferred) == 2 and all(w.grad is None for w in top)
+        m.criterion(o2.transpose(0, 1), tg, l2, tl).backward()
+        if m is ma:                            # the second gradient of a weight whose first is held back is computed at once
+            assert len(ma.engine()._deferred) == 2 and all(w.grad is not None for w in top)
+        o.step()
+        if m is ma:
+            assert not ma.engine()._deferred   # ... and step() added the held ones to .grad: one update
+    same(1e-4)
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_jasper_dense_golden(precision):
     """Jasper with dense (non-separable) blocks, repeat 2, residual 1x1 conv + BN, dilation 2, stride-2 first block,

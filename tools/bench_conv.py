@@ -50,6 +50,7 @@ def main():
                                                      '(index + 26 = the PIPE=1 loop of the same shape)')
     ap.add_argument('--warm-s', type=float, default=0.0, help='seconds of back-to-back launches before every timing')
     ap.add_argument('--deterministic', action='store_true', help='weight gradients through slabs + ticket (W2L_DETERMINISTIC=1 path)')
+    ap.add_argument('--no-dealt', action='store_true', help='weight gradients without a workspace: no dealt stream-K plans (round 4\'s plan space)')
     ap.add_argument('--no-splitk', action='store_true', help='with --tune: measure without the split-K configurations')
     ap.add_argument('--orders', default=None, help='with --wgrad-plans: comma-separated plan orders to time instead of all')
     ap.add_argument('--wgrad-plans', action='store_true',
@@ -105,8 +106,12 @@ def main():
                                               dy.shape[0] - (h - hb), L.ptr(wd), L.ptr(dx), 0, 0, None, None, 1, cout, cin,
                                               N * per, kw, 1, d, L.ptr(ws), ws.numel(), st))
 
-        wws = torch.zeros(min(1 << 30, int(L.lib.w2l_wgrad_workspace_bytes(cin, cout, kw))), dtype=torch.uint8, device='cuda')
-        wwsa = (L.ptr(wws), wws.numel()) if args.deterministic else (None, 0)     # the engine's default is the atomic path
+        # the engine's default: a workspace sized for the dealt stream-K plans, classic splits keep their atomics (tune flag 1);
+        # --deterministic: every split reduction through slabs; --no-dealt: round 4's plan space (no workspace)
+        need = L.lib.w2l_wgrad_workspace_bytes(cin, cout, kw) if args.deterministic else L.lib.w2l_wgrad_dealt_workspace_bytes(cin, cout, kw)
+        wws = torch.zeros(max(65536, min(1 << 30, int(need))), dtype=torch.uint8, device='cuda')
+        wwsa = (None, 0) if (args.no_dealt and not args.deterministic) or need == 0 else (L.ptr(wws), wws.numel())
+        wflags = 0 if args.deterministic else 1
 
         def wgrad():
             L.check(L.lib.w2l_conv1d_wgrad_ws(C.c_void_p(dy.data_ptr() + h * cout * 2), per * cout, L.ptr(x),
@@ -115,11 +120,19 @@ def main():
         if args.wgrad_plans:
             res = []
             # bit 0 block order, 2 two tap groups, 3 32x32x16 MFMA, 1 stream-K (6, 7: both), 4 three taps per block (AGPR accumulators)
-            for order in ([int(v) for v in args.orders.split(',')] if args.orders else (0, 1, 4, 5, 8, 9, 16, 17, 20, 21, 2, 3, 6, 7)):
+            # + 32: dealt stream-K of that form (split = the range count: 512 / 256); classic splits are timed with atomics (+ 64)
+            for order in ([int(v) for v in args.orders.split(',')] if args.orders else
+                          (0, 1, 4, 5, 8, 9, 16, 17, 20, 21, 2, 3, 6, 7, 33, 37, 41, 49, 53)):
                 best = (float('inf'), 0)
-                for sp in ((1,) if order & 2 else (1, 2, 3, 4, 5, 6, 8, 10, 12, 16)):
-                    L.lib.w2l_wgrad_force_plan(sp, order)
-                    zero = bool(L.lib.w2l_wgrad_needs_zero(N, cin, cout, Tout, kw))
+                if order & 32:
+                    sps = (256,) if order & 4 else (512, 256)
+                else:
+                    sps = (1,) if order & 2 else (1, 2, 3, 4, 5, 6, 8, 10, 12, 16)
+                for sp in sps:
+                    L.lib.w2l_wgrad_force_plan(sp, order if order & 32 or args.deterministic else order | 64)
+                    zero = bool(L.lib.w2l_wgrad_needs_zero_x(N, cin, cout, Tout, kw, s, d, wwsa[1]))
+                    if order & 32 and zero:
+                        continue                                   # no dealt form for this layer: the launch would be its fallback
 
                     def run():
                         if zero:
@@ -156,8 +169,8 @@ def main():
                 L.check(L.lib.w2l_conv1d_igemm_tune_ws(C.c_void_p(dy.data_ptr() + (h - hb) * cout * 2), dy.shape[0] * cout,
                                                        dy.shape[0] - (h - hb), L.ptr(wd), L.ptr(dx), 0, None, None, 1, cout, cin,
                                                        N * per, kw, 1, d, 3, *wsa, st))
-            L.check(L.lib.w2l_conv1d_wgrad_tune_ws(C.c_void_p(dy.data_ptr() + h * cout * 2), per * cout, L.ptr(x), rows * cin,
-                                                   N * rows, L.ptr(dw), N, cin, cout, Tout, kw, s, d, 3, *wwsa, st))
+            L.check(L.lib.w2l_conv1d_wgrad_tune_x(C.c_void_p(dy.data_ptr() + h * cout * 2), per * cout, L.ptr(x), rows * cin,
+                                                  N * rows, L.ptr(dw), N, cin, cout, Tout, kw, s, d, 3, *wwsa, wflags, st))
             dw.zero_()
         tw8 = float('nan')
         if args.fp8 and s == 1 and cin % 128 == 0 and cout % 128 == 0:
@@ -180,14 +193,21 @@ def main():
             tot['wgrad_fp8'][1] += mult[(cin, cout, kw, s, d)] * flops
         tf = timeit(fwd, args.reps)
         td = timeit(dgrad, args.reps) if s == 1 else float('nan')
-        tw = timeit(wgrad, args.reps)
+        wzero = bool(L.lib.w2l_wgrad_needs_zero_x(N, cin, cout, Tout, kw, s, d, wwsa[1]))
+
+        def wgrad_step():            # what the step pays for an atomic plan: the zero fill of dw as well
+            dw.zero_()
+            wgrad()
+        tw = timeit(wgrad, args.reps)                        # the kernel alone (comparable with earlier rounds' tables)
+        twz = timeit(wgrad_step, args.reps) if wzero else float('nan')
         m = mult[(cin, cout, kw, s, d)]
         for k, t in (('fwd', tf), ('dgrad', td), ('wgrad', tw)):
             if t == t:
                 tot[k][0] += m * t
                 tot[k][1] += m * flops
         print(f'{cin:5d} {cout:5d} {kw:3d} {s} {d} | {tf:8.3f} {flops / tf / 1e9:6.0f} | {td:8.3f} {flops / td / 1e9:6.0f} | '
-              f'{tw:8.3f} {flops / tw / 1e9:6.0f}   x{m}' + (f' | wgrad e4m3 {tw8:8.3f} {flops / tw8 / 1e9:6.0f}' if tw8 == tw8 else ''))
+              f'{tw:8.3f} {flops / tw / 1e9:6.0f}   x{m}' + (f' (atomic plan: {twz:.3f} ms with its zero fill)' if wzero else ' (stores: no fill)')
+              + (f' | wgrad e4m3 {tw8:8.3f} {flops / tw8 / 1e9:6.0f}' if tw8 == tw8 else ''))
     if args.tune_cache:
         L.check(L.lib.w2l_tune_save(args.tune_cache.encode()), 'w2l_tune_save')
     for k, (t, f) in tot.items():

@@ -79,7 +79,66 @@ constexpr int kTapGroups2 = 4;
 constexpr int kMfma32 = 8;                 // bit 3: the 32x32x16 MFMA form (stride 1; not combined with bits 1 and 2)
 constexpr int kTaps3 = 16;                 // bit 4: THREE taps per block, accumulators in AGPRs (conv_wgrad3_dev.hip; stride 1, dilation <= 4)
 constexpr int kTaps3MaxDil = 4;
+constexpr int kDealt = 32;                 // bit 5: dealt stream-K (WgradParams::dealt; the plan's split field holds the range count);
+                                           // needs the workspace -- without one the launch falls back to a classic split of 2
+constexpr int kAtomicSplit = 64;           // bit 6: a classic split adds its partial tiles atomically even when a workspace is given
+constexpr int kOrderMask = 127;
+constexpr int kDealtFallbackSplits = 2;
 constexpr int kResidentBlocks = 512;       // 256 CUs x 2 blocks (LDS and registers both allow two)
+thread_local bool g_last_dealt = false;    // did the calling thread's last launch take the dealt path? (the tuner asks)
+
+// second-segment blocks of a dealt launch, longest first (WgradParams::dealt_perm); cached per geometry: 21 launches per step
+// must not sort 512 ranges each
+struct DealtPerm { int nb; std::vector<unsigned short> perm; };
+std::map<std::tuple<int, int, int>, DealtPerm> g_dealt_perms;
+std::mutex g_dealt_mu;
+
+bool dealt_geometry_ok(int tiles, int S, int G) {
+    if (G < 1 || G > W2L_WGRAD_MAX_RANGES || tiles < 1 || tiles > G) return false;
+    const int64_t W = (int64_t)tiles * S;
+    return W >= G && W * (G + 2) < (1LL << 31);
+}
+
+// fills p.dealt_perm / p.dealt_b; false: this geometry has no dealt form
+bool dealt_fill(WgradParams& p, int tiles, int S, int G) {
+    if (!dealt_geometry_ok(tiles, S, G)) return false;
+    std::lock_guard<std::mutex> lock(g_dealt_mu);
+    auto key = std::make_tuple(tiles, S, G);
+    auto it = g_dealt_perms.find(key);
+    if (it == g_dealt_perms.end()) {
+        // Blocks are dealt round-robin to the 8 XCDs, so block G + j runs where blocks j % 8 ran: the first-segment blocks of
+        // XCD x own the consecutive ranges xcd_remap gives them, and the second segments of THOSE ranges (the next tiles
+        // along: same dy tiles and x windows in that XCD's L2) are dealt to the same XCD, longest first -- position j of the
+        // list holds the (j / 8)-th longest second segment of XCD j % 8's ranges, 0xffff where that XCD has no more.
+        std::vector<std::pair<int, int>> second[8];        // per XCD: (-steps, range)
+        const int q = G >> 3, rem = G & 7;
+        size_t longest = 0;
+        for (int x = 0; x < 8; ++x) {
+            const int base = x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q, cnt = x < rem ? q + 1 : q;
+            for (int r = base; r < base + cnt; ++r) {
+                const DealtSeg sg = dealt_segment((unsigned)tiles, (unsigned)S, (unsigned)G, (unsigned)r, true);
+                if (sg.w_end > sg.w) second[x].emplace_back(-(sg.w_end - sg.w), r);
+            }
+            std::sort(second[x].begin(), second[x].end());
+            longest = std::max(longest, second[x].size());
+        }
+        DealtPerm dp;
+        for (size_t i = 0; i < longest; ++i)
+            for (int x = 0; x < 8; ++x) dp.perm.push_back(i < second[x].size() ? (unsigned short)second[x][i].second : (unsigned short)0xffff);
+        while (!dp.perm.empty() && dp.perm.back() == 0xffff) dp.perm.pop_back();
+        dp.nb = (int)dp.perm.size();
+        if (dp.nb > W2L_WGRAD_MAX_RANGES) return false;
+        it = g_dealt_perms.emplace(key, std::move(dp)).first;
+    }
+    p.dealt = G;
+    p.dealt_b = it->second.nb;
+    std::copy(it->second.perm.begin(), it->second.perm.end(), p.dealt_perm);
+    return true;
+}
+
+size_t dealt_ws_need(int tiles, int kwblk, int G) {
+    return (size_t)64 * 1024 + (size_t)(G + tiles) * kwblk * BM * BNC * sizeof(float);
+}
 
 int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out, int* order_out = nullptr) {
     const int kwb = Kw > 1 ? KWB_DEFAULT : 1;
@@ -87,7 +146,8 @@ int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out, int
     {
         const int ts = (Tout + BT - 1) / BT;
         if (tsteps_out) *tsteps_out = ts;
-        if (g_force_splits > 0) return g_force_splits <= N * ts ? g_force_splits : N * ts;
+        if (g_force_splits > 0)        // (a dealt plan's "split count" is its range count: not bounded by the step count)
+            return (g_force_order >= 0 && (g_force_order & kDealt)) || g_force_splits <= N * ts ? g_force_splits : N * ts;
         std::lock_guard<std::mutex> lock(g_wtuned_mu);
         auto it = g_wtuned.find(WShapeKey(N, Cin, Cout, Tout, Kw));
         if (it != g_wtuned.end()) {
@@ -122,12 +182,16 @@ int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out, int
 // testing / profiling hook: pin the split count (0 = automatic) and the block order (-1 = automatic)
 extern "C" void w2l_wgrad_force_plan(int splits, int order) {
     g_force_splits = splits > 0 ? splits : 0;
-    g_force_order = order >= 0 ? (order & 31) : -1;      // bit 0: block order, 1: stream-K, 2: two tap groups per block, 3: 32x32x16 MFMA, 4: three taps (AGPR)
+    // bit 0: block order, 1: stream-K, 2: two tap groups per block, 3: 32x32x16 MFMA, 4: three taps (AGPR), 5: dealt stream-K
+    // (splits = the range count), 6: classic splits add atomically even with a workspace
+    g_force_order = order >= 0 ? (order & kOrderMask) : -1;
 }
 
 extern "C" int w2l_wgrad_needs_zero(int N, int Cin, int Cout, int Tout, int Kw) {
     int order = 0;
-    return plan_splits(N, Cin, Cout, Tout, Kw, nullptr, &order) > 1 || (order & kStreamK);
+    const int splits = plan_splits(N, Cin, Cout, Tout, Kw, nullptr, &order);
+    if ((order & kDealt) && !(order & kStreamK)) return 1;      // no workspace: the dealt plan's fallback is an atomic split
+    return splits > 1 || (order & kStreamK) ? 1 : 0;
 }
 
 constexpr size_t kWgradTicketBytes = 64 * 1024;
@@ -146,6 +210,41 @@ static size_t wgrad_ws_need(int Cin, int Cout, int Kw, int splits) {
     return kWgradTicketBytes + tiles_mn * taps * splits * BM * BNC * sizeof(float);
 }
 
+// the largest workspace a dealt plan of this layer can ask for: over the block forms (2 / 3 taps per 4-wave block on 512
+// or 256 ranges, 4 / 6 taps per 8-wave block on 256 ranges) that have one (tiles <= ranges)
+extern "C" int64_t w2l_wgrad_dealt_workspace_bytes(int Cin, int Cout, int Kw) {
+    const int tiles_mn = ((Cout + BM - 1) / BM) * ((Cin + BNC - 1) / BNC);
+    size_t need = 0;
+    const int forms[4][2] = {{2, kResidentBlocks}, {3, kResidentBlocks}, {4, kResidentBlocks / 2}, {6, kResidentBlocks / 2}};
+    for (const auto& f : forms) {
+        const int kwblk = Kw > 1 ? f[0] : 1, tiles = tiles_mn * ((Kw + kwblk - 1) / kwblk);
+        if (tiles <= f[1]) need = std::max(need, dealt_ws_need(tiles, kwblk, f[1]));
+    }
+    return (int64_t)need;
+}
+
+// test hook (host only): the blocks of a dealt launch in launch order, six ints each -- range, tile, first step, end step,
+// place among the tile's segments, number of the tile's segments; returns the block count, -1 if the geometry has no dealt form
+extern "C" int w2l_wgrad_dealt_segments(int tiles, int S, int G, int* out, int max_blocks) {
+    WgradParams p;
+    if (!dealt_fill(p, tiles, S, G)) return -1;
+    const int nblk = G + p.dealt_b;
+    for (int b = 0; b < nblk && b < max_blocks; ++b) {
+        const bool second = b >= G;
+        const int q = G >> 3, rem = G & 7, xcd = b & 7;          // xcd_remap, host side
+        const int r = second ? p.dealt_perm[b - G] : (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
+        int* o = out + 6 * b;
+        if (r == 0xffff) {                                       // a padding position of the per-XCD deal: the block exits at once
+            o[0] = -1; o[1] = o[2] = o[3] = o[4] = o[5] = 0;
+            continue;
+        }
+        const DealtSeg sg = dealt_segment((unsigned)tiles, (unsigned)S, (unsigned)G, (unsigned)r, second);
+        const int t = sg.w / S;
+        o[0] = r; o[1] = t; o[2] = sg.w - t * S; o[3] = sg.w_end - t * S; o[4] = sg.split; o[5] = sg.nsplit;
+    }
+    return nblk;
+}
+
 static bool wgrad_ws_ok(int Cin, int Cout, int Kw, int splits, const void* ws, int64_t ws_bytes) {
     if (ws == nullptr) return false;
     const int kwb = Kw > 1 ? KWB_DEFAULT : 1;          // the 2-tap form has the most tiles (tickets)
@@ -154,12 +253,64 @@ static bool wgrad_ws_ok(int Cin, int Cout, int Kw, int splits, const void* ws, i
 }
 
 // with a workspace of ws_bytes: does the launch still add into dw with atomics (i.e. need a zero-filled dw)?
+// What a launch of this problem will run as: the measured (or cost-model) plan, narrowed to what the layer's stride /
+// dilation / tap count admit and to the workspace at hand.  Shared by the launcher and by w2l_wgrad_needs_zero_*.
+struct WgradResolved {
+    int splits, order, tsteps;
+    bool streamk, tg2, m32, taps3, slabs, atomic;
+    int kwb, kwblk, kgroups, tiles;
+    int G;                       // > 0: the dealt stream-K path with G ranges
+    bool needs_zero;             // the launch ADDS into dw (atomics): the caller must hand it a zero-filled (or accumulated) dw
+};
+
+static WgradResolved wgrad_resolve(int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, bool have_ws, int64_t ws_bytes) {
+    WgradResolved r;
+    r.order = 0;
+    r.splits = plan_splits(N, Cin, Cout, Tout, Kw, &r.tsteps, &r.order);
+    const int order = r.order;
+    int G = 0;
+    if ((order & kDealt) && !(order & kStreamK)) { G = r.splits; r.splits = kDealtFallbackSplits; }
+    const int total_steps = N * r.tsteps;
+    if (r.splits > total_steps) r.splits = total_steps;
+    // (only split counts whose ranges are all non-empty: ceil(total / s) steps each leave ceil(total / that) ranges -- 32 asked of
+    // 40 steps are 20 ranges of 2; an empty range would start in the NEXT tile and draw that tile's ticket)
+    if (r.splits > 1) r.splits = (total_steps + (total_steps + r.splits - 1) / r.splits - 1) / ((total_steps + r.splits - 1) / r.splits);
+    // stream-K is the atomic path's alternative to split-K: with a workspace (deterministic slabs) the classic plan runs,
+    // unless the plan says that it adds atomically whatever it is given (bit 6)
+    r.streamk = (order & kStreamK) && (!have_ws || (order & kAtomicSplit));
+    if (r.streamk) r.splits = 1;
+    // (with stream-K: 256 persistent 8-wave blocks, one per CU -- built for stride 1 only; the plan cache is keyed without the
+    // stride, so a plan measured on a stride-1 layer may reach a strided one: that launch falls back to the 4-wave stream-K kernel)
+    r.tg2 = (order & kTapGroups2) && Kw > 2 && !(r.streamk && stride != 1);
+    r.m32 = (order & kMfma32) && !r.streamk && !r.tg2 && stride == 1;
+    // three taps per block (conv_wgrad3_dev.hip): a plan measured on a layer that admits it may reach one that does not
+    // (the plan cache is keyed without stride and dilation): such a launch takes the two-tap kernel
+    r.taps3 = (order & kTaps3) && !(order & kMfma32) && !r.streamk && stride == 1 && dil <= kTaps3MaxDil && Kw >= 3;
+    r.kwb = r.taps3 ? 3 : (Kw > 1 ? KWB_DEFAULT : 1);          // taps per wave
+    r.kwblk = r.tg2 ? 2 * r.kwb : r.kwb;                       // taps per block
+    r.kgroups = (Kw + r.kwblk - 1) / r.kwblk;
+    r.tiles = ((Cout + BM - 1) / BM) * ((Cin + BNC - 1) / BNC) * r.kgroups;
+    r.G = 0;
+    if (G > 0 && !r.streamk && have_ws && dealt_geometry_ok(r.tiles, total_steps, G) &&
+        dealt_ws_need(r.tiles, r.kwblk, G) <= (size_t)(ws_bytes > 0 ? ws_bytes : 0) && (size_t)r.tiles * sizeof(unsigned) <= 64 * 1024) {
+        r.G = G;
+        r.splits = 1;
+    }
+    r.slabs = r.G > 0 || (r.splits > 1 && have_ws && !(order & kAtomicSplit) && (size_t)r.tiles * sizeof(unsigned) <= 64 * 1024 &&
+                          wgrad_ws_need(Cin, Cout, Kw, r.splits) <= (size_t)(ws_bytes > 0 ? ws_bytes : 0));
+    r.atomic = r.splits > 1 && !r.slabs;
+    r.needs_zero = r.atomic || r.streamk;
+    return r;
+}
+
+// with a workspace of ws_bytes: does the launch still add into dw with atomics (i.e. need a zero-filled dw)?
+// (w2l_wgrad_needs_zero_ws assumes a stride-1, dilation-1 layer; w2l_wgrad_needs_zero_x is exact)
+extern "C" int w2l_wgrad_needs_zero_x(int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int64_t ws_bytes) {
+    return wgrad_resolve(N, Cin, Cout, Tout, Kw, stride, dil, ws_bytes > 0, ws_bytes).needs_zero ? 1 : 0;
+}
+
 extern "C" int w2l_wgrad_needs_zero_ws(int N, int Cin, int Cout, int Tout, int Kw, int64_t ws_bytes) {
-    int order = 0;
-    const int splits = plan_splits(N, Cin, Cout, Tout, Kw, nullptr, &order);
-    if (ws_bytes <= 0 && (order & kStreamK)) return 1;          // stream-K pieces are added atomically (no workspace form)
-    if (splits <= 1) return 0;
-    return wgrad_ws_need(Cin, Cout, Kw, splits) <= (size_t)(ws_bytes > 0 ? ws_bytes : 0) ? 0 : 1;
+    return w2l_wgrad_needs_zero_x(N, Cin, Cout, Tout, Kw, 1, 1, ws_bytes);
 }
 
 extern "C" int64_t w2l_wgrad_workspace_bytes(int Cin, int Cout, int Kw) {
@@ -185,35 +336,34 @@ extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const voi
     p.N = N; p.Cin = Cin; p.Cout = Cout; p.Tout = Tout; p.Kw = Kw; p.stride = stride; p.dil = dil;
     p.tiles_m = (Cout + BM - 1) / BM;
     p.tiles_n = (Cin + BNC - 1) / BNC;
-    int order = 0;
-    int splits = plan_splits(N, Cin, Cout, Tout, Kw, &p.tsteps, &order);
+    const WgradResolved rs = wgrad_resolve(N, Cin, Cout, Tout, Kw, stride, dil, ws != nullptr, ws_bytes);
+    const int order = rs.order, splits = rs.splits;
+    const bool tg2 = rs.tg2, m32 = rs.m32, taps3 = rs.taps3;
+    const int kwb = rs.kwb, kwblk = rs.kwblk;
+    p.tsteps = rs.tsteps;
     p.order = order & 1;
-    // stream-K is the atomic path's alternative to split-K: with a workspace (deterministic slabs) the classic plan runs
-    p.streamk = (order & kStreamK) && ws == nullptr ? 1 : 0;
-    if (p.streamk) splits = 1;
-    // (with stream-K: 256 persistent 8-wave blocks, one per CU -- built for stride 1 only; the plan cache is keyed without the
-    // stride, so a plan measured on a stride-1 layer may reach a strided one: that launch falls back to the 4-wave stream-K kernel)
-    const bool tg2 = (order & kTapGroups2) && Kw > 2 && !(p.streamk && stride != 1);
-    const bool m32 = (order & kMfma32) && !p.streamk && !tg2 && stride == 1;
-    // three taps per block (conv_wgrad3_dev.hip): a plan measured on a layer that admits it may reach one that does not
-    // (the plan cache is keyed without stride and dilation): such a launch takes the two-tap kernel
-    const bool taps3 = (order & kTaps3) && !(order & kMfma32) && !p.streamk && stride == 1 && dil <= kTaps3MaxDil && Kw >= 3;
+    p.streamk = rs.streamk ? 1 : 0;
     p.total_steps = N * p.tsteps;
     p.steps_per_split = (p.total_steps + splits - 1) / splits;
-    const bool slabs = splits > 1 && wgrad_ws_ok(Cin, Cout, Kw, splits, ws, ws_bytes);
     p.splits = splits;
     p.accumulate = accumulate;
-    p.tickets = slabs ? (unsigned*)ws : nullptr;
-    p.slabs = slabs ? (float*)((char*)ws + kWgradTicketBytes) : nullptr;
-    p.atomic = splits > 1 && !slabs;
-    const int kwb = taps3 ? 3 : (Kw > 1 ? KWB_DEFAULT : 1);    // taps per wave
-    const int kwblk = tg2 ? 2 * kwb : kwb;                 // taps per block
-    p.kgroups = (Kw + kwblk - 1) / kwblk;
+    p.tickets = rs.slabs ? (unsigned*)ws : nullptr;
+    p.slabs = rs.slabs ? (float*)((char*)ws + kWgradTicketBytes) : nullptr;
+    p.atomic = rs.atomic;
+    p.kgroups = rs.kgroups;
+    p.dealt = p.dealt_b = 0;
     const int xr = (BT - 1) * stride + (kwblk - 1) * dil + 1;
     p.xrows_lds = (xr + 3) & ~3;
     const size_t lds = 2 * BT * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
     W2L_CHECK_ARG(lds <= 160 * 1024, "conv1d_wgrad: stride %d / dilation %d need %zu bytes of LDS", stride, dil, lds);
     dim3 grid(p.tiles_m * p.tiles_n * p.kgroups, splits), block(tg2 ? 512 : 256);
+    g_last_dealt = false;
+    if (rs.G > 0) {
+        W2L_CHECK_ARG(dealt_fill(p, rs.tiles, p.total_steps, rs.G), "conv1d_wgrad: no dealt form for %d tiles x %d steps on %d ranges",
+                      rs.tiles, p.total_steps, rs.G);
+        grid = dim3((unsigned)(p.dealt + p.dealt_b), 1);
+        g_last_dealt = true;
+    }
     if (p.streamk) {
         // one block per resident slot, but at least ~16 K steps each (short ranges are all prologue and epilogue)
         const int64_t W = (int64_t)grid.x * p.total_steps;
@@ -275,9 +425,12 @@ extern "C" int w2l_conv1d_wgrad(const void* dy, int64_t dy_bstride, const void* 
 
 // Measure candidate split-K factors for this problem on the caller's device and remember the fastest
 // (SYNCHRONISING; warm-up only).  `dw_scratch` is a throw-away [Kw][Cout][Cin] fp32 buffer.
-extern "C" int w2l_conv1d_wgrad_tune_ws(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride,
-                                        int64_t x_rows_total, float* dw_scratch, int N, int Cin, int Cout, int Tout, int Kw,
-                                        int stride, int dil, int reps, void* ws, int64_t ws_bytes, void* stream) {
+// flags bit 0: classic split plans are measured (and will run) with fp32 atomics although a workspace is given -- the
+// workspace then only serves the dealt stream-K plans (the default mode of the step engine; without the bit every split
+// reduction goes through slabs: W2L_DETERMINISTIC=1)
+extern "C" int w2l_conv1d_wgrad_tune_x(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride,
+                                       int64_t x_rows_total, float* dw_scratch, int N, int Cin, int Cout, int Tout, int Kw,
+                                       int stride, int dil, int reps, void* ws, int64_t ws_bytes, int flags, void* stream) {
     const WShapeKey key(N, Cin, Cout, Tout, Kw);
     {
         std::lock_guard<std::mutex> lock(g_wtuned_mu);
@@ -297,10 +450,12 @@ extern "C" int w2l_conv1d_wgrad_tune_ws(const void* dy, int64_t dy_bstride, cons
     auto time_plan = [&](int s, int order, int n) -> float {
         g_force_splits = s;
         g_force_order = order;
-        const bool zero = (order & kStreamK) || (s > 1 && !wgrad_ws_ok(Cin, Cout, Kw, s, ws, ws_bytes));    // atomics need a zero-filled dw
+        const bool zero = wgrad_resolve(N, Cin, Cout, Tout, Kw, stride, dil, ws != nullptr, ws_bytes).needs_zero;    // atomics need a zero-filled dw
+        if (zero) (void)hipMemsetAsync(dw_scratch, 0, bytes, st);
         int rc = w2l_conv1d_wgrad_ws(dy, dy_bstride, xp, x_bstride, x_rows_total, dw_scratch, N, Cin, Cout, Tout, Kw, stride,
                                      dil, 0, ws, ws_bytes, stream);
         if (rc != 0) return -1.f;
+        if ((order & kDealt) && !g_last_dealt) return -1.f;      // this form has no dealt geometry here: the launch was its fallback
         (void)hipEventRecord(e0, st);
         for (int r = 0; r < n; ++r) {
             if (zero) (void)hipMemsetAsync(dw_scratch, 0, bytes, st);       // that fill is part of the launch's cost
@@ -330,11 +485,25 @@ extern "C" int w2l_conv1d_wgrad_tune_ws(const void* dy, int64_t dy_bstride, cons
             // and stream-K -- 256 persistent blocks, the balanced form of a kernel whose 1-block-per-CU tiles quantise badly),
             // once more with 32x32x16 MFMA fragments, and with three taps per wave (4- and 8-wave blocks)
             const bool sk = ci < 0;
-            if (sk && ws != nullptr) continue;
-            const int s = sk ? 1 : cands[ci >> 1], order = sk ? (kStreamK | (ci & 1) | tgbit) : ((ci & 1) | tgbit);
+            if (sk && ws != nullptr && !(flags & 1)) continue;
+            const int s = sk ? 1 : cands[ci >> 1];
+            int order = sk ? (kStreamK | (ci & 1) | tgbit) : ((ci & 1) | tgbit);
+            if ((sk || s > 1) && ws != nullptr && (flags & 1)) order |= kAtomicSplit;     // atomics although a workspace is there
             if (!sk && (s > total || s > 0xffff || (s > 1 && total / s < 4))) break;
             const float ms = time_plan(s, order, reps);
             if (ms >= 0.f) timed.emplace_back(ms, s | (order << 16));
+        }
+        // dealt stream-K (needs the workspace): one range per resident block slot -- 512 for the 4-wave forms (also tried:
+        // 256, one block per CU at a time), 256 for the 8-wave forms -- in both block orders
+        if (ws != nullptr) {
+            const bool waves8 = (tgbit & kTapGroups2) != 0;
+            const int ranges[2] = {waves8 ? kResidentBlocks / 2 : kResidentBlocks, waves8 ? 0 : kResidentBlocks / 2};
+            for (int gi = 0; gi < 2; ++gi)
+                for (int bo = 0; bo < 2 && ranges[gi] > 0; ++bo) {
+                    const int order = bo | tgbit | kDealt;
+                    const float ms = time_plan(ranges[gi], order, reps);
+                    if (ms >= 0.f) timed.emplace_back(ms, ranges[gi] | (order << 16));
+                }
         }
     }
     // (the first pass ranks ~100 plans on `reps` launches each while the chip's clock drifts: the three fastest are timed again,
@@ -364,6 +533,13 @@ extern "C" int w2l_conv1d_wgrad_tune_ws(const void* dy, int64_t dy_bstride, cons
     return 0;
 }
 
+extern "C" int w2l_conv1d_wgrad_tune_ws(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride,
+                                        int64_t x_rows_total, float* dw_scratch, int N, int Cin, int Cout, int Tout, int Kw,
+                                        int stride, int dil, int reps, void* ws, int64_t ws_bytes, void* stream) {
+    return w2l_conv1d_wgrad_tune_x(dy, dy_bstride, xp, x_bstride, x_rows_total, dw_scratch, N, Cin, Cout, Tout, Kw, stride, dil,
+                                   reps, ws, ws_bytes, 0, stream);
+}
+
 extern "C" int w2l_conv1d_wgrad_tune(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride,
                                      int64_t x_rows_total, float* dw_scratch, int N, int Cin, int Cout, int Tout, int Kw,
                                      int stride, int dil, int reps, void* stream) {
@@ -384,10 +560,12 @@ void w2l_wgrad_tune_dump(FILE* f) {
 }
 
 bool w2l_wgrad_tune_put(const int* v) {          // v[0..4] = key, v[5] = split count, v[6] = block order
-    if (v[5] < 1 || v[5] > 0xffff || v[0] < 1 || v[3] < 1 || v[6] < 0 || v[6] > 31 || ((v[6] & 8) && (v[6] & 6)) || ((v[6] & 16) && (v[6] & 10)))
+    if (v[5] < 1 || v[5] > 0xffff || v[0] < 1 || v[3] < 1 || v[6] < 0 || v[6] > kOrderMask || ((v[6] & 8) && (v[6] & 6)) || ((v[6] & 16) && (v[6] & 10)))
         return false;
     const int ts = (v[3] + BT - 1) / BT;
-    if ((int64_t)v[5] > (int64_t)v[0] * ts) return false;
+    if (v[6] & kDealt) {                      // the split field of a dealt plan is its range count
+        if ((v[6] & kStreamK) || v[5] > W2L_WGRAD_MAX_RANGES) return false;
+    } else if ((int64_t)v[5] > (int64_t)v[0] * ts) return false;
     std::lock_guard<std::mutex> lock(g_wtuned_mu);
     g_wtuned[WShapeKey(v[0], v[1], v[2], v[3], v[4])] = v[5] | (v[6] << 16);
     return true;

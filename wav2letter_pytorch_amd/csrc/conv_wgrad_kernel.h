@@ -23,6 +23,7 @@ constexpr int BNC = 128;      // ci per block
 constexpr int BT = 64;        // t rows per K step
 constexpr int ROWB = 256;     // bytes per LDS row (128 bf16)
 
+#define W2L_WGRAD_MAX_RANGES 1024
 constexpr int KWB_DEFAULT = W2L_DIAG_WGRAD_TAPS;   // taps per 4-wave block: 2 (common.h; a diagnostic build may probe 1)
 
 struct WgradParams {
@@ -42,7 +43,44 @@ struct WgradParams {
     int splits, accumulate;
     float* slabs;              // [tiles][splits][KWB*128*128]; NULL: fp32 atomics into a zero-filled dw
     unsigned* tickets;         // [tiles], zero between launches
+    // "dealt" stream-K (needs the workspace): the (tile, K step) space is cut into `dealt` equal ranges, one per resident
+    // block slot.  A range crosses at most one tile boundary (tiles <= dealt), i.e. it is one or two SEGMENTS, and every
+    // segment is a block of its own -- the kernel stays the one-segment classic kernel, no persistent loop and none of its
+    // live scalars.  Blocks 0 .. dealt-1 take the first segment of their range and start together; blocks dealt .. take the
+    // second segments, LONGEST FIRST (dealt_perm, sorted by the launcher per XCD: block G + j runs on the XCD of blocks j % 8
+    // and takes a second segment of THAT XCD's ranges, 0xffff = none left): the hardware hands the next block to the slot that
+    // frees first, which is the one whose first segment was shortest, so every slot ends up with about one range of work
+    // and the chip stays full whatever the tile count.  A segment that covers its tile alone stores it; every other segment
+    // writes its partial tile to slab (range + tile) and draws the tile's ticket; the last arriver sums the tile's slabs
+    // in range order (bit-reproducible, no atomics, no zero-filled dw).
+    int dealt, dealt_b;
+    unsigned short dealt_perm[W2L_WGRAD_MAX_RANGES];
 };
+
+// One segment of the dealt stream-K decomposition (WgradParams::dealt; shared by the kernel, the launcher and the host-side
+// test hook w2l_wgrad_dealt_segments): range r of G over the W = tiles * S (tile, K step) space is [W r / G, W (r + 1) / G);
+// its first segment ends at the next tile boundary, its second one (if any) starts there.  nsplit = how many segments (of
+// consecutive ranges r_lo .. r_hi) touch the segment's tile, split = this one's place among them, slab0 = r_lo + tile: the
+// segment of range r in tile t owns slab r + t (ranges and tile boundaries interleave, so r + t counts segments).
+// 32-bit arithmetic: the launcher checks W * (G + 2) < 2^31.
+struct DealtSeg { int w, w_end, nsplit, split, slab0; };
+__host__ __device__ inline DealtSeg dealt_segment(unsigned tiles, unsigned S, unsigned G, unsigned r, bool second) {
+    const unsigned W = tiles * S;
+    const unsigned w0 = W * r / G, w1 = W * (r + 1u) / G;
+    const unsigned bound = (w0 / S + 1u) * S;
+    DealtSeg o;
+    o.w = (int)(second ? bound : w0);
+    o.w_end = (int)(second ? w1 : (w1 < bound ? w1 : bound));
+    // the ranges that touch tile t: the last one that starts at or before the tile's first step .. the last one that starts
+    // before its end
+    const unsigned t = (unsigned)o.w / S;
+    const unsigned r_lo = ((t * S + 1u) * G + W - 1u) / W - 1u;
+    const unsigned r_hi = ((t + 1u) * S * G + W - 1u) / W - 1u;
+    o.nsplit = (int)(r_hi - r_lo + 1u);
+    o.split = (int)(r - r_lo);
+    o.slab0 = (int)(r_lo + t);
+    return o;
+}
 
 // 16 B per lane global -> LDS (LDS-DMA): lane l lands at lds_wave_base + 16*l.  Written as inline asm on purpose: with
 // the builtin the compiler (which cannot prove that the DMA destination and the buffer being read are different
@@ -120,17 +158,27 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, char* smem
     const int lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int S = p.total_steps;
     int w, w_end;                                  // (tiles * S < 2^31 is checked by the launcher)
-    int split = 0;
+    int split = 0, nsplit = p.splits, slab0 = 0;   // this block's place among the nsplit partial tiles of its tile; the tile's first slab
     if constexpr (SK) {
         const int64_t W = (int64_t)p.tiles_m * p.tiles_n * p.kgroups * S;
         w = (int)(W * lin / gridDim.x);
         w_end = (int)(W * (lin + 1) / gridDim.x);
     } else {
-        split = lin / gridDim.x;
-        const int tl = lin - split * gridDim.x;
-        w = tl * S + split * p.steps_per_split;
-        w_end = w + p.steps_per_split;
-        if (w_end > (tl + 1) * S) w_end = (tl + 1) * S;
+        if (p.dealt) {
+            const unsigned G = (unsigned)p.dealt, b = blockIdx.x;
+            const bool second = b >= G;
+            const unsigned r = __builtin_amdgcn_readfirstlane(second ? (unsigned)p.dealt_perm[b - G] : (unsigned)xcd_remap((int)b, (int)G));
+            if (r == 0xffffu) return;                  // a padding position of the per-XCD deal (whole block, before any barrier)
+            const DealtSeg sg = dealt_segment((unsigned)(p.tiles_m * p.tiles_n * p.kgroups), (unsigned)S, G, r, second);
+            w = sg.w; w_end = sg.w_end; nsplit = sg.nsplit; split = sg.split; slab0 = sg.slab0;
+        } else {
+            split = lin / gridDim.x;
+            const int tl = lin - split * gridDim.x;
+            w = tl * S + split * p.steps_per_split;
+            w_end = w + p.steps_per_split;
+            if (w_end > (tl + 1) * S) w_end = (tl + 1) * S;
+            slab0 = tl * p.splits;
+        }
     }
     int tile_id = 0, kw0 = 0, ntaps = KWB, m0 = 0, c0 = 0, shift = 0;
     const int s = S1 ? 1 : p.stride, d = p.dil;
@@ -559,45 +607,56 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, char* smem
     // (with p.accumulate -- dw already holds earlier passes -- every piece adds)
     const bool piece = SK && (p.accumulate || !(step_begin == 0 && step_end == S));
 
-    // ---- split-K through slabs: publish the partial tile, draw a ticket; only the last arriver goes on.  Agent-scope
-    // release before the ticket / acquire after it: correct wherever the tile's blocks ran (they are a whole grid row apart).
-    if (!SK && p.slabs != nullptr && p.splits > 1) {          // (the stream-K launch has no workspace form)
+    // ---- split-K through slabs: publish the partial tile, draw a ticket; only the last arriver goes on.  The eight XCDs' L2s
+    // are not coherent inside a launch, so the slabs never live in a cache that could be stale: every slab byte is STORED
+    // write-through (16-byte buffer stores with sc1) and LOADED with sc1 (past this CU's L1, which no plain load ever fills
+    // with slab lines), every storing wave drains its stores (vmcnt(0)) before the block barrier behind which ONE lane adds
+    // to the tile's agent-scope ticket, and the block whose add came last reads only behind another barrier.  No release
+    // fence (a buffer_wbl2 of the XCD's whole L2 per block: 2-7 us each with a freshly written 192 KB slab in it -- rounds
+    // 2-4 paid it on every partial tile) and no acquire (a buffer_inv per tile).  Correct wherever the tile's blocks ran.
+    if (!SK && p.slabs != nullptr && nsplit > 1) {            // (the stream-K launch has no workspace form)
         constexpr int TILE_F = KWBLK * BM * BNC;
         const int tid_t = tid & 255;                   // thread inside its tap group
-        float* slab = p.slabs + ((int64_t)tile_id * p.splits + split) * TILE_F;
-#pragma unroll
-        for (int tp = 0; tp < KWB; ++tp)
-#pragma unroll
-            for (int c = 0; c < 16; ++c)
-                *reinterpret_cast<f32x4*>(slab + (((tg * KWB + tp) * 16 + c) * 256 + tid_t) * 4) = chunk_get(tp, c);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                               // stores complete; the K loop's LDS is dead
-        unsigned* flag = reinterpret_cast<unsigned*>(smem);
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            *flag = __hip_atomic_fetch_add(&p.tickets[tile_id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        if (*flag != (unsigned)(p.splits - 1)) return;
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&p.tickets[tile_id], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int tp = 0; tp < KWB; ++tp)
-#pragma unroll
-            for (int c = 0; c < 16; ++c) chunk_set(tp, c, f32x4{0.f, 0.f, 0.f, 0.f});
-        const float* base = p.slabs + (int64_t)tile_id * p.splits * TILE_F;
-        for (int sp = 0; sp < p.splits; ++sp) {
-            const float* sl = base + (int64_t)sp * TILE_F;
+        // buffer descriptor over the nsplit slabs of this tile (wave-uniform inputs only)
+        const uint64_t tb = (uint64_t)(p.slabs + (int64_t)slab0 * TILE_F);
+        const unsigned tb_lo = __builtin_amdgcn_readfirstlane((unsigned)tb), tb_hi = __builtin_amdgcn_readfirstlane((unsigned)(tb >> 32));
+        const unsigned tbytes = __builtin_amdgcn_readfirstlane((unsigned)nsplit * (unsigned)(TILE_F * 4));
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)tb_hi << 32) | tb_lo), 0, tbytes, 0x00020000);
+        const unsigned voff0 = (unsigned)((tg * KWB * 16 * 256 + tid_t) * 16);     // + (tp * 16 + c) * 4096 + slab * TILE_F * 4
+        {
+            const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)split * (unsigned)(TILE_F * 4));
 #pragma unroll
             for (int tp = 0; tp < KWB; ++tp)
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
-                    chunk_set(tp, c, chunk_get(tp, c) + *reinterpret_cast<const f32x4*>(sl + (((tg * KWB + tp) * 16 + c) * 256 + tid_t) * 4));
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, chunk_get(tp, c)), rsrc,
+                                                           voff0 + (unsigned)((tp * 16 + c) * 4096), soff, 16 /* sc1 */);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave: its write-through stores have left
+        __syncthreads();                               // ... all of them; the K loop's LDS is dead
+        unsigned* flag = reinterpret_cast<unsigned*>(smem);
+        if (tid == 0) *flag = __hip_atomic_fetch_add(&p.tickets[tile_id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != (unsigned)(nsplit - 1)) return;
+        if (tid == 0) __hip_atomic_store(&p.tickets[tile_id], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (no instruction: the loads below stay below)
+#pragma unroll
+        for (int tp = 0; tp < KWB; ++tp)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) chunk_set(tp, c, f32x4{0.f, 0.f, 0.f, 0.f});
+        for (int sp = 0; sp < nsplit; ++sp) {          // in split order whoever came last: bit-reproducible
+            const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)sp * (unsigned)(TILE_F * 4));
+#pragma unroll
+            for (int tp = 0; tp < KWB; ++tp)
+#pragma unroll
+                for (int c0_ = 0; c0_ < 16; c0_ += 8) {     // eight 16-byte loads in flight per lane
+                    u32x4 t[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        t[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff0 + (unsigned)((tp * 16 + c0_ + c) * 4096), soff, 16 /* sc1 */);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) chunk_set(tp, c0_ + c, chunk_get(tp, c0_ + c) + __builtin_bit_cast(f32x4, t[c]));
+                }
         }
     }
 

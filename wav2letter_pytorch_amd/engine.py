@@ -339,6 +339,9 @@ _retired_ws = []                   # outgrown workspaces (grown only while shape
 # W2L_DETERMINISTIC=1: split weight-gradient reductions go through slabs summed in a fixed order instead of fp32 atomics
 # (bit-reproducible gradients, no zero fills) -- measured 6 % slower on the Wav2Letter table (943 vs 1004 TFLOP/s), so opt-in
 DETERMINISTIC_WGRAD = os.environ.get('W2L_DETERMINISTIC', '0') == '1'
+# W2L_DEALT_WGRAD=0: no workspace for the weight gradients in the default mode, i.e. the dealt stream-K plans (include/w2l_hip.h)
+# are neither measured nor run (round 4's plan space; the A/B switch of profiles/r05_step_ab.txt)
+DEALT_WGRAD = os.environ.get('W2L_DEALT_WGRAD', '1') == '1'
 # W2L_FUSED_BN_REDUCE: the BatchNorm-backward reduction of a layer formed in the epilogue of the data-gradient convolution
 # that produces the gradient wrt its output (w2l_conv1d_dgrad_bnreduce_ws) instead of by w2l_bn_act_bwd_reduce: one kernel
 # less per layer on the backward critical path.  '1' always, '0' never, 'auto' (default) for activations of fewer than
@@ -356,7 +359,14 @@ FOLD_BN_FINALIZE = os.environ.get('W2L_FOLD_BN_FINALIZE', '0') == '1'
 
 
 def _wgrad_workspace(dev, cin, cout, kw):
-    need = min(int(lib.w2l_wgrad_workspace_bytes(cin, cout, kw)), SPLITK_WS_CAP)
+    """the workspace of the weight-gradient stream: sized for every slab plan in deterministic mode, otherwise for the dealt
+    stream-K plans (the only ones that use it then: classic splits keep their atomics, plan order bit 6)"""
+    if DETERMINISTIC_WGRAD:
+        need = min(int(lib.w2l_wgrad_workspace_bytes(cin, cout, kw)), SPLITK_WS_CAP)
+    else:
+        need = min(int(lib.w2l_wgrad_dealt_workspace_bytes(cin, cout, kw)), SPLITK_WS_CAP)
+        if need == 0:
+            return None
     ws = _wgrad_ws.get(dev.index)
     if ws is None or ws.numel() < need:
         if ws is not None:
@@ -1320,7 +1330,7 @@ class StackEngine:
         x_bstride = src.rows * src.CP
         x_rows_total = N * src.rows - row_off
         dy_bstride = (Tout + halo) * pk.coutp          # shared-halo layout: utterance n starts at row halo + n*(Tout+halo)
-        ws = _wgrad_workspace(dev, pk.cinp, pk.coutp, kw) if DETERMINISTIC_WGRAD and f8 is None else None
+        ws = _wgrad_workspace(dev, pk.cinp, pk.coutp, kw) if f8 is None and (DETERMINISTIC_WGRAD or DEALT_WGRAD) else None
         ws_bytes = ws.numel() if ws is not None else 0
         if f8 is not None:
             if AUTOTUNE:
@@ -1341,15 +1351,16 @@ class StackEngine:
                 scratch = torch.empty(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
                 if self._side is not None:         # the workspace is shared with gradients still running on the side stream
                     torch.cuda.current_stream(dev).wait_stream(self._side)
-                check(lib.w2l_conv1d_wgrad_tune_ws(C.c_void_p(dy_hi.data_ptr() + halo * pk.coutp * 2), dy_bstride,
-                                                   C.c_void_p(src.hi.data_ptr() + row_off * src.CP * 2), x_bstride, x_rows_total,
-                                                   ptr(scratch), N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, TUNE_REPS,
-                                                   ptr(ws), ws_bytes, stream_ptr()), 'w2l_conv1d_wgrad_tune_ws')
+                check(lib.w2l_conv1d_wgrad_tune_x(C.c_void_p(dy_hi.data_ptr() + halo * pk.coutp * 2), dy_bstride,
+                                                  C.c_void_p(src.hi.data_ptr() + row_off * src.CP * 2), x_bstride, x_rows_total,
+                                                  ptr(scratch), N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, TUNE_REPS,
+                                                  ptr(ws), ws_bytes, 0 if DETERMINISTIC_WGRAD else 1, stream_ptr()),
+                      'w2l_conv1d_wgrad_tune_x')
         # with a workspace, split reductions end in plain stores by the last block of a tile: no zero fill, no atomics
         if f8 is not None:
             need_zero = bool(lib.w2l_wgrad_fp8_needs_zero(N, pk.cinp, pk.coutp, Tout, kw))
         else:
-            need_zero = bool(lib.w2l_wgrad_needs_zero_ws(N, pk.cinp, pk.coutp, Tout, kw, ws_bytes)) or self.precise
+            need_zero = bool(lib.w2l_wgrad_needs_zero_x(N, pk.cinp, pk.coutp, Tout, kw, conv.stride, conv.dilation, ws_bytes)) or self.precise
         # optim.FusedSGD leaves last step's gradient buffer zero-filled on the parameter: take it as this step's dW (only
         # when zero_grad(set_to_none=True) dropped p.grad -- otherwise autograd is about to ADD into that very tensor)
         recycled = w.__dict__.pop('_w2l_dw_zeroed', None)
