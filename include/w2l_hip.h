@@ -178,6 +178,27 @@ int w2l_conv1d_wgrad_tune_x(const void* dy, int64_t dy_bstride, const void* xp, 
 int w2l_wgrad_needs_zero_x(int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int64_t ws_bytes);
 int w2l_wgrad_dealt_segments(int tiles, int steps, int ranges, int* out, int max_blocks);
 
+/* A GROUP of layers' weight gradients in ONE launch (round 5): layers of the same N, Tout, stride 1 and dilation (any Cin,
+ * Cout, Kw) whose [128 co x 128 ci] x tap-group tiles form one pool of equal-shaped work items -- layers whose own tile
+ * count fills a fraction of the chip's block slots fill whole rounds together, with no split, no partial tiles, no atomics
+ * and no zero-filled dw (plain stores, accumulate = 0).  form = the block form (plan order bits 0: block order inside a
+ * layer, 2: two tap groups per 8-wave block, 3: 32x32x16 fragments, 4: three taps per wave with AGPR accumulators).
+ * Operand layouts per item as for w2l_conv1d_wgrad.  w2l_wgrad_group_tiles: the number of tiles a layer adds to the pool.
+ * Replaces the weight half of aten::convolution_backward for several nn.Conv1d call sites at once
+ * (wav2letter.py:35-36,42 / jasper.py:96-105,127). */
+typedef struct {
+    const void* dy;
+    int64_t dy_bstride;
+    const void* xp;
+    int64_t x_bstride;
+    int64_t x_rows_total;
+    float* dw;
+    int Cin, Cout, Kw, pad_;
+} w2l_wgrad_item_t;
+#define W2L_WGRAD_GROUP_MAX 8
+int w2l_conv1d_wgrad_group(const w2l_wgrad_item_t* items, int nitems, int N, int Tout, int dil, int form, void* stream);
+int w2l_wgrad_group_tiles(int Cin, int Cout, int Kw, int form);
+
 /* Testing / profiling hook: pin the split count (0 = automatic; a dealt plan: the range count) and the plan order (-1 =
  * automatic; bit 5 = dealt stream-K, bit 6 = atomics although a workspace is given, see above; bit 0 = block order,
  * bit 1 = stream-K decomposition, bit 2 = two tap groups per 8-wave block, bit 3 = 32x32x16 MFMA tiles, bit 4 = THREE taps
@@ -270,6 +291,38 @@ int w2l_bn_act_fwd(const w2l_bnact_t* d, void* out_hi, void* out_lo, int out_row
  * forward operand of the next nn.Conv1d in fp8 mode (BASELINE config 5).  out_q == NULL: plain w2l_bn_act_fwd. */
 int w2l_bn_act_fwd_q(const w2l_bnact_t* d, void* out_hi, void* out_lo, void* out_q, float q_scale, int out_rows,
                      int pad_l, int pad_r, int pad_mode, void* stream);
+/* w2l_bn_finalize + w2l_bn_act_fwd(_q) in ONE launch (round 5; bf16 y, C a multiple of 64): every block first sums the
+ * partial statistics rows of its own 64 channels and derives mean / invstd / scale / shift exactly as w2l_bn_finalize does;
+ * the blocks of the first row range publish them (f->mean, invstd, scale, shift: the backward pass reads them) and update
+ * the running statistics.  Meant for FEW partial rows: w2l_conv_stats_mode(S) makes the convolutions fold their per-tile
+ * statistics onto S rows.  One record per branch (f2 iff d->y2); a record with partial == NULL takes scale / shift from the
+ * descriptor (a branch without BatchNorm, or eval mode after w2l_bn_finalize).  The descriptor's own scale / shift pointers
+ * are ignored for a branch with a record.  Same output contract as w2l_bn_act_fwd_q (out_lo: none, bf16 mode only).
+ * Replaces nn.BatchNorm1d's statistics + normalisation + Dropout + clamp / ReLU (+ residual add, length mask, the next
+ * convolution's reflect padding): wav2letter.py:28-34,37-38,43-46 / jasper.py:116-119,363,376,409-410,448. */
+typedef struct {
+    const float* partial;   /* [rows][2][C]: sums, sums of squares (w2l_conv1d_igemm* statistics rows) */
+    int32_t rows;
+    int64_t count;          /* N * T: elements per channel */
+    const float* gamma;     /* NULL: 1 */
+    const float* beta;      /* NULL: 0 */
+    float eps, momentum;
+    float* running_mean;    /* NULL: not tracked */
+    float* running_var;
+    float* mean;            /* outputs, [C] each (mean / invstd may be NULL) */
+    float* invstd;
+    float* scale;
+    float* shift;
+} w2l_bnfin_t;
+int w2l_bn_act_fwd_fin(const w2l_bnact_t* d, const w2l_bnfin_t* f1, const w2l_bnfin_t* f2, void* out_hi, void* out_q,
+                       float q_scale, int out_rows, int pad_l, int pad_r, int pad_mode, void* stream);
+/* How the convolutions lay out their statistics rows, for launches made by the calling thread (thread-local, like
+ * w2l_conv_force_tile_config): 0 (default) = one row per 128-column tile, plain stores (w2l_conv_stat_tiles rows,
+ * bit-reproducible); S = 1..64: the per-tile sums are ADDED (fp32 atomics) onto row (tile mod S) of a [S][2][C] buffer the
+ * caller zero-filled -- a handful of rows that w2l_bn_act_fwd_fin / w2l_bn_act_bwd_apply_fin re-reduce per block instead of
+ * a finalize launch of their own.  Applies to w2l_conv1d_igemm*, w2l_conv1d_igemm_fp8 and w2l_conv1d_dgrad_bnreduce_ws. */
+void w2l_conv_stats_mode(int slots);
+
 /* dst[i] = e4m3(src[i] * scale), src bf16 (src_f32 = 0) or fp32, n a multiple of 8: per-tensor quantisation of the conv
  * weights (and of the spectrogram) for w2l_conv1d_igemm_fp8. */
 int w2l_quantize_e4m3(const void* src, int src_f32, int64_t n, float scale, void* dst, void* stream);
@@ -302,6 +355,16 @@ int w2l_bn_act_bwd_apply(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2
 int w2l_bn_act_bwd_apply_fin(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2, const float* partial,
                              int nblocks, float* sums, void* dy_hi, void* dy_lo, int halo, void* dy2_hi, void* dy2_lo,
                              int halo2, float* amax, void* stream);
+/* The backward chain in TWO launches (round 5; the fast path: bf16 y, bf16 gradient from one source, one branch, BatchNorm
+ * present, C a multiple of 64 -- w2l_bn_bwd_fast_ok says whether a unit qualifies): w2l_bn_act_bwd_reduce_slots ADDS the sums
+ * of g*gate and g*gate*xhat onto `slots` rows of a zero-filled partial [slots][2][C] (fp32 atomics, one 2 x 64 row segment
+ * per 128-row block), w2l_bn_act_bwd_apply_slots re-reduces those rows per block (the finalize folded in; sums [2][C] = d
+ * beta, d gamma published as by w2l_bn_bwd_finalize) and writes dy into its shared-halo buffer (halo rows zero-filled).  Both
+ * issue every load of a wave's rows before the first use.  amax as for w2l_bn_act_bwd_apply_amax (row 0 only). */
+int w2l_bn_bwd_fast_ok(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2);
+int w2l_bn_act_bwd_reduce_slots(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, float* partial, int slots, void* stream);
+int w2l_bn_act_bwd_apply_slots(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const float* partial, int nrows, float* sums,
+                               void* dy_hi, int halo, float* amax, void* stream);
 /* the same, also leaving max |dy| and max |dy2| in device memory -- the scale of the e4m3 copy of dy that the data gradient
  * reads in fp8 mode.  amax is [2][W2L_AMAX_SLOTS] floats, zeroed by the caller: slot (block index mod W2L_AMAX_SLOTS) of row
  * 0 (dy) / row 1 (dy2) takes an integer atomic max of the bit patterns; the tensor's amax is the max over a row's slots

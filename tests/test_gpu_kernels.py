@@ -349,6 +349,59 @@ def test_conv_wgrad_every_plan(L, Kw, s, d):
             L.lib.w2l_wgrad_force_plan(0, -1)
 
 
+@pytest.mark.parametrize('d', [1, 2, 4])
+def test_conv_wgrad_group_launch(L, d):
+    """w2l_conv1d_wgrad_group: the weight gradients of several layers (different Cin / Cout / Kw, same N, Tout, dilation) in ONE
+    launch whose tiles form one pool -- every block form (two taps, two tap groups, 32x32x16 fragments, three taps in AGPRs,
+    six taps) and both block orders, over NaN-filled outputs, against autograd of nn.Conv1d per layer; one- and four-layer
+    groups; a tile count per layer as w2l_wgrad_group_tiles says"""
+    from wav2letter_pytorch_amd._lib import WgradItem
+    N, T = 3, 150
+    shapes = [(192, 320, 7), (128, 128, 5), (320, 192, 9), (64, 256, 1)]
+    items, refs, outs, keep = [], [], [], []
+    for i, (Cin, Cout, Kw) in enumerate(shapes):
+        pl = pr = (Kw - 1) * d // 2
+        pr += (Kw - 1) * d - pl - pr
+        x, w, b = conv_inputs(N, Cin, Cout, Kw, T, pl, pr, 30 + i)
+        xp = to_ntc_padded(x, pl, pr, 1)
+        rows = xp.shape[1]
+        Tout = rows - (Kw - 1) * d
+        assert Tout == T
+        dy = torch.randn(N, Cout, Tout, generator=torch.Generator().manual_seed(40 + i))
+        hb = (Kw - 1) * d
+        ha = max(hb, (Tout + 63) // 64 * 64 - Tout)
+        dyp = to_ntc_padded(dy, hb, ha, 0, Cout)
+        drows = dyp.shape[1]
+        dyh, xh = dyp.to(torch.bfloat16).cuda(), xp.to(torch.bfloat16).cuda()
+        wr = bf(w).requires_grad_(True)
+        F.conv1d(F.pad(bf(x), (pl, pr), mode='reflect') if pl or pr else bf(x), wr, None, dilation=d).backward(bf(dy))
+        dw = torch.empty(Kw, Cout, Cin, device='cuda')
+        it = WgradItem(dyh.data_ptr() + hb * Cout * 2, drows * Cout, xh.data_ptr(), rows * Cin, N * rows, dw.data_ptr(), Cin, Cout, Kw, 0)
+        items.append(it)
+        refs.append(wr.grad)
+        outs.append(dw)
+        keep += [dyh, xh]
+    for form in (0, 1, 4, 5, 8, 9, 16, 17, 20, 21):
+        kwblk = (3 if form & 16 else 2) * (2 if form & 4 else 1)
+        for sel in ([0], [0, 1, 2, 3], [3, 2], [1, 0, 2]):
+            for i in sel:
+                Cin, Cout, Kw = shapes[i]
+                want = -(-Cout // 128) * -(-Cin // 128) * -(-Kw // (kwblk if Kw > 1 or form & 16 else 1))
+                assert L.lib.w2l_wgrad_group_tiles(Cin, Cout, Kw, form) == (want if Kw > 1 else -(-Cout // 128) * -(-Cin // 128))
+                outs[i].fill_(float('nan'))
+            arr = (WgradItem * len(sel))(*[items[i] for i in sel])
+            L.check(L.lib.w2l_conv1d_wgrad_group(arr, len(sel), N, T, d, form, L.stream_ptr()), 'w2l_conv1d_wgrad_group')
+            torch.cuda.synchronize()
+            for i in sel:
+                got = outs[i].cpu().permute(1, 2, 0)
+                assert torch.isfinite(got).all(), (form, sel, i)
+                assert relerr(got, refs[i]) < 2e-3, (form, sel, i, relerr(got, refs[i]))
+    # more than W2L_WGRAD_GROUP_MAX layers, or a form that is not a block form: refused with a message
+    arr = (WgradItem * 9)(*([items[0]] * 9))
+    assert L.lib.w2l_conv1d_wgrad_group(arr, 9, N, T, d, 1, L.stream_ptr()) != 0
+    assert L.lib.w2l_conv1d_wgrad_group(arr, 1, N, T, d, 2, L.stream_ptr()) != 0
+
+
 @pytest.mark.parametrize('order', [0, 4, 16, 20, 21])
 def test_conv_wgrad_workspace_holds_the_largest_split(L, order):
     """w2l_wgrad_workspace_bytes must cover the slabs of EVERY block form at the largest split count the tuner tries (32):
@@ -624,6 +677,135 @@ def test_bn_act_fwd_bwd(L, N, T, C, pl, pr, mode, act, f32):
     dyu = dy[h:].view(N, T + h, C)
     assert (dyu[:, T:] == 0).all()
     assert relerr(dyu[:, :T].transpose(1, 2), yr.grad) < 1e-4, relerr(dyu[:, :T].transpose(1, 2), yr.grad)
+
+
+@pytest.mark.parametrize('N,T,C,pl,pr,mode,act,p,lens,h', [
+    (3, 150, 128, 12, 12, 1, 1, 0.0, False, 24), (2, 333, 192, 4, 5, 1, 1, 0.3, False, 51), (2, 90, 64, 3, 3, 0, 2, 0.0, True, 38),
+    (4, 500, 896, 28, 28, 1, 1, 0.4, False, 56), (1, 40, 64, 7, 7, 1, 0, 0.2, True, 24)])
+def test_bn_bwd_two_launch_chain_equals_three(L, N, T, C, pl, pr, mode, act, p, lens, h):
+    """the backward chain's fast path (w2l_bn_act_bwd_reduce_slots + w2l_bn_act_bwd_apply_slots: sums added onto 8 slot rows,
+    the finalize folded into the dy pass) against reduce + finalize + apply: the same sums (up to the order of the fp32
+    additions), the same dy incl. the zero halo rows of its shared-halo buffer, the same amax; reflect folds, dropout masks
+    and length masks included"""
+    g = torch.Generator().manual_seed(N * 100 + T + C)
+    st = L.stream_ptr()
+    R = pl + T + pr
+    y = (torch.randn(N, T, C, generator=g) * 3 + 1).to(torch.bfloat16).cuda()
+    scale, shift, mean, invstd = ((torch.rand(C, generator=g) + 0.5).cuda() for _ in range(4))
+    mask = (torch.randint(0, 256, (N * T * (C // 8),), generator=g, dtype=torch.int32).to(torch.uint8)).cuda() if p > 0 else None
+    lens_d = torch.tensor([T - 3 * i for i in range(N)], dtype=torch.int32).cuda() if lens else None
+    gp = torch.randn(N, R, C, generator=g).to(torch.bfloat16).cuda()
+    d = _bnact_desc(L, N, T, C, y, scale, shift, mean, invstd, act, p=p, mask=mask, lens=lens_d)
+    gs = L.GradSrc()
+    gs.dxp, gs.f32, gs.pad_l, gs.pad_r, gs.pad_mode, gs.rows = gp.data_ptr(), 0, pl, pr, mode, R
+    assert L.lib.w2l_bn_bwd_fast_ok(C_.byref(d), C_.byref(gs), None) == 1
+    # three launches
+    nb = L.lib.w2l_bn_bwd_blocks(N, T, C)
+    part = torch.empty(nb, 2, C, device='cuda')
+    sums_a = torch.zeros(4, C, device='cuda')
+    dy_a = torch.full((h + N * (T + h), C), float('nan'), dtype=torch.bfloat16, device='cuda')
+    amax_a = torch.zeros(2, 64, device='cuda')
+    L.check(L.lib.w2l_bn_act_bwd_reduce(C_.byref(d), C_.byref(gs), None, L.ptr(part), st))
+    L.check(L.lib.w2l_bn_bwd_finalize(L.ptr(part), nb, C, 2, L.ptr(sums_a), st))
+    L.check(L.lib.w2l_bn_act_bwd_apply_amax(C_.byref(d), C_.byref(gs), None, L.ptr(sums_a), L.ptr(dy_a), None, h, None, None, 0,
+                                            L.ptr(amax_a), st))
+    # two launches
+    slots = torch.zeros(8, 2, C, device='cuda')
+    sums_b = torch.zeros(4, C, device='cuda')
+    dy_b = torch.full((h + N * (T + h), C), float('nan'), dtype=torch.bfloat16, device='cuda')
+    amax_b = torch.zeros(2, 64, device='cuda')
+    L.check(L.lib.w2l_bn_act_bwd_reduce_slots(C_.byref(d), C_.byref(gs), L.ptr(slots), 8, st), 'reduce_slots')
+    L.check(L.lib.w2l_bn_act_bwd_apply_slots(C_.byref(d), C_.byref(gs), L.ptr(slots), 8, L.ptr(sums_b), L.ptr(dy_b), h, L.ptr(amax_b),
+                                             st), 'apply_slots')
+    torch.cuda.synchronize()
+    assert relerr(slots.sum(0), sums_a[:2]) < 2e-5 and relerr(sums_b[:2], sums_a[:2]) < 2e-5
+    a, b = dy_a.float(), dy_b.float()
+    assert torch.isfinite(b).all()
+    assert (a - b).abs().max() <= 1.2e-2 * a.abs().max() and relerr(b, a) < 2e-3        # (a bf16 ulp where the sums' last bits differ)
+    zr = torch.ones(h + N * (T + h), dtype=torch.bool)
+    zr[h:].view(N, T + h)[:, :T] = False
+    assert not dy_b[zr.cuda()].any()
+    assert abs(float(amax_a[0].max()) - float(amax_b[0].max())) <= 1.2e-2 * float(amax_a[0].max())
+    # a unit outside the fast path says so
+    d2 = _bnact_desc(L, N, T, C, y.float(), scale, shift, mean, invstd, act)
+    assert L.lib.w2l_bn_bwd_fast_ok(C_.byref(d2), C_.byref(gs), None) == 0
+    assert L.lib.w2l_bn_bwd_fast_ok(C_.byref(d), C_.byref(gs), C_.byref(gs)) == 0
+
+
+@pytest.mark.parametrize('N,T,C,pl,pr,mode,act,p,res,lens,q', [
+    (3, 150, 128, 12, 12, 1, 1, 0.0, False, False, False), (2, 333, 192, 4, 5, 1, 1, 0.3, False, False, False),
+    (2, 90, 64, 3, 3, 0, 2, 0.0, True, True, False), (4, 500, 896, 28, 28, 1, 1, 0.4, False, False, True),
+    (2, 75, 256, 0, 0, 0, 2, 0.2, True, False, True), (1, 40, 64, 7, 7, 1, 0, 0.0, False, True, False)])
+def test_bn_act_fwd_fin_equals_finalize_plus_apply(L, N, T, C, pl, pr, mode, act, p, res, lens, q):
+    """w2l_bn_act_fwd_fin (the statistics finalize folded into the apply pass: every block re-reduces the few partial rows of
+    its 64 channels) against w2l_bn_finalize + w2l_bn_act_fwd_q on the same partial rows: bit-identical padded activation,
+    dropout mask and e4m3 copy, the same mean / invstd / scale / shift and running statistics -- with dropout, a residual
+    branch with its own BatchNorm, length masks, reflect and zero padding, 1 .. 8 partial rows"""
+    g = torch.Generator().manual_seed(N * 100 + T + C)
+    st = L.stream_ptr()
+    R = pl + T + pr
+
+    def branch(rows):
+        y = (torch.randn(N, T, C, generator=g) * 3 + 1).to(torch.bfloat16).cuda()
+        # partial rows as the convolutions leave them under w2l_conv_stats_mode(rows): the tile sums folded onto `rows` rows
+        yf = y.float().reshape(-1, C)
+        part = torch.zeros(rows, 2, C, device='cuda')
+        for r in range(rows):
+            part[r, 0] = yf[r::rows].sum(0)
+            part[r, 1] = (yf[r::rows] ** 2).sum(0)
+        gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+        return y, part, gam, bet
+
+    y1, part1, gam1, bet1 = branch(8 if C > 64 else 3)
+    b2 = branch(1 if C > 64 else 5) if res else None
+    lens_d = torch.tensor([T - 3 * i for i in range(N)], dtype=torch.int32).cuda() if lens else None
+
+    def run(folded):
+        vec = lambda: [torch.empty(C, device='cuda') for _ in range(4)]       # noqa: E731
+        s1, s2 = vec(), vec()
+        rm1, rv1 = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+        rm2, rv2 = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+        mask = torch.zeros(N * T * (C // 8), dtype=torch.uint8, device='cuda') if p > 0 else None
+        out = torch.full((N, R, C), float('nan'), dtype=torch.bfloat16, device='cuda')
+        outq = torch.full((N, R, C), 77, dtype=torch.uint8, device='cuda') if q else None
+        clipped = torch.zeros(1, dtype=torch.int64, device='cuda')
+        if not folded:
+            L.check(L.lib.w2l_bn_finalize(L.ptr(part1), part1.shape[0], C, N * T, L.ptr(gam1), L.ptr(bet1), 1e-3, 0.9, L.ptr(rm1),
+                                          L.ptr(rv1), L.ptr(s1[2]), L.ptr(s1[3]), L.ptr(s1[0]), L.ptr(s1[1]), st))
+            if res:
+                L.check(L.lib.w2l_bn_finalize(L.ptr(b2[1]), b2[1].shape[0], C, N * T, L.ptr(b2[2]), L.ptr(b2[3]), 1e-3, 0.1,
+                                              L.ptr(rm2), L.ptr(rv2), L.ptr(s2[2]), L.ptr(s2[3]), L.ptr(s2[0]), L.ptr(s2[1]), st))
+        d = _bnact_desc(L, N, T, C, y1, s1[0], s1[1], s1[2], s1[3], act, p=p, mask=mask, lens=lens_d,
+                        y2=b2[0] if res else None, bn2=s2 if res else None)
+        if q:
+            d.q_clipped = clipped.data_ptr()
+        if folded:
+            def rec(part, gam, bet, mom, rm, rv, s):
+                f = L.BnFin()
+                f.partial, f.rows, f.count = part.data_ptr(), part.shape[0], N * T
+                f.gamma, f.beta, f.eps, f.momentum = gam.data_ptr(), bet.data_ptr(), 1e-3, mom
+                f.running_mean, f.running_var = rm.data_ptr(), rv.data_ptr()
+                f.scale, f.shift, f.mean, f.invstd = (t.data_ptr() for t in s)
+                return f
+            f1 = rec(part1, gam1, bet1, 0.9, rm1, rv1, s1)
+            f2 = rec(b2[1], b2[2], b2[3], 0.1, rm2, rv2, s2) if res else None
+            d.scale = d.shift = d.scale2 = d.shift2 = None            # (ignored for a branch with a record)
+            L.check(L.lib.w2l_bn_act_fwd_fin(C_.byref(d), C_.byref(f1), C_.byref(f2) if res else None, L.ptr(out), L.ptr(outq),
+                                             4.0, R, pl, pr, mode, st), 'w2l_bn_act_fwd_fin')
+        else:
+            L.check(L.lib.w2l_bn_act_fwd_q(C_.byref(d), L.ptr(out), None, L.ptr(outq), 4.0, R, pl, pr, mode, st))
+        torch.cuda.synchronize()
+        return out, outq, mask, s1, s2, (rm1, rv1, rm2, rv2), clipped
+
+    a, b = run(False), run(True)
+    assert torch.equal(a[0].view(torch.int16), b[0].view(torch.int16))
+    assert not torch.isnan(b[0].float()).any()
+    if q:
+        assert torch.equal(a[1], b[1]) and int(a[6]) == int(b[6])
+    if p > 0:
+        assert torch.equal(a[2], b[2]) and 0.5 * (1 - p) < float((a[2] != 0).float().mean()) <= 1.0
+    for u, v in zip(a[3] + (a[4] if res else []) + list(a[5][: 4 if res else 2]), b[3] + (b[4] if res else []) + list(b[5][: 4 if res else 2])):
+        assert torch.equal(u, v)
 
 
 @pytest.mark.parametrize('N,T,S', [(2, 2500, 700), (2, 8000, 2600), (1, 8000, 4000)])

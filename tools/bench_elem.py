@@ -45,11 +45,31 @@ def main():
         h = 28
         dy = torch.empty(h + N * (T + h), Cn, dtype=torch.bfloat16, device='cuda')
         t_f = timeit(lambda: L.check(L.lib.w2l_bn_act_fwd(C.byref(d), L.ptr(out), None, R, pl, pl, 1, st)))
+        # the statistics finalize: its own launch over 125 per-tile rows (round 4) vs folded into the apply pass over 8 slot rows
+        gam, bet, rm, rv = (torch.rand(Cn, device='cuda') + 0.5 for _ in range(4))
+        part125, part8 = torch.rand(N * 4, 2, Cn, device='cuda') + 1, torch.rand(8, 2, Cn, device='cuda') + 1
+        t_fz = timeit(lambda: L.check(L.lib.w2l_bn_finalize(L.ptr(part125), N * 4, Cn, N * T, L.ptr(gam), L.ptr(bet), 1e-3, 0.9, L.ptr(rm),
+                                                            L.ptr(rv), L.ptr(mean), L.ptr(invstd), L.ptr(scale), L.ptr(shift), st)))
+        f = L.BnFin()
+        f.partial, f.rows, f.count = part8.data_ptr(), 8, N * T
+        f.gamma, f.beta, f.eps, f.momentum = gam.data_ptr(), bet.data_ptr(), 1e-3, 0.9
+        f.running_mean, f.running_var = rm.data_ptr(), rv.data_ptr()
+        f.scale, f.shift, f.mean, f.invstd = (t.data_ptr() for t in (scale, shift, mean, invstd))
+        t_ff = timeit(lambda: L.check(L.lib.w2l_bn_act_fwd_fin(C.byref(d), C.byref(f), None, L.ptr(out), None, 1.0, R, pl, pl, 1, st)))
+        for t in (scale, shift, mean, invstd):                        # (the folded launch rewrote them from random sums)
+            t.copy_(torch.rand(Cn, device='cuda') + 0.5)
         t_r = timeit(lambda: L.check(L.lib.w2l_bn_act_bwd_reduce(C.byref(d), C.byref(gs), None, L.ptr(partial), st)))
         t_z = timeit(lambda: L.check(L.lib.w2l_bn_bwd_finalize(L.ptr(partial), nb, Cn, 2, L.ptr(sums), st)))
         t_a = timeit(lambda: L.check(L.lib.w2l_bn_act_bwd_apply(C.byref(d), C.byref(gs), None, L.ptr(sums), L.ptr(dy), None, h,
                                                                 None, None, 0, st)))
+        slots = torch.zeros(8, 2, Cn, device='cuda')
+        t_r2 = timeit(lambda: L.check(L.lib.w2l_bn_act_bwd_reduce_slots(C.byref(d), C.byref(gs), L.ptr(slots), 8, st)))
+        t_a2 = timeit(lambda: L.check(L.lib.w2l_bn_act_bwd_apply_slots(C.byref(d), C.byref(gs), L.ptr(slots), 8, L.ptr(sums), L.ptr(dy), h,
+                                                                       None, st)))
         el = N * T * Cn
+        print(f'C={Cn:5d}: bwd two-launch chain: reduce {t_r2:5.1f} us ({el * 4 / t_r2 / 1e6:5.2f} TB/s) + apply {t_a2:5.1f} us '
+              f'({el * 6 / t_a2 / 1e6:5.2f} TB/s)   [three launches: {t_r:.1f} + {t_z:.1f} + {t_a:.1f}]')
+        print(f'C={Cn:5d}: fwd finalize {t_fz:5.1f} + apply {t_f:5.1f} us | folded {t_ff:5.1f} us ({el * 4 / t_ff / 1e6:5.2f} TB/s)')
         print(f'C={Cn:5d}: fwd {t_f:7.1f} us ({el * 4 / t_f / 1e6:5.2f} TB/s)  reduce {t_r:7.1f} us ({el * 4 / t_r / 1e6:5.2f} TB/s)  '
               f'finalize {t_z:6.1f} us  apply {t_a:7.1f} us ({el * 6 / t_a / 1e6:5.2f} TB/s)')
 

@@ -32,6 +32,12 @@ def main():
     def run():
         L.check(L.lib.w2l_conv1d_wgrad_ws(C.c_void_p(dy.data_ptr() + h * cout * 2), per * cout, L.ptr(x), rows * cin, N * rows,
                                           L.ptr(dw), N, cin, cout, Tout, kw, 1, d, 0, L.ptr(ws), ws.numel(), st))
+    import time
+    t0 = time.time()                 # the first second of launches in a process runs slow (clocks): keep it out of the table
+    while time.time() - t0 < 3.0:
+        for _ in range(20):
+            run()
+        torch.cuda.synchronize()
     for order in orders:
         out = []
         for G in Gs:

@@ -40,6 +40,19 @@ class BnActDesc(C.Structure):
     ]
 
 
+class WgradItem(C.Structure):
+    """w2l_wgrad_item_t (include/w2l_hip.h): one layer of a grouped weight-gradient launch."""
+    _fields_ = [('dy', c_p), ('dy_bstride', C.c_int64), ('xp', c_p), ('x_bstride', C.c_int64), ('x_rows_total', C.c_int64),
+                ('dw', c_p), ('Cin', C.c_int32), ('Cout', C.c_int32), ('Kw', C.c_int32), ('pad_', C.c_int32)]
+
+
+class BnFin(C.Structure):
+    """w2l_bnfin_t (include/w2l_hip.h): the statistics finalize of one BatchNorm branch, folded into w2l_bn_act_fwd_fin."""
+    _fields_ = [('partial', c_p), ('rows', C.c_int32), ('count', C.c_int64), ('gamma', c_p), ('beta', c_p), ('eps', c_f),
+                ('momentum', c_f), ('running_mean', c_p), ('running_var', c_p), ('mean', c_p), ('invstd', c_p), ('scale', c_p),
+                ('shift', c_p)]
+
+
 class GradSrc(C.Structure):
     """w2l_gradsrc_t (include/w2l_hip.h)."""
     _fields_ = [('dxp', c_p), ('f32', C.c_int32), ('pad_l', C.c_int32), ('pad_r', C.c_int32),
@@ -77,6 +90,8 @@ _SIGNATURES = {
     'w2l_conv1d_wgrad_tune_x': (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_i, c_p]),
     'w2l_wgrad_needs_zero_x': (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i64]),
     'w2l_wgrad_dealt_segments': (c_i, [c_i, c_i, c_i, c_p, c_i]),
+    'w2l_conv1d_wgrad_group': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'w2l_wgrad_group_tiles': (c_i, [c_i, c_i, c_i, c_i]),
     'w2l_conv1d_wgrad_tune': (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'w2l_dwconv_fwd': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'w2l_dwconv_dgrad': (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
@@ -84,6 +99,11 @@ _SIGNATURES = {
     'w2l_bn_finalize': (c_i, [c_p, c_i, c_i, c_i64, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'w2l_bn_act_fwd': (c_i, [C.POINTER(BnActDesc), c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'w2l_bn_act_fwd_q': (c_i, [C.POINTER(BnActDesc), c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_p]),
+    'w2l_bn_bwd_fast_ok': (c_i, [C.POINTER(BnActDesc), C.POINTER(GradSrc), C.POINTER(GradSrc)]),
+    'w2l_bn_act_bwd_reduce_slots': (c_i, [C.POINTER(BnActDesc), C.POINTER(GradSrc), c_p, c_i, c_p]),
+    'w2l_bn_act_bwd_apply_slots': (c_i, [C.POINTER(BnActDesc), C.POINTER(GradSrc), c_p, c_i, c_p, c_p, c_i, c_p, c_p]),
+    'w2l_bn_act_fwd_fin': (c_i, [C.POINTER(BnActDesc), C.POINTER(BnFin), C.POINTER(BnFin), c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_p]),
+    'w2l_conv_stats_mode': (None, [c_i]),
     'w2l_quantize_e4m3': (c_i, [c_p, c_i, c_i64, c_f, c_p, c_p]),
     'w2l_quantize_e4m3_dyn': (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p]),
     'w2l_bn_act_bwd_apply_amax': (c_i, [C.POINTER(BnActDesc), C.POINTER(GradSrc), C.POINTER(GradSrc), c_p, c_p, c_p, c_i,
@@ -184,7 +204,8 @@ TRACE_NAMES = {
     'w2l_conv1d_dgrad_bnreduce_ws': 'conv_igemm_kernel/dgrad+bnreduce', 'w2l_conv1d_igemm_fp8': 'conv_igemm_fp8_kernel',
     'w2l_conv1d_wgrad': 'conv_wgrad_kernel', 'w2l_conv1d_wgrad_ws': 'conv_wgrad_kernel', 'w2l_conv1d_wgrad_fp8': 'conv_wgrad_fp8_kernel',
     'w2l_bn_finalize': 'bn_finalize_kernel', 'w2l_bn_act_fwd': 'bn_act_fwd_kernel', 'w2l_bn_act_fwd_q': 'bn_act_fwd_kernel',
-    'w2l_bn_act_bwd_reduce': 'bn_act_bwd_reduce_kernel', 'w2l_bn_bwd_finalize': 'bn_bwd_finalize_kernel',
+    'w2l_bn_act_fwd_fin': 'bn_act_fwd_kernel', 'w2l_bn_act_bwd_reduce': 'bn_act_bwd_reduce_kernel',
+    'w2l_bn_act_bwd_reduce_slots': 'bn_act_bwd_reduce_kernel', 'w2l_bn_act_bwd_apply_slots': 'bn_act_bwd_apply_kernel', 'w2l_bn_bwd_finalize': 'bn_bwd_finalize_kernel',
     'w2l_bn_act_bwd_apply': 'bn_act_bwd_apply_kernel', 'w2l_bn_act_bwd_apply_amax': 'bn_act_bwd_apply_kernel',
     'w2l_bn_act_bwd_apply_fin': 'bn_act_bwd_apply_kernel', 'w2l_sgd_pack': 'sgd_pack_kernel', 'w2l_pack_weights': 'pack_weights_kernel',
     'w2l_ctc_loss': 'ctc_kernels', 'w2l_log_softmax_fwd': 'log_softmax_fwd', 'w2l_log_softmax_bwd': 'log_softmax_bwd',

@@ -139,6 +139,7 @@ __device__ __forceinline__ bool act_pass(float z, int act) {
 // device-side amax of dy (fp8 mode): W2L_AMAX_SLOTS partial maxima per tensor, the slot picked by the block index -- one
 // word for a whole launch serialises 16 000 atomics at one L2 address (measured: the dy kernel 33 -> 171 us)
 constexpr int AMAX_SLOTS = W2L_AMAX_SLOTS;
+constexpr int BWD_SLAB = 64;             // channels per wave of the slab-form kernels (one 128-byte line per row)
 
 // 8 floats -> 8 OCP e4m3 bytes (round to nearest even, saturating at +-448), v * scale
 __device__ __forceinline__ uint2 quant8_e4m3(const float v[8], float scale) {
@@ -200,6 +201,175 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(w2l_bnact_t d, bf16_raw
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) clipped += __shfl_xor(clipped, m, 64);
         if ((threadIdx.x & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long*>(d.q_clipped), (unsigned long long)clipped);
+    }
+}
+
+// ---- forward with the statistics finalize folded in ("slab" form; round 5).  The separate bn_finalize launch is a 5 us kernel
+// that costs its layer 17-20 us (two more stream boundaries on the critical path).  Here a block owns a
+// 64-channel slab (one 128-byte line per row) of a range of OUTPUT rows; its prologue sums the few partial rows of ITS 64
+// channels (w2l_conv_stats_mode(S): the convolution's epilogue folds its per-tile sums onto S <= 64 rows with fp32 atomics --
+// 2 x S x 64 floats per block instead of 2 x 125 x C), derives mean / invstd / scale / shift exactly as bn_finalize_kernel
+// does, and the blocks of row chunk 0 publish them (the backward pass reads them) and update the running statistics.  Then
+// each wave walks its rows eight at a time, FOUR row groups per iteration with all their loads issued before the first use
+// (one load in flight per lane is what held the flat kernel at 3.4 TB/s).  bf16 y only (the fp32 parity mode keeps the
+// deterministic two-kernel path).
+struct FinBranch {
+    const float* partial;      // [rows][2][C] sums / sums of squares; NULL: take scale / shift from the descriptor
+    int rows;
+    double count;
+    const float* gamma;
+    const float* beta;
+    float eps, momentum;
+    float* running_mean;
+    float* running_var;
+    float* mean;
+    float* invstd;
+    float* scale;
+    float* shift;
+};
+
+constexpr int FWD_FIN_U = 4;                           // row groups (of 8 rows) per wave of bn_act_fwd_fin_kernel
+__host__ __device__ inline int fwd_rows_per_block(int64_t rows, int C) {
+    (void)rows; (void)C;
+    return 4 * FWD_FIN_U * 8;                          // 4 waves x U groups x 8 rows: one batch of loads per wave
+}
+
+template <bool HAS2>
+__global__ __launch_bounds__(256) void bn_act_fwd_fin_kernel(w2l_bnact_t d, FinBranch f1, FinBranch f2, bf16_raw* out_hi, int R,
+                                                              int pad_l, int pad_r, int pad_mode, uint32_t thresh, float inv_keep,
+                                                              uint8_t* out_q, float q_scale, int rpb) {
+    __shared__ double red[2][2][BWD_SLAB];
+    __shared__ float s_sc[2][BWD_SLAB], s_sh[2][BWD_SLAB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = d.C >> 3;
+    const int nslabs = d.C / BWD_SLAB;
+    const int slab = blockIdx.x % nslabs, chunk = blockIdx.x / nslabs;
+    const int cgl = lane & 7, rr = lane >> 3;
+    const int cg = slab * (BWD_SLAB / 8) + cgl, c = cg * 8;
+    const int T = d.T;
+    const int64_t rows = (int64_t)d.N * R;
+    constexpr int U = FWD_FIN_U;                       // row groups per wave: rpb = 4 waves x U x 8 rows, ONE batch per wave
+    const int64_t q0 = (int64_t)chunk * rpb + (int64_t)wave * (U * 8) + rr;
+    // ---- every load of the block's rows is issued FIRST: they do not depend on the statistics, and the prologue's own
+    // round trip (the partial rows, two barriers) hides behind them
+    u16x8 ya[U], yb[U];
+    int nn[U], tt[U], rw[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t q = q0 + 8 * u;
+        ok[u] = false;
+        nn[u] = 0; tt[u] = 0; rw[u] = 0;
+        if (q < rows) {
+            const int n = (int)(q / R), r = (int)(q - (int64_t)n * R);
+            const int t = pad_src_row(r, T, pad_l, pad_r, pad_mode);
+            nn[u] = n; tt[u] = t; rw[u] = r;
+            ok[u] = t >= 0 && (!d.lens || t < d.lens[n]);
+            if (ok[u]) {
+                const int64_t src = ((int64_t)n * T + t) * d.C + c;
+                ya[u] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16_raw*>(d.y) + src);
+                if (HAS2) yb[u] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16_raw*>(d.y2) + src);
+            }
+        }
+    }
+    // ---- prologue: this slab's statistics
+    {
+        const int cc = tid & 63, ch = slab * BWD_SLAB + cc;
+        const int br = tid >> 7, k = (tid >> 6) & 1;              // branch, component (sum / sum of squares)
+        const FinBranch& f = br ? f2 : f1;
+        if ((br == 0 || HAS2) && f.partial) {
+            double a = 0.0;
+            int j = 0;
+            for (; j + 8 <= f.rows; j += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = f.partial[((int64_t)(j + u) * 2 + k) * d.C + ch];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += v[u];
+            }
+            for (; j < f.rows; ++j) a += f.partial[((int64_t)j * 2 + k) * d.C + ch];
+            red[br][k][cc] = a;
+        }
+        __syncthreads();
+        if (tid < 128 && (tid < 64 || HAS2)) {
+            const int b = tid >> 6;
+            const FinBranch& g = b ? f2 : f1;
+            float sc = 1.f, sh = 0.f;
+            if (g.partial) {
+                const double mu = red[b][0][cc] / g.count;
+                double var = red[b][1][cc] / g.count - mu * mu;   // biased: normalisation uses it
+                if (var < 0.0) var = 0.0;
+                const float m = (float)mu, istd = (float)(1.0 / sqrt(var + (double)g.eps));
+                const float ga = g.gamma ? g.gamma[ch] : 1.f, be = g.beta ? g.beta[ch] : 0.f;
+                sc = ga * istd;
+                sh = be - m * ga * istd;
+                if (chunk == 0) {
+                    if (g.running_mean) {
+                        const double unbiased = g.count > 1.0 ? var * g.count / (g.count - 1.0) : var;
+                        g.running_mean[ch] = (1.f - g.momentum) * g.running_mean[ch] + g.momentum * m;
+                        g.running_var[ch] = (1.f - g.momentum) * g.running_var[ch] + g.momentum * (float)unbiased;
+                    }
+                    if (g.mean) { g.mean[ch] = m; g.invstd[ch] = istd; }
+                    g.scale[ch] = sc;
+                    g.shift[ch] = sh;
+                }
+            } else {
+                const float* scp = b ? d.scale2 : d.scale;
+                const float* shp = b ? d.shift2 : d.shift;
+                if (scp) { sc = scp[ch]; sh = shp[ch]; }
+            }
+            s_sc[b][cc] = sc;
+            s_sh[b][cc] = sh;
+        }
+        __syncthreads();
+    }
+    float sc1[8], sh1[8], sc2[8], sh2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc1[j] = s_sc[0][cgl * 8 + j]; sh1[j] = s_sh[0][cgl * 8 + j];
+        sc2[j] = HAS2 ? s_sc[1][cgl * 8 + j] : 0.f; sh2[j] = HAS2 ? s_sh[1][cgl * 8 + j] : 0.f;
+    }
+    unsigned clipped = 0;
+    const float q_limit = 448.f / q_scale;
+    const bool drop = d.drop_p > 0.f;
+    const uint64_t off = drop ? d.offset + (d.offset_dev ? *d.offset_dev : 0ull) : 0ull;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t q = q0 + 8 * u;
+        if (q >= rows) break;
+        float a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = 0.f;
+        if (ok[u]) {
+            float z[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                z[j] = bf16_bits_to_f32(ya[u][j]) * sc1[j] + sh1[j];
+                if (HAS2) z[j] += bf16_bits_to_f32(yb[u][j]) * sc2[j] + sh2[j];
+            }
+            if (drop) {                            // every row (halo copies too) regenerates its bits; the primary row records them
+                const int64_t gidx = ((int64_t)nn[u] * T + tt[u]) * G + cg;
+                const uint32_t bits = dropout_bits(d.seed, off, (uint64_t)gidx, thresh);
+                if (rw[u] - pad_l == tt[u]) d.mask[gidx] = (uint8_t)bits;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[j] = (bits >> j) & 1u ? z[j] * inv_keep : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = activate(z[j], d.act);
+        }
+        store8_split(out_hi, nullptr, q * d.C + c, a);
+        if (out_q) {
+            *reinterpret_cast<uint2*>(out_q + q * d.C + c) = quant8_e4m3(a, q_scale);
+            if (d.q_clipped && rw[u] - pad_l == tt[u]) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) clipped += fabsf(a[j]) > q_limit ? 1u : 0u;
+            }
+        }
+    }
+    if (out_q && d.q_clipped && __any(clipped != 0)) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) clipped += __shfl_xor(clipped, m, 64);
+        if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(d.q_clipped), (unsigned long long)clipped);
     }
 }
 
@@ -275,7 +445,6 @@ __device__ __forceinline__ void bwd_row(const w2l_bnact_t& d, const Chan& c1, co
 // no block barrier: the kernel's occupancy is bounded by registers only, so its blocks fit next to whatever else is
 // resident (the LDS version -- 24 KB per block -- ran at one block per CU beside the weight-gradient kernel, which takes
 // 132 of a CU's 160 KB).  The four waves of a block take four adjacent slabs of the same rows.  Deterministic.
-constexpr int BWD_SLAB = 64;             // channels per wave
 __host__ __device__ inline int bwd_rows_per_wave(int64_t rows, int C) {
     // ~4096 wave tasks per launch: 16 rows for the narrow layers, up to 64 for the wide ones
     // (rounded UP to whole 8-row steps: rounding down left 4 600-6 000 tasks, i.e. a second, mostly empty round of waves behind
@@ -609,6 +778,191 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_fin_kernel(w2l_bnact_t d
     }
 }
 
+// ---- the backward chain's fast path (round 5): bf16 y, bf16 gradient from ONE source, one branch -- every Wav2Letter unit and
+// every Jasper unit that is not a block end.  Two launches instead of three, both in the slab form (a wave = 64 channels x 8
+// row lanes, one 128-byte line per row) with EVERY load of a wave's rows issued before the first use:
+//   bn_bwd_reduce_fast_kernel: sums of g*gate and g*gate*xhat; the four waves of a block (four consecutive 32-row chunks of
+//     one slab) combine in LDS and ADD their 2 x 64 sums onto row (chunk mod S) of a zero-filled [S][2][C] buffer (fp32
+//     atomics: ~16 adds per address over the launch);
+//   bn_bwd_apply_fast_kernel: every block re-reduces the S rows of its 64 channels (the finalize folded in; the blocks of
+//     row chunk 0 publish d beta / d gamma), then forms dy.
+// The separate finalize launch -- a 5 us kernel between two stream boundaries on the backward critical path -- is gone.
+constexpr int BWD_FAST_U = 4;                          // row groups (of 8 rows) per wave
+
+struct FastRow {
+    u16x8 y, g, ga, gb;                                // conv output, gradient of the frame, of its reflected images (left / right halo)
+    unsigned bits;                                     // dropout keep bits
+    bool live, fa, fb, masked;
+    int n, t;
+};
+
+__device__ __forceinline__ void fast_row_load(const w2l_bnact_t& d, const w2l_gradsrc_t& s, int64_t row, int64_t rows, int c,
+                                              int cg, int G, FastRow& o) {
+    o.live = row < rows;
+    o.fa = o.fb = o.masked = false;
+    o.bits = 0xFFu;
+    o.n = 0; o.t = 0;
+    if (!o.live) return;
+    const int T = d.T;
+    const int n = (int)(row / T), t = (int)(row - (int64_t)n * T);
+    o.n = n; o.t = t;
+    o.y = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16_raw*>(d.y) + row * d.C + c);
+    if (d.drop_p > 0.f) o.bits = d.mask[row * G + cg];
+    o.masked = d.lens && t >= d.lens[n];
+    const bf16_raw* gp = reinterpret_cast<const bf16_raw*>(s.dxp);
+    const int64_t base = (int64_t)n * s.rows;
+    o.g = *reinterpret_cast<const u16x8*>(gp + (base + t + s.pad_l) * d.C + c);
+    if (s.pad_mode == 1) {                             // the reflected halo rows' gradient folds back onto its source frame
+        o.fa = t >= 1 && t <= s.pad_l;
+        o.fb = t <= T - 2 && t >= T - 1 - s.pad_r;
+        if (o.fa) o.ga = *reinterpret_cast<const u16x8*>(gp + (base + s.pad_l - t) * d.C + c);
+        if (o.fb) o.gb = *reinterpret_cast<const u16x8*>(gp + (base + s.pad_l + 2 * (T - 1) - t) * d.C + c);
+    }
+}
+
+// gated gradient and normalised input of one row's 8 channels
+__device__ __forceinline__ void fast_row_eval(const w2l_bnact_t& d, const FastRow& r, const Chan& ch, float inv_keep, float g[8],
+                                              float xh[8]) {
+    const float gk = d.drop_p > 0.f ? inv_keep : 1.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float y = bf16_bits_to_f32(r.y[j]);
+        float z = y * ch.sc[j] + ch.sh[j];
+        const bool keep = (r.bits >> j) & 1u;
+        if (d.drop_p > 0.f) z = keep ? z * inv_keep : 0.f;
+        float gv = bf16_bits_to_f32(r.g[j]);
+        if (r.fa) gv += bf16_bits_to_f32(r.ga[j]);
+        if (r.fb) gv += bf16_bits_to_f32(r.gb[j]);
+        g[j] = (!r.masked && keep && act_pass(z, d.act)) ? gv * gk : 0.f;
+        xh[j] = (y - ch.m[j]) * ch.is[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(w2l_bnact_t d, w2l_gradsrc_t g1, float* partial, float inv_keep,
+                                                                  int slots) {
+    __shared__ float red[4][2][BWD_SLAB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = d.C >> 3, nslabs = d.C / BWD_SLAB;
+    const int slab = blockIdx.x % nslabs, chunk = blockIdx.x / nslabs;
+    const int cgl = lane & 7, rr = lane >> 3;
+    const int cg = slab * (BWD_SLAB / 8) + cgl, c = cg * 8;
+    const int64_t rows = (int64_t)d.N * d.T;
+    constexpr int U = BWD_FAST_U;
+    const int64_t q0 = ((int64_t)chunk * 4 + wave) * (U * 8) + rr;
+    FastRow r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) fast_row_load(d, g1, q0 + 8 * u, rows, c, cg, G, r[u]);
+    Chan ch;
+    load_chan(ch, d.scale, d.shift, d.mean, d.invstd, c);
+    float s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!r[u].live) continue;
+        float g[8], xh[8];
+        fast_row_eval(d, r[u], ch, inv_keep, g, xh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s0[j] += g[j]; s1[j] += g[j] * xh[j]; }
+    }
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s0[j] += __shfl_xor(s0[j], m, 64);
+            s1[j] += __shfl_xor(s1[j], m, 64);
+        }
+    if (rr == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[wave][0][cgl * 8 + j] = s0[j]; red[wave][1][cgl * 8 + j] = s1[j]; }
+    }
+    __syncthreads();
+    if (tid < 2 * BWD_SLAB) {
+        const int k = tid >> 6, cc = tid & 63;
+        const float t4 = (red[0][k][cc] + red[1][k][cc]) + (red[2][k][cc] + red[3][k][cc]);
+        atomicAdd(partial + ((int64_t)(chunk % slots) * 2 + k) * d.C + slab * BWD_SLAB + cc, t4);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(w2l_bnact_t d, w2l_gradsrc_t g1, const float* partial, int nb,
+                                                                 float* sums_out, bf16_raw* dy_hi, int h1, float inv_keep,
+                                                                 float* amax) {
+    __shared__ float ssum[2][BWD_SLAB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = d.C >> 3, nslabs = d.C / BWD_SLAB;
+    const int slab = blockIdx.x % nslabs, chunk = blockIdx.x / nslabs;
+    const int cgl = lane & 7, rr = lane >> 3;
+    const int cg = slab * (BWD_SLAB / 8) + cgl, c = cg * 8;
+    const int T = d.T, N = d.N;
+    const int64_t rows = (int64_t)N * T;
+    constexpr int U = BWD_FAST_U;
+    const int64_t q0 = ((int64_t)chunk * 4 + wave) * (U * 8) + rr;
+    FastRow r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) fast_row_load(d, g1, q0 + 8 * u, rows, c, cg, G, r[u]);     // before the prologue's round trip
+    if (tid < 2 * BWD_SLAB) {                          // column sums of partial[nb][2][C] over this slab's channels, fixed order
+        const int k = tid >> 6, cc = tid & 63;
+        float a = 0.f;
+        int j = 0;
+        for (; j + 8 <= nb; j += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[((int64_t)(j + u) * 2 + k) * d.C + slab * BWD_SLAB + cc];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; j < nb; ++j) a += partial[((int64_t)j * 2 + k) * d.C + slab * BWD_SLAB + cc];
+        ssum[k][cc] = a;
+        if (chunk == 0) sums_out[(int64_t)k * d.C + slab * BWD_SLAB + cc] = a;
+    }
+    __syncthreads();
+    Chan ch;
+    load_chan(ch, d.scale, d.shift, d.mean, d.invstd, c);
+    float sg[8], sgx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sg[j] = ssum[0][cgl * 8 + j]; sgx[j] = ssum[1][cgl * 8 + j]; }
+    const float invM = 1.f / ((float)N * (float)T);
+    float mx = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!r[u].live) continue;
+        float g[8], xh[8], o[8];
+        fast_row_eval(d, r[u], ch, inv_keep, g, xh);
+        if (d.mean) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = ch.sc[j] * (g[j] - sg[j] * invM - xh[j] * sgx[j] * invM);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = g[j] * ch.sc[j];
+        }
+        store8_split(dy_hi, nullptr, ((int64_t)h1 + (int64_t)r[u].n * (T + h1) + r[u].t) * d.C + c, o);
+        if (amax) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(o[j]));
+        }
+    }
+    // ---- halo rows of the shared-halo layout: (N+1) gaps of h1 rows each, this block's share (its slab's 128 bytes per row)
+    if (h1 > 0) {
+        const int nchunks = gridDim.x / nslabs;
+        float z[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = 0.f;
+        const int total = h1 * (N + 1);
+        const int per = (total + nchunks - 1) / nchunks;
+        int e = (chunk + 1) * per;
+        if (e > total) e = total;
+        for (int hr = chunk * per + wave * 8 + rr; hr < e; hr += 32) {
+            const int gap = hr / h1, rw = hr - gap * h1;
+            store8_split(dy_hi, nullptr, ((int64_t)gap * (T + h1) + rw) * d.C + c, z);
+        }
+    }
+    if (amax) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(amax) + (blockIdx.x & (AMAX_SLOTS - 1)), __float_as_uint(mx));
+    }
+}
+
 // e4m3 quantisation with the scale taken from a device-resident amax (no host round trip): scale = the power of two that
 // puts amax at <= 224 (one binade of head-room below e4m3's 448); inv_scale[0] = 1 / scale for the consumer's epilogue
 __global__ __launch_bounds__(256) void quantize_e4m3_dyn_kernel(const bf16_raw* src, int64_t ngroups, const float* amax,
@@ -749,6 +1103,44 @@ extern "C" int w2l_bn_act_fwd_q(const w2l_bnact_t* d, void* out_hi, void* out_lo
     return 0;
 }
 
+extern "C" int w2l_bn_act_fwd_fin(const w2l_bnact_t* d, const w2l_bnfin_t* f1, const w2l_bnfin_t* f2, void* out_hi, void* out_q,
+                                  float q_scale, int out_rows, int pad_l, int pad_r, int pad_mode, void* stream) {
+    if (int e = check_desc(d, "bn_act_fwd_fin")) return e;
+    W2L_CHECK_ARG(!d->y_f32, "bn_act_fwd_fin: bf16 y only (the fp32 mode takes w2l_bn_finalize + w2l_bn_act_fwd)");
+    W2L_CHECK_ARG(d->C % BWD_SLAB == 0, "bn_act_fwd_fin: C=%d must be a multiple of %d", d->C, BWD_SLAB);
+    W2L_CHECK_ARG(f1 && (f2 != nullptr) == (d->y2 != nullptr), "bn_act_fwd_fin: one finalize record per branch");
+    W2L_CHECK_ARG(!out_q || q_scale > 0.f, "bn_act_fwd_fin: the e4m3 copy needs a positive scale");
+    W2L_CHECK_ARG(out_hi && out_rows >= pad_l + d->T + pad_r && pad_l >= 0 && pad_r >= 0, "bn_act_fwd_fin: bad output geometry");
+    W2L_CHECK_ARG(pad_mode != 1 || (pad_l < d->T && pad_r < d->T), "bn_act_fwd_fin: reflect pad (%d,%d) needs pad < T=%d", pad_l,
+                  pad_r, d->T);
+    FinBranch b[2];
+    const w2l_bnfin_t* fs[2] = {f1, f2};
+    for (int i = 0; i < 2; ++i) {
+        FinBranch& o = b[i];
+        const w2l_bnfin_t* f = fs[i];
+        o = FinBranch{nullptr, 0, 1.0, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (!f) continue;
+        W2L_CHECK_ARG(!f->partial || (f->rows > 0 && f->count > 0 && f->scale && f->shift), "bn_act_fwd_fin: bad finalize record");
+        o = FinBranch{f->partial, f->rows, (double)f->count, f->gamma, f->beta, f->eps, f->momentum, f->running_mean, f->running_var,
+                      f->mean, f->invstd, f->scale, f->shift};
+    }
+    const uint32_t thresh = (uint32_t)(d->drop_p * 65536.f);
+    const float inv_keep = 1.f / (1.f - d->drop_p);
+    const int64_t rows = (int64_t)d->N * out_rows;
+    W2L_CHECK_ARG(rows * (d->C / 8) < (1LL << 31), "bn_act_fwd_fin: tensor too large for 32-bit indexing");
+    const int rpb = fwd_rows_per_block(rows, d->C);
+    const int nchunks = (int)((rows + rpb - 1) / rpb);
+    const dim3 grid((unsigned)(nchunks * (d->C / BWD_SLAB)));
+    if (d->y2)
+        hipLaunchKernelGGL((bn_act_fwd_fin_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, *d, b[0], b[1], (bf16_raw*)out_hi,
+                           out_rows, pad_l, pad_r, pad_mode, thresh, inv_keep, (uint8_t*)out_q, q_scale, rpb);
+    else
+        hipLaunchKernelGGL((bn_act_fwd_fin_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, *d, b[0], b[1], (bf16_raw*)out_hi,
+                           out_rows, pad_l, pad_r, pad_mode, thresh, inv_keep, (uint8_t*)out_q, q_scale, rpb);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int w2l_bn_bwd_blocks(int N, int T, int C) {
     if (N <= 0 || T <= 0 || C < BWD_SLAB) return 0;
     const int64_t rows = (int64_t)N * T;
@@ -785,6 +1177,45 @@ extern "C" int w2l_bn_act_bwd_reduce(const w2l_bnact_t* d, const w2l_gradsrc_t* 
     w2l_gradsrc_t g2v = g2 ? *g2 : *g1;
     W2L_DISPATCH_BWD(bn_act_bwd_reduce_kernel, dim3((tasks + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d, *g1, g2v,
                      g2 ? 1 : 0, partial, inv_keep, rw, nchunks);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}
+
+// the fast path's preconditions (bn_bwd_reduce_fast_kernel / bn_bwd_apply_fast_kernel)
+static bool bwd_fast_ok(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2) {
+    return !d->y_f32 && !d->y2 && g1 && !g1->f32 && g2 == nullptr && d->C % BWD_SLAB == 0 && d->scale != nullptr;
+}
+
+extern "C" int w2l_bn_bwd_fast_ok(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2) {
+    return d && bwd_fast_ok(d, g1, g2) ? 1 : 0;
+}
+
+extern "C" int w2l_bn_act_bwd_reduce_slots(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, float* partial, int slots, void* stream) {
+    if (int e = check_desc(d, "bn_act_bwd_reduce_slots")) return e;
+    W2L_CHECK_ARG(g1 && g1->dxp && partial && slots >= 1 && slots <= 64, "bn_act_bwd_reduce_slots: null pointer / slots not in 1..64");
+    W2L_CHECK_ARG(bwd_fast_ok(d, g1, nullptr), "bn_act_bwd_reduce_slots: bf16 y and gradient, one branch, one source, C %% 64 == 0 only");
+    W2L_CHECK_ARG(g1->rows >= g1->pad_l + d->T + g1->pad_r, "bn_act_bwd_reduce_slots: gradient source has too few rows per utterance");
+    const int64_t rows = (int64_t)d->N * d->T;
+    const int nchunks = (int)((rows + 4 * BWD_FAST_U * 8 - 1) / (4 * BWD_FAST_U * 8));
+    const float inv_keep = 1.f / (1.f - d->drop_p);
+    hipLaunchKernelGGL(bn_bwd_reduce_fast_kernel, dim3((unsigned)(nchunks * (d->C / BWD_SLAB))), dim3(256), 0, (hipStream_t)stream, *d,
+                       *g1, partial, inv_keep, slots);
+    W2L_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int w2l_bn_act_bwd_apply_slots(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const float* partial, int nrows, float* sums,
+                                          void* dy_hi, int halo, float* amax, void* stream) {
+    if (int e = check_desc(d, "bn_act_bwd_apply_slots")) return e;
+    W2L_CHECK_ARG(g1 && g1->dxp && dy_hi && partial && sums && nrows > 0 && halo >= 0, "bn_act_bwd_apply_slots: null pointer / no partial rows");
+    W2L_CHECK_ARG(bwd_fast_ok(d, g1, nullptr), "bn_act_bwd_apply_slots: bf16 y and gradient, one branch, one source, C %% 64 == 0 only");
+    W2L_CHECK_ARG(g1->rows >= g1->pad_l + d->T + g1->pad_r, "bn_act_bwd_apply_slots: gradient source has too few rows per utterance");
+    const int64_t rows = (int64_t)d->N * d->T;
+    W2L_CHECK_ARG((rows + (int64_t)halo * (d->N + 1)) * (d->C / 8) < (1LL << 31), "bn_act_bwd_apply_slots: tensor too large for 32-bit indexing");
+    const int nchunks = (int)((rows + 4 * BWD_FAST_U * 8 - 1) / (4 * BWD_FAST_U * 8));
+    const float inv_keep = 1.f / (1.f - d->drop_p);
+    hipLaunchKernelGGL(bn_bwd_apply_fast_kernel, dim3((unsigned)(nchunks * (d->C / BWD_SLAB))), dim3(256), 0, (hipStream_t)stream, *d,
+                       *g1, partial, nrows, sums, (bf16_raw*)dy_hi, halo, inv_keep, amax);
     W2L_CHECK_LAUNCH();
     return 0;
 }

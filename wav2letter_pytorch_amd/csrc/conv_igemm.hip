@@ -34,6 +34,7 @@ struct IgemmParams {
     void* y;
     const float* bias;
     float* stats;
+    int stats_slots;          // 0: one statistics row per 128-column tile (plain stores); S: added onto row (tile mod S) with fp32 atomics
     int64_t x_rows_per_utt;   // x_bstride / Cin
     int64_t x_max_row;        // last readable flat row
     int N, Cin, Cout, Tout, Kw, stride, dil;
@@ -536,9 +537,16 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
                     a += red[((h * WPH + w) * 2 + 0) * BM + cl];
                     b += red[((h * WPH + w) * 2 + 1) * BM + cl];
                 }
-                float* dst = p.stats + ((int64_t)n * tiles128 + trow) * 2 * Cout;
-                dst[m0 + cl] = a;
-                dst[Cout + m0 + cl] = b;
+                const int64_t srow = (int64_t)n * tiles128 + trow;
+                if (p.stats_slots) {                       // w2l_conv_stats_mode(S): a handful of rows, re-reduced by their reader
+                    float* dst = p.stats + (srow % p.stats_slots) * 2 * Cout;
+                    atomicAdd(dst + m0 + cl, a);
+                    atomicAdd(dst + Cout + m0 + cl, b);
+                } else {
+                    float* dst = p.stats + srow * 2 * Cout;
+                    dst[m0 + cl] = a;
+                    dst[Cout + m0 + cl] = b;
+                }
             }
         }
     }
@@ -626,6 +634,8 @@ constexpr size_t kTicketBytes = 64 * 1024;              // head of the split-K w
 // thread-local: the tuner (and the test hook below) force a configuration for launches made by the CALLING thread only --
 // a backward running on an autograd worker thread while another thread tunes never sees a forced index
 static thread_local int g_force_cfg = -1;
+static thread_local int g_stats_slots = 0;      // w2l_conv_stats_mode
+extern "C" void w2l_conv_stats_mode(int slots) { g_stats_slots = slots < 0 ? 0 : (slots > 64 ? 64 : slots); }
 extern "C" void w2l_conv_force_tile_config(int idx) { g_force_cfg = idx; }
 W2L_DIAG_IGEMM_EXPORTS
 
@@ -744,6 +754,7 @@ static int igemm_launch(const void* xp, int64_t x_bstride, int64_t x_rows_total,
     p.y = y;
     p.bias = bias;
     p.stats = stats_partial;
+    p.stats_slots = stats_partial ? g_stats_slots : 0;
     p.x_rows_per_utt = x_bstride / Cin;
     p.x_max_row = x_rows_total - 1;
     p.N = N; p.Cin = Cin; p.Cout = Cout; p.Tout = Tout; p.Kw = Kw; p.stride = stride; p.dil = dil;
@@ -1008,6 +1019,7 @@ extern "C" int w2l_conv1d_igemm_fp8(const void* xq, int64_t x_bstride, int64_t x
     p.y = y;
     p.bias = bias;
     p.stats = stats_partial;
+    p.stats_slots = stats_partial ? g_stats_slots : 0;
     p.x_rows_per_utt = x_bstride / Cin;
     p.x_max_row = x_rows_total - 1;
     p.N = N; p.Cin = Cin; p.Cout = Cout; p.Tout = Tout; p.Kw = Kw; p.stride = 1; p.dil = dil;

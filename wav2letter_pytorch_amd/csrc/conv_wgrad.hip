@@ -16,6 +16,7 @@
 // Replaces the weight-gradient half of aten::convolution_backward for the
 // nn.Conv1d call sites wav2letter.py:35-36,42 / jasper.py:96-105,127.
 #include "conv_wgrad_kernel.h"
+#include "../../include/w2l_hip.h"
 #include <algorithm>
 #include <array>
 #include <map>
@@ -317,63 +318,10 @@ extern "C" int64_t w2l_wgrad_workspace_bytes(int Cin, int Cout, int Kw) {
     return (int64_t)wgrad_ws_need(Cin, Cout, Kw, 32);      // 32 = the largest split count the tuner tries
 }
 
-extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride,
-                                   int64_t x_rows_total, float* dw, int N, int Cin, int Cout, int Tout, int Kw,
-                                   int stride, int dil, int accumulate, void* ws, int64_t ws_bytes, void* stream) {
-    W2L_CHECK_ARG(dy && xp && dw, "conv1d_wgrad: null pointer");
-    W2L_CHECK_ARG(N > 0 && Tout > 0 && Kw > 0 && stride > 0 && dil > 0, "conv1d_wgrad: bad sizes");
-    W2L_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && Cin > 0 && Cout > 0,
-                  "conv1d_wgrad: channels (%d,%d) must be positive multiples of 64", Cin, Cout);
-    W2L_CHECK_ARG(dy_bstride % Cout == 0 && x_bstride % Cin == 0, "conv1d_wgrad: batch strides must be whole rows");
-    W2L_CHECK_ARG(x_rows_total * (int64_t)Cin * 2 < (1LL << 32), "conv1d_wgrad: activation buffer exceeds 32-bit byte offsets");
-    WgradParams p;
-    p.dy = (const bf16_raw*)dy;
-    p.x = (const bf16_raw*)xp;
-    p.dw = dw;
-    p.dy_rows_per_utt = dy_bstride / Cout;
-    p.x_rows_per_utt = x_bstride / Cin;
-    p.x_max_row = x_rows_total - 1;
-    p.N = N; p.Cin = Cin; p.Cout = Cout; p.Tout = Tout; p.Kw = Kw; p.stride = stride; p.dil = dil;
-    p.tiles_m = (Cout + BM - 1) / BM;
-    p.tiles_n = (Cin + BNC - 1) / BNC;
-    const WgradResolved rs = wgrad_resolve(N, Cin, Cout, Tout, Kw, stride, dil, ws != nullptr, ws_bytes);
-    const int order = rs.order, splits = rs.splits;
-    const bool tg2 = rs.tg2, m32 = rs.m32, taps3 = rs.taps3;
-    const int kwb = rs.kwb, kwblk = rs.kwblk;
-    p.tsteps = rs.tsteps;
-    p.order = order & 1;
-    p.streamk = rs.streamk ? 1 : 0;
-    p.total_steps = N * p.tsteps;
-    p.steps_per_split = (p.total_steps + splits - 1) / splits;
-    p.splits = splits;
-    p.accumulate = accumulate;
-    p.tickets = rs.slabs ? (unsigned*)ws : nullptr;
-    p.slabs = rs.slabs ? (float*)((char*)ws + kWgradTicketBytes) : nullptr;
-    p.atomic = rs.atomic;
-    p.kgroups = rs.kgroups;
-    p.dealt = p.dealt_b = 0;
-    const int xr = (BT - 1) * stride + (kwblk - 1) * dil + 1;
-    p.xrows_lds = (xr + 3) & ~3;
-    const size_t lds = 2 * BT * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
-    W2L_CHECK_ARG(lds <= 160 * 1024, "conv1d_wgrad: stride %d / dilation %d need %zu bytes of LDS", stride, dil, lds);
-    dim3 grid(p.tiles_m * p.tiles_n * p.kgroups, splits), block(tg2 ? 512 : 256);
-    g_last_dealt = false;
-    if (rs.G > 0) {
-        W2L_CHECK_ARG(dealt_fill(p, rs.tiles, p.total_steps, rs.G), "conv1d_wgrad: no dealt form for %d tiles x %d steps on %d ranges",
-                      rs.tiles, p.total_steps, rs.G);
-        grid = dim3((unsigned)(p.dealt + p.dealt_b), 1);
-        g_last_dealt = true;
-    }
-    if (p.streamk) {
-        // one block per resident slot, but at least ~16 K steps each (short ranges are all prologue and epilogue)
-        const int64_t W = (int64_t)grid.x * p.total_steps;
-        W2L_CHECK_ARG(W < (1LL << 31), "conv1d_wgrad: (tile, step) space exceeds 32 bits");
-        int64_t g = W / 16;
-        const int64_t resident = tg2 ? kResidentBlocks / 2 : kResidentBlocks;
-        if (g > resident) g = resident;
-        if (g < 1) g = 1;
-        grid = dim3((unsigned)g, 1);
-    }
+// the kernel of a resolved plan: (taps per wave, stride-1 specialisation, stream-K, tap groups per block, 32x32x16 fragments,
+// three taps with AGPR accumulators)
+static int wgrad_dispatch(const WgradParams& p, dim3 grid, bool tg2, bool m32, bool taps3, int kwb, int stride, size_t lds, void* stream) {
+    dim3 block(tg2 ? 512 : 256);
 #define W2L_WGRAD_LAUNCH(K, S1_, SK_)                                                                     \
     do {                                                                                                  \
         W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<K, S1_, SK_>));                    \
@@ -383,7 +331,7 @@ extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const voi
         hipFunction_t fn;
         if (int e = wgrad3_function(&fn, tg2 ? 1 : 0)) return e;
         W2L_CHECK_ARG(lds <= 2 * BT * ROWB + 2 * (size_t)(tg2 ? 88 : 72) * ROWB, "conv1d_wgrad: the three-tap kernel's LDS window is too small");
-        void* args[] = {&p};
+        void* args[] = {const_cast<WgradParams*>(&p)};
         W2L_CHECK_HIP(hipModuleLaunchKernel(fn, grid.x, grid.y, 1, tg2 ? 512 : 256, 1, 1, 0, (hipStream_t)stream, args, nullptr));
     } else if (m32) {
         if (kwb == 2) {
@@ -414,6 +362,134 @@ extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const voi
 #undef W2L_WGRAD_LAUNCH
     W2L_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int w2l_conv1d_wgrad_ws(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride,
+                                   int64_t x_rows_total, float* dw, int N, int Cin, int Cout, int Tout, int Kw,
+                                   int stride, int dil, int accumulate, void* ws, int64_t ws_bytes, void* stream) {
+    W2L_CHECK_ARG(dy && xp && dw, "conv1d_wgrad: null pointer");
+    W2L_CHECK_ARG(N > 0 && Tout > 0 && Kw > 0 && stride > 0 && dil > 0, "conv1d_wgrad: bad sizes");
+    W2L_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && Cin > 0 && Cout > 0,
+                  "conv1d_wgrad: channels (%d,%d) must be positive multiples of 64", Cin, Cout);
+    W2L_CHECK_ARG(dy_bstride % Cout == 0 && x_bstride % Cin == 0, "conv1d_wgrad: batch strides must be whole rows");
+    W2L_CHECK_ARG(x_rows_total * (int64_t)Cin * 2 < (1LL << 32), "conv1d_wgrad: activation buffer exceeds 32-bit byte offsets");
+    WgradParams p;
+    p.nlayers = 1;
+    WgradLayer& l0 = p.layers[0];
+    l0.dy = (const bf16_raw*)dy;
+    l0.x = (const bf16_raw*)xp;
+    l0.dw = dw;
+    l0.dy_rows_per_utt = dy_bstride / Cout;
+    l0.x_rows_per_utt = x_bstride / Cin;
+    l0.x_max_row = x_rows_total - 1;
+    l0.Cin = Cin; l0.Cout = Cout; l0.Kw = Kw;
+    l0.tiles_m = (Cout + BM - 1) / BM;
+    l0.tiles_n = (Cin + BNC - 1) / BNC;
+    l0.tile0 = 0;
+    p.N = N; p.Tout = Tout; p.stride = stride; p.dil = dil;
+    const WgradResolved rs = wgrad_resolve(N, Cin, Cout, Tout, Kw, stride, dil, ws != nullptr, ws_bytes);
+    const int order = rs.order, splits = rs.splits;
+    const bool tg2 = rs.tg2, m32 = rs.m32, taps3 = rs.taps3;
+    const int kwb = rs.kwb, kwblk = rs.kwblk;
+    p.tsteps = rs.tsteps;
+    p.order = order & 1;
+    p.streamk = rs.streamk ? 1 : 0;
+    p.total_steps = N * p.tsteps;
+    p.steps_per_split = (p.total_steps + splits - 1) / splits;
+    p.splits = splits;
+    p.accumulate = accumulate;
+    p.tickets = rs.slabs ? (unsigned*)ws : nullptr;
+    p.slabs = rs.slabs ? (float*)((char*)ws + kWgradTicketBytes) : nullptr;
+    p.atomic = rs.atomic;
+    l0.kgroups = rs.kgroups;
+    p.tiles_total = rs.tiles;
+    p.dealt = p.dealt_b = 0;
+    const int xr = (BT - 1) * stride + (kwblk - 1) * dil + 1;
+    p.xrows_lds = (xr + 3) & ~3;
+    const size_t lds = 2 * BT * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
+    W2L_CHECK_ARG(lds <= 160 * 1024, "conv1d_wgrad: stride %d / dilation %d need %zu bytes of LDS", stride, dil, lds);
+    dim3 grid(p.tiles_total, splits), block(tg2 ? 512 : 256);
+    g_last_dealt = false;
+    if (rs.G > 0) {
+        W2L_CHECK_ARG(dealt_fill(p, rs.tiles, p.total_steps, rs.G), "conv1d_wgrad: no dealt form for %d tiles x %d steps on %d ranges",
+                      rs.tiles, p.total_steps, rs.G);
+        grid = dim3((unsigned)(p.dealt + p.dealt_b), 1);
+        g_last_dealt = true;
+    }
+    if (p.streamk) {
+        // one block per resident slot, but at least ~16 K steps each (short ranges are all prologue and epilogue)
+        const int64_t W = (int64_t)grid.x * p.total_steps;
+        W2L_CHECK_ARG(W < (1LL << 31), "conv1d_wgrad: (tile, step) space exceeds 32 bits");
+        int64_t g = W / 16;
+        const int64_t resident = tg2 ? kResidentBlocks / 2 : kResidentBlocks;
+        if (g > resident) g = resident;
+        if (g < 1) g = 1;
+        grid = dim3((unsigned)g, 1);
+    }
+    return wgrad_dispatch(p, grid, tg2, m32, taps3, kwb, stride, lds, stream);
+}
+
+// ---- a GROUP of layers in one launch (WgradLayer): their tiles are one pool of equal-shaped work items.  Plain stores, one
+// block per tile (no split: a group exists to fill the chip without one).  form: plan order bits 0 (block order inside a
+// layer), 2 (two tap groups per 8-wave block), 3 (32x32x16 fragments), 4 (three taps per wave, AGPR accumulators).
+extern "C" int w2l_wgrad_group_tiles(int Cin, int Cout, int Kw, int form) {
+    const int kwb = (form & kTaps3) ? 3 : (Kw > 1 ? KWB_DEFAULT : 1);
+    const int kwblk = (form & kTapGroups2) ? 2 * kwb : kwb;
+    return ((Cout + BM - 1) / BM) * ((Cin + BNC - 1) / BNC) * ((Kw + kwblk - 1) / kwblk);
+}
+
+extern "C" int w2l_conv1d_wgrad_group(const w2l_wgrad_item_t* items, int nitems, int N, int Tout, int dil, int form, void* stream) {
+    W2L_CHECK_ARG(items && nitems >= 1 && nitems <= W2L_WGRAD_MAX_LAYERS, "conv1d_wgrad_group: 1..%d layers", W2L_WGRAD_MAX_LAYERS);
+    W2L_CHECK_ARG(N > 0 && Tout > 0 && dil > 0, "conv1d_wgrad_group: bad sizes");
+    const bool taps3 = (form & kTaps3) != 0, tg2 = (form & kTapGroups2) != 0, m32 = (form & kMfma32) != 0 && !taps3 && !tg2;
+    W2L_CHECK_ARG(!(form & (kStreamK | kDealt | kAtomicSplit)), "conv1d_wgrad_group: block forms only (order bits 0, 2, 3, 4)");
+    W2L_CHECK_ARG(!taps3 || dil <= kTaps3MaxDil, "conv1d_wgrad_group: the three-tap form takes dilation <= %d", kTaps3MaxDil);
+    WgradParams p;
+    const int kwb = taps3 ? 3 : KWB_DEFAULT, kwblk = tg2 ? 2 * kwb : kwb;
+    int tiles = 0;
+    for (int i = 0; i < nitems; ++i) {
+        const w2l_wgrad_item_t& it = items[i];
+        W2L_CHECK_ARG(it.dy && it.xp && it.dw, "conv1d_wgrad_group: null pointer (layer %d)", i);
+        W2L_CHECK_ARG(it.Cin % 64 == 0 && it.Cout % 64 == 0 && it.Cin > 0 && it.Cout > 0 && it.Kw > 0,
+                      "conv1d_wgrad_group: channels (%d,%d) must be positive multiples of 64", it.Cin, it.Cout);
+        W2L_CHECK_ARG(it.Kw > 1 || kwb == KWB_DEFAULT || taps3, "conv1d_wgrad_group: bad form");
+        W2L_CHECK_ARG(it.dy_bstride % it.Cout == 0 && it.x_bstride % it.Cin == 0, "conv1d_wgrad_group: batch strides must be whole rows");
+        W2L_CHECK_ARG(it.x_rows_total * (int64_t)it.Cin * 2 < (1LL << 32), "conv1d_wgrad_group: activation buffer exceeds 32-bit byte offsets");
+        WgradLayer& l = p.layers[i];
+        l.dy = (const bf16_raw*)it.dy;
+        l.x = (const bf16_raw*)it.xp;
+        l.dw = it.dw;
+        l.dy_rows_per_utt = it.dy_bstride / it.Cout;
+        l.x_rows_per_utt = it.x_bstride / it.Cin;
+        l.x_max_row = it.x_rows_total - 1;
+        l.Cin = it.Cin; l.Cout = it.Cout; l.Kw = it.Kw;
+        l.tiles_m = (it.Cout + BM - 1) / BM;
+        l.tiles_n = (it.Cin + BNC - 1) / BNC;
+        l.kgroups = (it.Kw + kwblk - 1) / kwblk;
+        l.tile0 = tiles;
+        tiles += l.tiles_m * l.tiles_n * l.kgroups;
+    }
+    p.nlayers = nitems;
+    p.tiles_total = tiles;
+    p.N = N; p.Tout = Tout; p.stride = 1; p.dil = dil;
+    p.tsteps = (Tout + BT - 1) / BT;
+    p.total_steps = N * p.tsteps;
+    W2L_CHECK_ARG((int64_t)tiles * p.total_steps < (1LL << 31), "conv1d_wgrad_group: (tile, step) space exceeds 32 bits");
+    p.steps_per_split = p.total_steps;
+    p.splits = 1;
+    p.accumulate = 0;
+    p.atomic = 0;
+    p.order = form & 1;
+    p.streamk = 0;
+    p.slabs = nullptr;
+    p.tickets = nullptr;
+    p.dealt = p.dealt_b = 0;
+    const int xr = (BT - 1) + (kwblk - 1) * dil + 1;
+    p.xrows_lds = (xr + 3) & ~3;
+    const size_t lds = 2 * BT * ROWB + 2 * (size_t)p.xrows_lds * ROWB;
+    W2L_CHECK_ARG(lds <= 160 * 1024, "conv1d_wgrad_group: dilation %d needs %zu bytes of LDS", dil, lds);
+    g_last_dealt = false;
+    return wgrad_dispatch(p, dim3(tiles, 1), tg2, m32, taps3, kwb, 1, lds, stream);
 }
 
 extern "C" int w2l_conv1d_wgrad(const void* dy, int64_t dy_bstride, const void* xp, int64_t x_bstride,

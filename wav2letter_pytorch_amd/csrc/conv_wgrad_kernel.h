@@ -26,15 +26,29 @@ constexpr int ROWB = 256;     // bytes per LDS row (128 bf16)
 #define W2L_WGRAD_MAX_RANGES 1024
 constexpr int KWB_DEFAULT = W2L_DIAG_WGRAD_TAPS;   // taps per 4-wave block: 2 (common.h; a diagnostic build may probe 1)
 
-struct WgradParams {
+#define W2L_WGRAD_MAX_LAYERS 8
+// One layer of a launch.  A launch may cover SEVERAL layers (a "group": same N, Tout, stride 1, dilation and block form; any
+// Cin / Cout / Kw): their [128 co x 128 ci] x tap-group tiles form ONE pool of equal-shaped work items, so layers whose own
+// tile count fills a fraction of the 512 block slots (640 -> 640, k21: 175 three-tap tiles) fill whole rounds together --
+// no split, no partial tiles, no atomics, no zero-filled dw.
+struct WgradLayer {
     const bf16_raw* dy;
     const bf16_raw* x;
     float* dw;
     int64_t dy_rows_per_utt;  // dy_bstride / Cout
     int64_t x_rows_per_utt;
     int64_t x_max_row;
-    int N, Cin, Cout, Tout, Kw, stride, dil;
-    int tiles_m, tiles_n, kgroups, tsteps, total_steps, steps_per_split, atomic;
+    int Cin, Cout, Kw;
+    int tiles_m, tiles_n, kgroups;
+    int tile0;                // first tile of this layer in the launch's pool
+    int pad_;
+};
+
+struct WgradParams {
+    WgradLayer layers[W2L_WGRAD_MAX_LAYERS];
+    int nlayers, tiles_total;
+    int N, Tout, stride, dil;
+    int tsteps, total_steps, steps_per_split, atomic;
     int order;                 // block order inside a split: 1 = tap group fastest, 0 = co tile fastest
     int streamk;               // 1: `gridDim.x` persistent blocks share the (tile, K step) space in equal contiguous ranges
     int xrows_lds;
@@ -92,6 +106,10 @@ __device__ __forceinline__ void glds16(const void* gbase_uniform, unsigned voff,
                  :
                  : "v"(voff), "s"(gbase_uniform), "s"(lds_wave_base)
                  : "memory");
+}
+
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {     // a wave-uniform 64-bit value, provably so
+    return ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -160,7 +178,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, char* smem
     int w, w_end;                                  // (tiles * S < 2^31 is checked by the launcher)
     int split = 0, nsplit = p.splits, slab0 = 0;   // this block's place among the nsplit partial tiles of its tile; the tile's first slab
     if constexpr (SK) {
-        const int64_t W = (int64_t)p.tiles_m * p.tiles_n * p.kgroups * S;
+        const int64_t W = (int64_t)p.tiles_total * S;
         w = (int)(W * lin / gridDim.x);
         w_end = (int)(W * (lin + 1) / gridDim.x);
     } else {
@@ -169,8 +187,14 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, char* smem
             const bool second = b >= G;
             const unsigned r = __builtin_amdgcn_readfirstlane(second ? (unsigned)p.dealt_perm[b - G] : (unsigned)xcd_remap((int)b, (int)G));
             if (r == 0xffffu) return;                  // a padding position of the per-XCD deal (whole block, before any barrier)
-            const DealtSeg sg = dealt_segment((unsigned)(p.tiles_m * p.tiles_n * p.kgroups), (unsigned)S, G, r, second);
-            w = sg.w; w_end = sg.w_end; nsplit = sg.nsplit; split = sg.split; slab0 = sg.slab0;
+            const DealtSeg sg = dealt_segment((unsigned)p.tiles_total, (unsigned)S, G, r, second);
+            // (the divisions run on the vector unit: hand the results back to scalar registers, or every tile coordinate and
+            // staging address of the K loop becomes a vector value -- measured: 15 % of the kernel)
+            w = __builtin_amdgcn_readfirstlane(sg.w);
+            w_end = __builtin_amdgcn_readfirstlane(sg.w_end);
+            nsplit = __builtin_amdgcn_readfirstlane(sg.nsplit);
+            split = __builtin_amdgcn_readfirstlane(sg.split);
+            slab0 = __builtin_amdgcn_readfirstlane(sg.slab0);
         } else {
             split = lin / gridDim.x;
             const int tl = lin - split * gridDim.x;
@@ -195,29 +219,51 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, char* smem
     const int schunk = lane & 15;                  // LDS 16-byte chunk
     constexpr int AG = BT / 4 / NWV;               // four-row groups of the dy tile per wave
     unsigned a_voff[AG];                           // byte offset of this lane's 16 B inside the step's dy tile
-    const unsigned x_max_row = (unsigned)p.x_max_row;          // rows * Cin * 2 < 2^32 is checked by the launcher
+    unsigned x_max_row = 0;                                    // (of the tile's layer; rows * Cin * 2 < 2^32 is checked by the launcher)
+    WgradLayer L = p.layers[0];                                // the layer of the current tile (set_tile)
     // the x window likewise (stride 1, <= 20 four-row groups): per-lane offsets inside the window, computed once per tile
     constexpr int XG = TG == 1 ? 5 : 3;
     const bool x_fast = S1 && (xrows >> 2) <= NWV * XG;
     unsigned x_voff[XG];
     // tile id -> (tap group, co tile, ci tile) and everything that depends on them
     auto set_tile = [&](int tile) {
-        tile_id = tile;
+        tile = __builtin_amdgcn_readfirstlane(tile);   // (wave-uniform, but a stream-K range start comes out of a vector division)
+        tile_id = tile;                                // (of the launch's pool: tickets and slabs are numbered by it)
+        if (p.nlayers > 1) {                           // a group launch: which layer's tile is this?  (wave-uniform: scalar loads)
+            int li = 0;
+            for (int i = 1; i < p.nlayers; ++i) li = tile >= p.layers[i].tile0 ? i : li;
+            const WgradLayer& g = p.layers[li];
+            // (field by field through readfirstlane: the values ARE uniform, and the LDS-DMA's base pointer must be a scalar operand)
+            L.dy = reinterpret_cast<const bf16_raw*>(uni64(reinterpret_cast<uint64_t>(g.dy)));
+            L.x = reinterpret_cast<const bf16_raw*>(uni64(reinterpret_cast<uint64_t>(g.x)));
+            L.dw = reinterpret_cast<float*>(uni64(reinterpret_cast<uint64_t>(g.dw)));
+            L.dy_rows_per_utt = (int64_t)uni64((uint64_t)g.dy_rows_per_utt);
+            L.x_rows_per_utt = (int64_t)uni64((uint64_t)g.x_rows_per_utt);
+            L.x_max_row = (int64_t)uni64((uint64_t)g.x_max_row);
+            L.Cin = __builtin_amdgcn_readfirstlane(g.Cin);
+            L.Cout = __builtin_amdgcn_readfirstlane(g.Cout);
+            L.Kw = __builtin_amdgcn_readfirstlane(g.Kw);
+            L.tiles_m = __builtin_amdgcn_readfirstlane(g.tiles_m);
+            L.tiles_n = __builtin_amdgcn_readfirstlane(g.tiles_n);
+            L.kgroups = __builtin_amdgcn_readfirstlane(g.kgroups);
+            tile -= __builtin_amdgcn_readfirstlane(g.tile0);
+        }
+        x_max_row = (unsigned)L.x_max_row;
         int tm, tn;
         if (p.order) {
-            kw0 = (tile % p.kgroups) * KWBLK;          // first tap of this block's group
-            tile /= p.kgroups;
-            tm = tile % p.tiles_m;
-            tn = tile / p.tiles_m;
+            kw0 = (tile % L.kgroups) * KWBLK;          // first tap of this block's group
+            tile /= L.kgroups;
+            tm = tile % L.tiles_m;
+            tn = tile / L.tiles_m;
         } else {
-            tm = tile % p.tiles_m;
-            tile /= p.tiles_m;
-            tn = tile % p.tiles_n;
-            kw0 = (tile / p.tiles_n) * KWBLK;
+            tm = tile % L.tiles_m;
+            tile /= L.tiles_m;
+            tn = tile % L.tiles_n;
+            kw0 = (tile / L.tiles_n) * KWBLK;
         }
         shift = kw0 * d;                               // the block's x window starts at its first tap
         kw0 += tg * KWB;                               // from here on: the first tap of THIS WAVE
-        ntaps = p.Kw - kw0;                            // live taps of this wave: 0 (TG > 1 only) .. KWB
+        ntaps = L.Kw - kw0;                            // live taps of this wave: 0 (TG > 1 only) .. KWB
         ntaps = ntaps < 0 ? 0 : (ntaps < KWB ? ntaps : KWB);
         m0 = tm * BM;
         c0 = tn * BNC;
@@ -226,39 +272,39 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, char* smem
             const int r = (wave_all * AG + i) * 4 + srow;
             const int g = schunk ^ (rkey(r) << 1);
             int co = m0 + g * 8;
-            co = co < p.Cout ? co : p.Cout - 8;
-            a_voff[i] = ((unsigned)r * (unsigned)p.Cout + (unsigned)co) * 2u;
+            co = co < L.Cout ? co : L.Cout - 8;
+            a_voff[i] = ((unsigned)r * (unsigned)L.Cout + (unsigned)co) * 2u;
         }
 #pragma unroll
         for (int i = 0; i < XG; ++i) {
             const int r = (wave_all + NWV * i) * 4 + srow;
             const int g = schunk ^ (rkey(r) << 1);
             int ci = c0 + g * 8;
-            ci = ci < p.Cin ? ci : p.Cin - 8;
-            x_voff[i] = ((unsigned)r * (unsigned)p.Cin + (unsigned)ci) * 2u;
+            ci = ci < L.Cin ? ci : L.Cin - 8;
+            x_voff[i] = ((unsigned)r * (unsigned)L.Cin + (unsigned)ci) * 2u;
         }
     };
     auto stage = [&](char* adst, char* bdst, int n, int ts) {
         const int t0 = ts * BT;
         // dy rows t0..t0+63 (rows >= Tout are zero by contract)
-        const char* abase = reinterpret_cast<const char*>(p.dy) + ((int64_t)n * p.dy_rows_per_utt + t0) * p.Cout * 2;
+        const char* abase = reinterpret_cast<const char*>(L.dy) + ((int64_t)n * L.dy_rows_per_utt + t0) * L.Cout * 2;
         const unsigned a_lds = __builtin_amdgcn_readfirstlane(lds_addr(adst) + wave_all * AG * 1024);
         // (the 32x32x16 form's swizzle key depends on row & 3 only, i.e. on the lane: the pieces of a wave differ by a wave-uniform
         // number of rows, which goes into the scalar base -- one offset register for the dy tile, one for the x window)
 #pragma unroll
         for (int i = 0; i < AG; ++i) {
-            if constexpr (M32) glds16(abase + (int64_t)i * 4 * p.Cout * 2, a_voff[0], a_lds + i * 1024);
+            if constexpr (M32) glds16(abase + (int64_t)i * 4 * L.Cout * 2, a_voff[0], a_lds + i * 1024);
             else glds16(abase, a_voff[i], a_lds + i * 1024);
         }
         const unsigned b_lds = __builtin_amdgcn_readfirstlane(lds_addr(bdst));
-        const unsigned xrow0 = (unsigned)(n * p.x_rows_per_utt) + (unsigned)(t0 * s + shift);
+        const unsigned xrow0 = (unsigned)(n * L.x_rows_per_utt) + (unsigned)(t0 * s + shift);
         const int ngrp = xrows >> 2;
         if (x_fast && xrow0 + (unsigned)xrows - 1u <= x_max_row) {     // (wave-uniform) the whole window exists: no clamping
-            const char* xbase = reinterpret_cast<const char*>(p.x) + (uint64_t)xrow0 * (unsigned)p.Cin * 2u;
+            const char* xbase = reinterpret_cast<const char*>(L.x) + (uint64_t)xrow0 * (unsigned)L.Cin * 2u;
 #pragma unroll
             for (int i = 0; i < XG; ++i)
                 if (wave_all + NWV * i < ngrp) {
-                    if constexpr (M32) glds16(xbase + (int64_t)i * NWV * 4 * p.Cin * 2, x_voff[0], b_lds + (wave_all + NWV * i) * 1024);
+                    if constexpr (M32) glds16(xbase + (int64_t)i * NWV * 4 * L.Cin * 2, x_voff[0], b_lds + (wave_all + NWV * i) * 1024);
                     else glds16(xbase, x_voff[i], b_lds + (wave_all + NWV * i) * 1024);
                 }
             return;
@@ -269,9 +315,9 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, char* smem
             unsigned fr = xrow0 + (unsigned)r;
             fr = fr < x_max_row ? fr : x_max_row;
             int ci = c0 + g * 8;
-            ci = ci < p.Cin ? ci : p.Cin - 8;
-            const unsigned voff = (fr * (unsigned)p.Cin + (unsigned)ci) * 2u;
-            glds16(p.x, voff, b_lds + grp * 1024);
+            ci = ci < L.Cin ? ci : L.Cin - 8;
+            const unsigned voff = (fr * (unsigned)L.Cin + (unsigned)ci) * 2u;
+            glds16(L.x, voff, b_lds + grp * 1024);
         }
     };
 
@@ -672,7 +718,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, char* smem
 #pragma unroll
     for (int tp = 0; tp < KWB; ++tp) {
         if (tp >= ntaps) break;
-        float* base = p.dw + (int64_t)(kw0 + tp) * p.Cout * p.Cin;
+        float* base = L.dw + (int64_t)(kw0 + tp) * L.Cout * L.Cin;
         if constexpr (M32) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
@@ -682,7 +728,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, char* smem
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int co = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        if (co < p.Cout && ci < p.Cin) put(base + (int64_t)co * p.Cin + ci, acc32[tp][mi][ni][r]);
+                        if (co < L.Cout && ci < L.Cin) put(base + (int64_t)co * L.Cin + ci, acc32[tp][mi][ni][r]);
                     }
                 }
         } else {
@@ -694,7 +740,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, char* smem
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int co = m0 + wm * 64 + mi * 16 + fq * 4 + r;
-                        if (co < p.Cout && ci < p.Cin) put(base + (int64_t)co * p.Cin + ci, acc[tp][mi][ni][r]);
+                        if (co < L.Cout && ci < L.Cin) put(base + (int64_t)co * L.Cin + ci, acc[tp][mi][ni][r]);
                     }
                 }
         }

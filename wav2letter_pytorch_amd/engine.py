@@ -24,6 +24,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 
 from . import _lib
+from . import wgrad_groups as WG
 from ._lib import BnActDesc, GradSrc, check, lib, ptr, stream_ptr
 
 ACT_NONE, ACT_CLAMP20, ACT_RELU = 0, 1, 2
@@ -334,6 +335,9 @@ def _side_stream(dev, main=None) -> 'torch.cuda.Stream':
     return st
 
 
+_wgroup_plans = {}                 # (convolutions of a backward pass, W2L_WGRAD_GROUPS) -> groups (wgrad_groups.plan)
+_wgroup_forms = {}                 # group signature -> measured block form of its launch, -1: one by one
+WGROUP_MAX = int(os.environ.get('W2L_WGRAD_GROUP_MAX', '8'))
 _wgrad_ws = {}                     # device index -> workspace of the stream the weight gradients run on
 _retired_ws = []                   # outgrown workspaces (grown only while shapes are new, i.e. a handful of times)
 # W2L_DETERMINISTIC=1: split weight-gradient reductions go through slabs summed in a fixed order instead of fp32 atomics
@@ -342,6 +346,8 @@ DETERMINISTIC_WGRAD = os.environ.get('W2L_DETERMINISTIC', '0') == '1'
 # W2L_DEALT_WGRAD=0: no workspace for the weight gradients in the default mode, i.e. the dealt stream-K plans (include/w2l_hip.h)
 # are neither measured nor run (round 4's plan space; the A/B switch of profiles/r05_step_ab.txt)
 DEALT_WGRAD = os.environ.get('W2L_DEALT_WGRAD', '1') == '1'
+DEFER_SPREAD = os.environ.get('W2L_DEFER_SPREAD', 'even')      # StackEngine._defer_positions
+WGRAD_AFTER_DGRAD = os.environ.get('W2L_WGRAD_AFTER_DGRAD', '0') == '1'      # StackEngine._units_backward
 # W2L_FUSED_BN_REDUCE: the BatchNorm-backward reduction of a layer formed in the epilogue of the data-gradient convolution
 # that produces the gradient wrt its output (w2l_conv1d_dgrad_bnreduce_ws) instead of by w2l_bn_act_bwd_reduce: one kernel
 # less per layer on the backward critical path.  '1' always, '0' never, 'auto' (default) for activations of fewer than
@@ -356,6 +362,19 @@ FUSED_BN_REDUCE_MAX_ROWS = 12288
 # for its own 64 channels (w2l_bn_act_bwd_apply_fin) instead of by a finalize launch of their own.  OFF by default: measured
 # neutral to slightly slower (13.75-13.85 vs 13.71-13.80 ms; with the separate reduction pass 14.1 vs 13.7-13.9).
 FOLD_BN_FINALIZE = os.environ.get('W2L_FOLD_BN_FINALIZE', '0') == '1'
+# W2L_FOLD_BN_FWD=1 (bf16 / fp8 training steps; OFF by default): the forward statistics finalize is folded into the BatchNorm-apply pass
+# (w2l_bn_act_fwd_fin) -- the convolutions add their per-tile sums onto STAT_SLOTS rows (w2l_conv_stats_mode; fp32 atomics),
+# every block of the apply pass re-reduces the rows of its 64 channels: one dependent launch less per layer on the forward's
+# critical path.  Measured (tools/step_ab.py, interleaved in one process): the forward's BatchNorm gaps shrink from 48-52 to
+# 41-45 us per layer, the step by 0.00-0.04 ms -- inside the noise -- and the forward stops being bit-reproducible (atomics):
+# off.  0 = round 4's two launches (bit-reproducible sums).
+FOLD_BN_FWD = os.environ.get('W2L_FOLD_BN_FWD', '0') == '1'
+# W2L_FAST_BN_BWD (default 1): the BatchNorm-backward chain of a plain unit (bf16, one gradient source, no residual branch) in
+# TWO launches instead of three (w2l_bn_act_bwd_reduce_slots + w2l_bn_act_bwd_apply_slots: sums onto STAT_SLOTS rows with fp32
+# atomics, finalize folded into the dy pass, every load of a wave issued before the first use).  Measured -0.14 ms per step
+# (13.14 -> 13.00, tools/step_ab.py, profiles/r05_step_ab.txt).  0 (or W2L_DETERMINISTIC=1) = round 4's chain.
+FAST_BN_BWD = os.environ.get('W2L_FAST_BN_BWD', '1') == '1' and not DETERMINISTIC_WGRAD     # (atomics: not bit-reproducible)
+STAT_SLOTS = int(os.environ.get('W2L_STAT_SLOTS', '8'))
 
 
 def _wgrad_workspace(dev, cin, cout, kw):
@@ -397,6 +416,8 @@ def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw
                 check(lib.w2l_conv1d_igemm_tune_ws(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y),
                                                    int(y.dtype == torch.float32), ptr(bias), ptr(stats), n, Cin, Cout, Tout,
                                                    Kw, stride, dil, TUNE_REPS, ptr(ws), ws.numel(), st), 'w2l_conv1d_igemm_tune_ws')
+                if stats is not None and stats.shape[0] <= 64:      # w2l_conv_stats_mode: the measuring launches ADDED to the rows
+                    stats.zero_()
         with _timed('conv_igemm_kernel', alg_flops):
             check(lib.w2l_conv1d_igemm_ws(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y), int(y.dtype == torch.float32),
                                           0, ptr(bias), ptr(stats), n, Cin, Cout, Tout, Kw, stride, dil, ptr(ws), ws.numel(),
@@ -538,6 +559,10 @@ class StackEngine:
         self.deferred = None              # the optimizer: accepts(p), token(), stepped(token), apply(p, grad)
         self.grad_reduce_start: Optional[Callable] = None      # distributed.GradReducer.start
         self._deferred: list = []
+        # grouped weight gradients (wgrad_groups.py): id(conv) -> (group id, members) for this backward pass, and the members
+        # of each group that have arrived so far -- a group is launched when its last member's dy exists
+        self._wg_of: dict = {}
+        self._wg_pending: dict = {}
 
     # ------------------------------------------------------------------ parameters
     def parameters(self) -> List[torch.Tensor]:
@@ -578,8 +603,23 @@ class StackEngine:
         _lib.require_device(x)
         global _dropout_calls
         if self._deferred:
-            self.flush_deferred()
+            self.flush_deferred(pos=0)
         precise = self.precise
+        # folded statistics finalize: the convolutions of this forward add their statistics onto STAT_SLOTS rows of ONE
+        # zero-filled pool (one fill launch per forward, not one per layer)
+        fold = FOLD_BN_FWD and training and not precise and x.is_cuda
+        self._stat_pool = None
+        self._after_apply = []
+        if fold:
+            need = 0
+            for u in self.units:
+                for c in (u.main, u.res):
+                    if c is not None and c.has_bn:
+                        need += STAT_SLOTS * 2 * padded_channels(c.cout)
+            fold = need > 0
+            if fold:
+                self._stat_pool = [torch.zeros(need, dtype=torch.float32, device=x.device), 0]
+        lib.w2l_conv_stats_mode(STAT_SLOTS if fold else 0)        # (thread-local: this thread's launches)
         N, C0, T0 = x.shape
         x = x.contiguous().float()
         dev = x.device
@@ -609,6 +649,8 @@ class StackEngine:
             check(lib.w2l_quantize_e4m3(ptr(a_hi), 0, a_hi.numel(), a0.q_scale, ptr(a0.q), st()), 'w2l_quantize_e4m3')
 
         for ui, u in enumerate(self.units):
+            if ui and self._deferred:       # held-back weight gradients due in front of this unit (flush_deferred)
+                self.flush_deferred(pos=ui)
             uc = _UnitCtx(unit=u)
             src = acts[u.src]
             conv = u.main
@@ -619,8 +661,12 @@ class StackEngine:
             y, stats, Tout = self._conv_forward(conv, src, need_stats=conv.has_bn and training)
             uc.y, uc.Tout = y, Tout
             coutp = y.shape[2]
+            fins = [None, None]             # folded finalize records (w2l_bn_act_fwd_fin) of the two branches
             if conv.has_bn:
-                uc.scale, uc.shift, uc.mean, uc.invstd = self._bn_finalize(conv, stats, N * Tout, coutp, training)
+                if fold:
+                    fins[0], (uc.scale, uc.shift, uc.mean, uc.invstd) = self._bn_fin_record(conv, stats, N * Tout, coutp)
+                else:
+                    uc.scale, uc.shift, uc.mean, uc.invstd = self._bn_finalize(conv, stats, N * Tout, coutp, training)
             if u.res is not None:
                 rsrc = acts[u.res_src]
                 y2, stats2, Tout2 = self._conv_forward(u.res, rsrc, need_stats=u.res.has_bn and training)
@@ -628,7 +674,10 @@ class StackEngine:
                     raise ValueError('residual branch shape mismatch')
                 uc.y2 = y2
                 if u.res.has_bn:
-                    uc.scale2, uc.shift2, uc.mean2, uc.invstd2 = self._bn_finalize(u.res, stats2, N * Tout, coutp, training)
+                    if fold:
+                        fins[1], (uc.scale2, uc.shift2, uc.mean2, uc.invstd2) = self._bn_fin_record(u.res, stats2, N * Tout, coutp)
+                    else:
+                        uc.scale2, uc.shift2, uc.mean2, uc.invstd2 = self._bn_finalize(u.res, stats2, N * Tout, coutp, training)
             uc.lens_out = out_lens[ui]               # length mask of this unit's output (None: not masked)
             # ---- BN-apply + dropout + activation -> padded input of the next conv
             opl, opr, omode = self._in_pad_for(ui + 1)
@@ -651,8 +700,18 @@ class StackEngine:
                 if self._q_clipped is None or self._q_clipped.device != dev:
                     self._q_clipped = torch.zeros(1, dtype=torch.int64, device=dev)
                 d.q_clipped = self._q_clipped.data_ptr()
-            check(lib.w2l_bn_act_fwd_q(C.byref(d), ptr(out_hi), ptr(out_lo), ptr(out_q), q_scale, opl + Tout + opr, opl, opr,
-                                       omode, st()), 'w2l_bn_act_fwd_q')
+            if fins[0] is not None or fins[1] is not None:
+                f1 = fins[0] if fins[0] is not None else _lib.BnFin()          # (partial NULL: scale / shift from the descriptor)
+                f2 = (fins[1] if fins[1] is not None else _lib.BnFin()) if u.res is not None else None
+                check(lib.w2l_bn_act_fwd_fin(C.byref(d), C.byref(f1), C.byref(f2) if f2 is not None else None, ptr(out_hi),
+                                             ptr(out_q), q_scale, opl + Tout + opr, opl, opr, omode, st()), 'w2l_bn_act_fwd_fin')
+                for rm, rv, rm_p, rv_p in self._after_apply:       # running statistics of a channel count that is padded
+                    rm.copy_(rm_p[: rm.numel()])
+                    rv.copy_(rv_p[: rv.numel()])
+                self._after_apply = []
+            else:
+                check(lib.w2l_bn_act_fwd_q(C.byref(d), ptr(out_hi), ptr(out_lo), ptr(out_q), q_scale, opl + Tout + opr, opl, opr,
+                                           omode, st()), 'w2l_bn_act_fwd_q')
             uc.out_index = ui + 1
             acts.append(Act(out_hi, out_lo, N, Tout, conv.cout, coutp, opl, opr, omode, uc.lens_out, out_q, q_scale))
             ctx['units'].append(uc)
@@ -660,6 +719,9 @@ class StackEngine:
         if self._nbt_pending:
             torch._foreach_add_(self._nbt_pending, 1)
             self._nbt_pending = []
+        if fold:
+            lib.w2l_conv_stats_mode(0)
+            self._stat_pool = None
         ctx['acts'] = acts
         ctx['softmax_mode'] = softmax_mode
         ctx['lens_out'] = lens_final
@@ -752,8 +814,14 @@ class StackEngine:
         y = torch.empty(N, Tout, pk.coutp, dtype=torch.float32 if f32 else torch.bfloat16, device=src.hi.device)
         stats = None
         if need_stats:
-            tiles = lib.w2l_conv_stat_tiles(N, Tout)
-            stats = torch.empty(tiles, 2, pk.coutp, dtype=torch.float32, device=src.hi.device)
+            pool = getattr(self, '_stat_pool', None)
+            if pool is not None:            # folded finalize: STAT_SLOTS zero rows of the forward's pool, added to atomically
+                n = STAT_SLOTS * 2 * pk.coutp
+                stats = pool[0][pool[1]: pool[1] + n].view(STAT_SLOTS, 2, pk.coutp)
+                pool[1] += n
+            else:
+                tiles = lib.w2l_conv_stat_tiles(N, Tout)
+                stats = torch.empty(tiles, 2, pk.coutp, dtype=torch.float32, device=src.hi.device)
         bias = _padded_vec(conv.bias, pk.coutp, 0.0)
         flops = 2.0 * N * Tout * conv.cout * conv.cin * conv.kernel
         if self.fp8 and src.q is not None and conv.stride == 1 and pk.cinp % 128 == 0 and not force_f32:
@@ -780,6 +848,8 @@ class StackEngine:
                 check(lib.w2l_conv1d_igemm_fp8_tune(xq, bstride, rows_total, ptr(wq), ptr(y), y_f32, ptr(bias), ptr(stats), N,
                                                     cin, cout, Tout, conv.kernel, conv.dilation, TUNE_REPS, st),
                       'w2l_conv1d_igemm_fp8_tune')
+                if stats is not None and getattr(self, '_stat_pool', None) is not None:
+                    stats.zero_()                                   # (the measuring launches ADDED to the statistics rows)
         with _timed('conv_igemm_fp8_kernel', flops):
             check(lib.w2l_conv1d_igemm_fp8(xq, bstride, rows_total, ptr(wq), ptr(y), y_f32, 1.0 / (src.q_scale * w_scale), None,
                                            ptr(bias), ptr(stats), N, cin, cout, Tout, conv.kernel, conv.dilation, st),
@@ -876,6 +946,31 @@ class StackEngine:
                   'w2l_bn_finalize')
         return scale, shift, mean, invstd
 
+    def _bn_fin_record(self, conv: ConvSpec, stats, count, cp):
+        """the finalize of one BatchNorm branch as a record for w2l_bn_act_fwd_fin (training mode, STAT_SLOTS statistics rows);
+        returns (record, (scale, shift, mean, invstd)) -- the four vectors are written by that launch"""
+        dev = conv.weight.device
+        scale, shift, mean, invstd = torch.empty(4, cp, dtype=torch.float32, device=dev).unbind(0)     # one allocation
+        gamma = _padded_vec(conv.bn_weight, cp, 1.0)
+        beta = _padded_vec(conv.bn_bias, cp, 0.0)
+        rm, rv = conv.running_mean, conv.running_var
+        if rm is not None and rm.numel() != cp:
+            rm_p, rv_p = _padded_vec(rm, cp, 0.0).clone(), _padded_vec(rv, cp, 1.0).clone()
+            self._after_apply.append((rm, rv, rm_p, rv_p))
+        else:
+            rm_p, rv_p = rm, rv
+        f = _lib.BnFin()
+        f.partial, f.rows, f.count = stats.data_ptr(), stats.shape[0], count
+        f.gamma, f.beta = gamma.data_ptr(), beta.data_ptr()
+        f.eps, f.momentum = conv.eps, conv.momentum
+        f.running_mean = rm_p.data_ptr() if rm_p is not None else None
+        f.running_var = rv_p.data_ptr() if rv_p is not None else None
+        f.mean, f.invstd, f.scale, f.shift = mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr()
+        f._keep = (gamma, beta, rm_p, rv_p, stats)          # alive until the launch has been enqueued (same stream: enough)
+        if conv.num_batches_tracked is not None:
+            self._nbt_pending.append(conv.num_batches_tracked)
+        return f, (scale, shift, mean, invstd)
+
     def _desc(self, uc: _UnitCtx, N, T, cp, p, lens, constant_stats: bool = False) -> BnActDesc:
         """``constant_stats``: leave mean / invstd out, which makes w2l_bn_act_bwd_apply treat BatchNorm as the per-channel
         affine map it is in eval mode (dy = scale * g)"""
@@ -927,8 +1022,14 @@ class StackEngine:
             gp[:, :, :last.C] = g_out.float().transpose(1, 2)
             act_grads[len(acts) - 1].append((gp, 0, 0, PAD_ZERO, last.T))
         else:
+            self._plan_wgrad_groups(ctx)
             pool_off = self._head_backward(ctx, g_out, small_pool, grads, act_grads)
         self._units_backward(ctx, act_grads, small_pool, pool_off, grads, batch_stats)
+        for recs in list(self._wg_pending.values()):          # (a group whose members did not all arrive: never in a full backward)
+            for r in recs:
+                self._wgrad_single(r, grads)
+        self._wg_pending.clear()
+        self._wg_of = {}
         ctx['input_grad'] = self.input_grad(ctx, act_grads[0]) if ctx.get('want_dx') and act_grads[0] else None
         if self.flat_ready is not None:
             self.flat_ready(small_pool)
@@ -1004,6 +1105,11 @@ class StackEngine:
         st = stream_ptr
         amax_pool = (torch.zeros(len(acts) + 1, 2, AMAX_SLOTS, dtype=torch.float32, device=dev)        # one fill per step
                      if self.fp8 else None)
+        slot_pool = None               # zero rows the two-launch BatchNorm-backward chain adds its sums onto (one fill per step)
+        if FAST_BN_BWD and batch_stats and not precise and dev.type == 'cuda':
+            need = sum(STAT_SLOTS * 2 * acts[uc.out_index].CP for uc in ctx['units'] if uc.unit.main.has_bn and uc.unit.res is None)
+            if need:
+                slot_pool = [torch.zeros(need, dtype=torch.float32, device=dev), 0]
         for uc in reversed(ctx['units']):
             u = uc.unit
             oi = uc.out_index
@@ -1019,14 +1125,23 @@ class StackEngine:
             g1 = self._gsrc(srcs[0])
             g2 = self._gsrc(srcs[1]) if len(srcs) > 1 else None
             sums = None
-            fold = False
+            fold = fast = False
             if u.main.has_bn or (u.res is not None and u.res.has_bn):
                 ncomp = 4 if u.res is not None else 2
                 fused = [s_[5] for s_ in srcs if len(s_) > 5 and s_[5] is not None]
+                fast = False
                 if len(fused) == len(srcs) and ncomp == 2:
                     # every gradient source was a data-gradient convolution that formed the sums in its epilogue
                     partial = fused[0] if len(fused) == 1 else torch.cat(fused, 0)
                     nb = partial.shape[0]
+                elif (FAST_BN_BWD and batch_stats and not precise and g2 is None and ncomp == 2 and slot_pool is not None
+                        and lib.w2l_bn_bwd_fast_ok(C.byref(d), C.byref(g1), None)):
+                    # the two-launch chain: sums added onto STAT_SLOTS zero rows of the step's pool, finalize folded into the dy pass
+                    fast = True
+                    nb = STAT_SLOTS
+                    partial = slot_pool[0][slot_pool[1]: slot_pool[1] + nb * 2 * coutp].view(nb, 2, coutp)
+                    slot_pool[1] += nb * 2 * coutp
+                    check(lib.w2l_bn_act_bwd_reduce_slots(C.byref(d), C.byref(g1), ptr(partial), nb, st()), 'w2l_bn_act_bwd_reduce_slots')
                 else:
                     nb = lib.w2l_bn_bwd_blocks(N, Tout, coutp)
                     partial = torch.empty(nb, ncomp, coutp, dtype=torch.float32, device=dev)
@@ -1034,7 +1149,7 @@ class StackEngine:
                                                     st()), 'w2l_bn_act_bwd_reduce')
                 sums = small_pool[pool_off: pool_off + 4 * coutp].view(4, coutp)
                 pool_off += 4 * coutp
-                fold = FOLD_BN_FINALIZE and batch_stats
+                fold = (FOLD_BN_FINALIZE and batch_stats) or fast
                 if not fold:
                     check(lib.w2l_bn_bwd_finalize(ptr(partial), nb, coutp, ncomp, ptr(sums), st()), 'w2l_bn_bwd_finalize')
                 uc.keep.append((partial, sums))
@@ -1061,7 +1176,10 @@ class StackEngine:
             amax = amax_pool[oi] if fp8_dgrad or fp8_wgrad else None          # [2][AMAX_SLOTS]: dy, dy2
             amax_w = amax if fp8_wgrad else None
             amax_d = amax if fp8_dgrad else None
-            if fold:
+            if fold and fast:
+                check(lib.w2l_bn_act_bwd_apply_slots(C.byref(d), C.byref(g1), ptr(partial), nb, ptr(sums), ptr(dy_hi), h1, ptr(amax),
+                                                     st()), 'w2l_bn_act_bwd_apply_slots')
+            elif fold:
                 check(lib.w2l_bn_act_bwd_apply_fin(C.byref(d), C.byref(g1), C.byref(g2) if g2 else None, ptr(partial), nb,
                                                    ptr(sums), ptr(dy_hi), ptr(dy_lo), h1, ptr(dy2_hi), ptr(dy2_lo), h2, ptr(amax),
                                                    st()), 'w2l_bn_act_bwd_apply_fin')
@@ -1081,8 +1199,16 @@ class StackEngine:
             # main branch
             pkm = pack_weights(main, precise)
             src = acts[u.src] if u.dw is None else uc.mid
-            self._wgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, grads, amax=None if amax_w is None else amax_w[0],
-                        defer=self._defer_ok(ctx, uc, main))
+            # Which of the unit's two gradients is enqueued first decides what the weight gradient runs beside.  Weight
+            # gradient first (rounds 1-4): its side-stream launch waits for dy only, so it competes with the data gradient of
+            # the SAME unit -- two kernels that each fill the chip gain nothing from sharing it -- and is over when the next
+            # unit's BatchNorm-backward chain (three short HBM-bound kernels + their stream boundaries, 60-90 us with the
+            # matrix cores idle) begins.  Data gradient first (WGRAD_AFTER_DGRAD): the weight gradient's launch waits for the
+            # data gradient too, i.e. it STARTS where that chain starts and runs beside it.
+            late = WGRAD_AFTER_DGRAD and u.dw is None and need_dx_main
+            if not late:
+                self._wgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, grads, amax=None if amax_w is None else amax_w[0],
+                            defer=self._defer_ok(ctx, uc, main))
             if main.bias is not None:
                 if main.has_bn and batch_stats:      # sum(dy) == 0 identically under batch-statistics BatchNorm
                     grads[id(main.bias)] = self._zeros(main.cout, dev)      # zero on every rank: nothing to average
@@ -1097,6 +1223,9 @@ class StackEngine:
             elif need_dx_main:
                 act_grads[u.src].append(self._dgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, self._producer(ctx, u.src),
                                                     amax=None if amax_d is None else amax_d[0]))
+            if late:
+                self._wgrad(main, pkm, dy_hi, dy_lo, h1, Tout, src, grads, amax=None if amax_w is None else amax_w[0],
+                            defer=self._defer_ok(ctx, uc, main))
             if res is not None:
                 pkr = pack_weights(res, precise)
                 rsrc = acts[u.res_src]
@@ -1207,10 +1336,35 @@ class StackEngine:
             return False
         return (w.is_cuda and w.grad is None and not torch.cuda.is_current_stream_capturing() and opt.accepts(w))
 
-    def flush_deferred(self):
+    def _defer_positions(self, recs):
+        """WHERE in the forward pass each held-back weight gradient is launched (unit index; it is launched in front of
+        that unit's convolution).  All of them at the start (round 4) run as one burst of long-lived full-chip kernels in
+        the first ~3 ms of the forward -- the BatchNorm chains of the early, narrow layers are over-covered, those of the wide
+        layers at the end (and the classifier / CTC tail) meet no matrix work at all -- and the forward's small dependent
+        kernels queue behind whole rounds of their blocks.  W2L_DEFER_SPREAD: 'start' = round 4; 'la:K' = K units ahead of
+        the layer whose update it carries (just in time, with margin); 'even' (default) = evenly over the units in front of
+        the first deferred layer.  A gradient is always launched strictly before its own layer's convolution."""
+        mode = DEFER_SPREAD
+        uis = []
+        for r in recs:
+            conv = r['conv']
+            uis.append(next((i for i, u in enumerate(self.units) if u.main is conv or u.res is conv or u.dw is conv), 0))
+        first = min(uis) if uis else 0
+        for j, (r, ui) in enumerate(zip(recs, uis)):
+            if mode == 'start':
+                at = 0
+            elif mode.startswith('la:'):
+                at = ui - int(mode[3:])
+            else:
+                at = (j * max(first - 1, 0)) // max(len(recs), 1)
+            r['at'] = max(0, min(at, ui - 1))
+
+    def flush_deferred(self, pos=None):
         """launch the weight gradients held back by the last backward pass -- on the weight-gradient stream, in forward order,
         each one handed to the optimizer's fused update (which tags the weight's operand pack with an event the forward
-        convolution of that layer waits for).  Called at the start of every forward; optim.FusedSGD.join() calls it too.
+        convolution of that layer waits for).  The forward pass calls it in front of every unit with that unit's index
+        (``pos``): the gradients due there are launched (_defer_positions); without ``pos`` (optim.FusedSGD.join(): checkpoints,
+        validation, the end of the forward) everything pending goes.
         If no optimizer step was taken since that backward (the caller only wanted gradients), the gradients are computed
         on the current stream and stored in ``param.grad`` instead."""
         recs, self._deferred = self._deferred, []
@@ -1218,6 +1372,15 @@ class StackEngine:
             return
         recs.sort(key=lambda r: r['order'])
         opt = self.deferred
+        if pos is not None:
+            if any('at' not in r for r in recs):
+                self._defer_positions([r for r in recs if opt is not None and opt.stepped(r['token'])])
+            later = [r for r in recs if r.get('at', 0) > pos and opt is not None and opt.stepped(r['token'])]
+            if later:
+                self._deferred = later
+                recs = [r for r in recs if not any(r is q for q in later)]
+                if not recs:
+                    return
         dev = recs[0]['dy_hi'].device
         main = torch.cuda.current_stream(dev)
         pending = []
@@ -1304,6 +1467,14 @@ class StackEngine:
             self._deferred.append({'conv': conv, 'pk': pk, 'dy_hi': dy_hi, 'dy_lo': dy_lo, 'halo': halo, 'Tout': Tout, 'src': src,
                                    'f8': f8, 'order': len(self._deferred) * -1, 'token': self.deferred.token()})
             return
+        grp = self._wg_of.get(id(conv)) if self._wg_of else None
+        if grp is not None and f8 is None and dy_hi.is_cuda:
+            recs = self._wg_pending.setdefault(grp[0], [])
+            recs.append({'conv': conv, 'pk': pk, 'dy_hi': dy_hi, 'dy_lo': dy_lo, 'halo': halo, 'Tout': Tout, 'src': src})
+            if len(recs) == grp[1]:
+                del self._wg_pending[grp[0]]
+                self._wgrad_group_now(recs, grads)
+            return
         if not self.overlap_wgrad or not dy_hi.is_cuda:
             return self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads, f8=f8)
         main = self._main_stream or torch.cuda.current_stream(dy_hi.device)
@@ -1317,6 +1488,152 @@ class StackEngine:
         self._wgrad_now(conv, pk, dy_hi, dy_lo, halo, Tout, src, grads, fork=(main, side), f8=f8)
         self._held.extend(t for t in (dy_hi, dy_lo, src.hi, src.lo) + ((src.q,) + f8 if f8 else ()) if t is not None)
         self._side_used = True
+
+    # ------------------------------------------------------------------ grouped weight gradients
+    def _plan_wgrad_groups(self, ctx):
+        """which weight gradients of this backward pass share a launch (wgrad_groups.plan over the convolutions in the order
+        their dy appears: classifier, then the units top down, main branch before residual branch)"""
+        self._wg_of, self._wg_pending = {}, {}
+        setting = WG.setting()
+        if self.precise or self.fp8 or setting.strip().lower() in ('0', 'off', 'none') or not ctx['training']:
+            return
+        acts: List[Act] = ctx['acts']
+        N = ctx['out'].shape[0]
+        convs, seq = [], []
+
+        def add(conv, src, Tout, uc):
+            ok = (conv.stride == 1 and conv.weight.is_cuda and (uc is None or not self._defer_ok(ctx, uc, conv)))
+            pk = pack_weights(conv, False) if ok else None
+            ok = ok and src.CP == pk.cinp and src.lo is None
+            convs.append(conv)
+            seq.append((pk.cinp, pk.coutp, conv.kernel, conv.dilation, (N, Tout)) if ok else None)
+
+        if self.head is not None:
+            add(self.head, acts[-1], ctx['out'].shape[1], None)
+        for uc in reversed(ctx['units']):
+            u = uc.unit
+            add(u.main, acts[u.src] if u.dw is None else uc.mid, uc.Tout, uc)
+            if u.res is not None:
+                add(u.res, acts[u.res_src], uc.Tout, uc)
+        key = (tuple(seq), setting)
+        groups = _wgroup_plans.get(key)
+        if groups is None:
+            groups = WG.parse_override(setting, len(seq))
+            if groups is None:
+                groups = WG.plan(seq, max_group=WGROUP_MAX)
+            groups = [g for g in groups if all(seq[i] is not None for i in g)
+                      and len({(seq[i][3], seq[i][4]) for i in g}) == 1 and len(g) <= WG.MAX_GROUP]
+            _wgroup_plans[key] = groups
+        for gi, g in enumerate(groups):
+            for i in g:
+                self._wg_of[id(convs[i])] = (gi, len(g))
+
+    def _wgrad_single(self, r, grads, sink=None):
+        """one member of a group through the ordinary path (its own measured plan)"""
+        conv, dy_hi = r['conv'], r['dy_hi']
+        if not self.overlap_wgrad or sink is not None:
+            return self._wgrad_now(conv, r['pk'], dy_hi, r['dy_lo'], r['halo'], r['Tout'], r['src'], grads, sink=sink)
+        main = self._main_stream or torch.cuda.current_stream(dy_hi.device)
+        if self._side is None or self._side.device != dy_hi.device:
+            self._side = _side_stream(dy_hi.device, main)
+        self._wgrad_now(conv, r['pk'], dy_hi, r['dy_lo'], r['halo'], r['Tout'], r['src'], grads, fork=(main, self._side))
+        self._held.extend(t for t in (dy_hi, r['dy_lo'], r['src'].hi, r['src'].lo) if t is not None)
+        self._side_used = True
+
+    def _wgrad_group_now(self, recs, grads):
+        """the weight gradients of ``recs`` (same N, Tout, dilation; stride 1) in ONE launch (w2l_conv1d_wgrad_group) -- or one
+        by one, if that measured faster for this group (decided once per group signature, during warm-up)"""
+        dev = recs[0]['dy_hi'].device
+        N, Tout, dil = recs[0]['src'].N, recs[0]['Tout'], recs[0]['conv'].dilation
+        key = (tuple((r['pk'].cinp, r['pk'].coutp, r['conv'].kernel) for r in recs), N, Tout, dil, dev.index)
+        form = _wgroup_forms.get(key)
+        if form is None:
+            form = self._wgrad_group_measure(recs, key) if AUTOTUNE and not torch.cuda.is_current_stream_capturing() else \
+                WG.best_cost([k for k in key[0]], dil, False)[1]
+            _wgroup_forms[key] = form
+        if form < 0:
+            for r in recs:
+                self._wgrad_single(r, grads)
+            return
+        main = self._main_stream or torch.cuda.current_stream(dev)
+        fork = None
+        if self.overlap_wgrad:
+            if self._side is None or self._side.device != dev:
+                self._side = _side_stream(dev, main)
+            fork = (main, self._side)
+        dws = self._wgrad_group_launch(recs, form, fork)
+        for r, dw in zip(recs, dws):
+            w = r['conv'].weight
+            cout, cin, kw = w.shape
+            g = dw.permute(1, 2, 0)                     # logical [CoutP, CinP, Kw]
+            if not (r['pk'].coutp == cout and r['pk'].cinp == cin):
+                g = g[:cout, :cin, :]
+            self._set(grads, w, g, storage=dw)
+
+    def _wgrad_group_launch(self, recs, form, fork):
+        dev = recs[0]['dy_hi'].device
+        N, Tout, dil = recs[0]['src'].N, recs[0]['Tout'], recs[0]['conv'].dilation
+        items = (_lib.WgradItem * len(recs))()
+        dws = []
+        for it, r in zip(items, recs):
+            conv, pk, src, halo = r['conv'], r['pk'], r['src'], r['halo']
+            row_off = src.pad_l - conv.pad_l
+            dw = torch.empty(conv.kernel, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)      # (on the caller's stream)
+            dws.append(dw)
+            it.dy = r['dy_hi'].data_ptr() + halo * pk.coutp * 2
+            it.dy_bstride = (Tout + halo) * pk.coutp
+            it.xp = src.hi.data_ptr() + row_off * src.CP * 2
+            it.x_bstride = src.rows * src.CP
+            it.x_rows_total = N * src.rows - row_off
+            it.dw = dw.data_ptr()
+            it.Cin, it.Cout, it.Kw = pk.cinp, pk.coutp, conv.kernel
+        flops = sum(2.0 * N * Tout * r['pk'].coutp * r['pk'].cinp * r['conv'].kernel for r in recs)
+        if fork is not None:
+            ev = torch.cuda.Event()
+            ev.record(fork[0])
+            fork[1].wait_event(ev)
+            self._held.extend(dws)
+            self._held.extend(t for r in recs for t in (r['dy_hi'], r['src'].hi) if t is not None)
+            self._side_used = True
+        with torch.cuda.stream(fork[1]) if fork is not None else _nullctx():
+            with _timed('conv_wgrad3_kernel' if form & 16 else 'conv_wgrad_kernel', flops):
+                check(lib.w2l_conv1d_wgrad_group(items, len(recs), N, Tout, dil, form, stream_ptr()), 'w2l_conv1d_wgrad_group')
+        return dws
+
+    def _wgrad_group_measure(self, recs, key) -> int:
+        """SYNCHRONISING, warm-up only: the group in every block form against its members one by one with their own measured
+        plans (zero fills included); returns the fastest form, or -1 for 'one by one'"""
+        dev = recs[0]['dy_hi'].device
+        main = torch.cuda.current_stream(dev)
+        if self._side is not None:
+            main.wait_stream(self._side)
+
+        def timed(fn, reps=3):
+            fn()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(main)
+            for _ in range(reps):
+                fn()
+            e.record(main)
+            e.synchronize()
+            return s.elapsed_time(e) / reps
+
+        def singles():
+            for r in recs:
+                self._wgrad_single(r, {}, sink=lambda *a: None)
+        best = (timed(singles), -1)
+        report = [f'one by one {best[0]:.3f}']
+        for form in WG.forms_for(key[3]):
+            try:
+                t = timed(lambda: self._wgrad_group_launch(recs, form, None))
+            except RuntimeError:
+                continue
+            report.append(f'form {form} {t:.3f}')
+            best = min(best, (t, form))
+        if os.environ.get('W2L_WGRAD_GROUPS_VERBOSE'):
+            print(f'[w2l] wgrad group {key[0]} N={key[1]} T={key[2]} d={key[3]}: ' + ', '.join(report) + f' ms -> {best[1]}', flush=True)
+        _tune_state['dirty'] = True
+        return best[1]
 
     def _wgrad_now(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, grads, fork=None, f8=None, sink=None):
         """dW through w2l_conv1d_wgrad, written in the parameter's own physical layout when possible.
