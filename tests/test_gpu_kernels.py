@@ -206,6 +206,36 @@ def test_conv_igemm_every_configuration(L, with_stats):
             if len(outs) == 2:
                 assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), idx
                 assert not ws[:65536].any(), idx
+                if idx % 13 == 0:
+                    # the same split plan and workspace on OTHER data (x * 2, no bias: exact): a slab line left in a cache by
+                    # the launch before would show -- the slabs are stored and loaded past the non-coherent caches (sc1)
+                    ys = []
+                    for xin in (xh, xh * 2):
+                        y2 = torch.full((N, Tout, coutp), float('nan'), dtype=torch.bfloat16, device='cuda')
+                        L.lib.w2l_conv_force_tile_config(idx)
+                        try:
+                            L.check(L.lib.w2l_conv1d_igemm_ws(L.ptr(xin), rows * cinp, N * rows, L.ptr(fh), L.ptr(y2), 0, 0, None, None,
+                                                              N, cinp, coutp, Tout, Kw, s, d, L.ptr(ws), ws.numel(), L.stream_ptr()))
+                        finally:
+                            L.lib.w2l_conv_force_tile_config(-1)
+                        torch.cuda.synchronize()
+                        ys.append(y2)
+                    assert torch.equal(ys[1], ys[0] * 2), idx
+            if with_stats and idx % 7 == 0:
+                # w2l_conv_stats_mode(8): the per-tile statistics ADDED onto 8 zero rows (fp32 atomics) -- the same column sums
+                slots = torch.zeros(8, 2, coutp, device='cuda')
+                y3 = torch.empty(N, Tout, coutp, dtype=torch.bfloat16, device='cuda')
+                L.lib.w2l_conv_force_tile_config(idx)
+                L.lib.w2l_conv_stats_mode(8)
+                try:
+                    L.check(L.lib.w2l_conv1d_igemm_ws(L.ptr(xh), rows * cinp, N * rows, L.ptr(fh), L.ptr(y3), 0, 0, L.ptr(bd), L.ptr(slots),
+                                                      N, cinp, coutp, Tout, Kw, s, d, L.ptr(ws), ws.numel(), L.stream_ptr()))
+                finally:
+                    L.lib.w2l_conv_stats_mode(0)
+                    L.lib.w2l_conv_force_tile_config(-1)
+                torch.cuda.synchronize()
+                assert torch.equal(y3, y), idx
+                assert relerr(slots.sum(0), stats.sum(0)) < 1e-5, idx
     assert ran >= (28 if with_stats else 40) * 6, ran
     assert split_ran >= 100, split_ran
 

@@ -65,7 +65,7 @@ def main():
         torch.cuda.synchronize()
 
     defaults = {k: getattr(E, k) for k in ('FOLD_BN_FWD', 'STAT_SLOTS', 'DEFER_SPREAD', 'FOLD_BN_FINALIZE', 'FUSED_BN_REDUCE',
-                                           'DETERMINISTIC_WGRAD', 'DEALT_WGRAD', 'WGRAD_AFTER_DGRAD', 'FAST_BN_BWD')}
+                                           'DETERMINISTIC_WGRAD', 'DEALT_WGRAD', 'WGRAD_AFTER_DGRAD', 'FAST_BN_BWD', 'WGROUP_MAX')}
     defaults['GROUPS'] = os.environ.get('W2L_WGRAD_GROUPS', E.WG.setting())
     defaults['DEFER'] = args.defer
     defaults['PROBE'] = ''            # what-if probes (wrong gradients, timing only): nowgrad = no weight-gradient launches (and no

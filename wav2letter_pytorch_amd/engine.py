@@ -337,7 +337,10 @@ def _side_stream(dev, main=None) -> 'torch.cuda.Stream':
 
 _wgroup_plans = {}                 # (convolutions of a backward pass, W2L_WGRAD_GROUPS) -> groups (wgrad_groups.plan)
 _wgroup_forms = {}                 # group signature -> measured block form of its launch, -1: one by one
-WGROUP_MAX = int(os.environ.get('W2L_WGRAD_GROUP_MAX', '8'))
+# (the largest group: measured in the step -- tools/step_ab.py, profiles/r05_step_ab.txt -- groups of up to 3 layers are worth -0.16 ms
+# on the headline step and -0.18 on Jasper 10x5, groups of 8 the same on the headline but +0.13 at N = 16: long-lived
+# full-chip launches keep the data gradients of the main stream waiting)
+WGROUP_MAX = int(os.environ.get('W2L_WGRAD_GROUP_MAX', '3'))
 _wgrad_ws = {}                     # device index -> workspace of the stream the weight gradients run on
 _retired_ws = []                   # outgrown workspaces (grown only while shapes are new, i.e. a handful of times)
 # W2L_DETERMINISTIC=1: split weight-gradient reductions go through slabs summed in a fixed order instead of fp32 atomics
@@ -1014,6 +1017,15 @@ class StackEngine:
                 pool_elems += 4 * acts[uc.out_index].CP
         small_pool = torch.zeros(pool_elems, dtype=torch.float32, device=dev)       # rows of absent residual branches stay 0
         pool_off = 0
+        # the two-launch BatchNorm-backward chain (FAST_BN_BWD): STAT_SLOTS zero rows per plain unit, ONE fill per step; the
+        # data gradients that form the sums in their epilogue (w2l_conv1d_dgrad_bnreduce_ws) add onto the same rows
+        # (w2l_conv_stats_mode: thread-local, this -- the autograd -- thread's launches)
+        self._slot_pool = None
+        if FAST_BN_BWD and batch_stats and not self.precise and dev.type == 'cuda':
+            need = sum(STAT_SLOTS * 2 * acts[uc.out_index].CP for uc in ctx['units'] if uc.unit.main.has_bn and uc.unit.res is None)
+            if need:
+                self._slot_pool = [torch.zeros(need, dtype=torch.float32, device=dev), 0, {}]
+        lib.w2l_conv_stats_mode(STAT_SLOTS if self._slot_pool is not None else 0)
         act_grads: List[List[tuple]] = [[] for _ in acts]
         if self.head is None:
             # open stack: the caller's gradient wrt the fp32 [N, C, T'] result becomes the (unpadded, fp32) gradient source
@@ -1047,6 +1059,8 @@ class StackEngine:
         self._held.clear()
         self._dyq.clear()
         self._zero_pool = None
+        self._slot_pool = None
+        lib.w2l_conv_stats_mode(0)
         _flush_tune_cache()
         if self.backward_done is not None:
             self.backward_done()
@@ -1105,11 +1119,7 @@ class StackEngine:
         st = stream_ptr
         amax_pool = (torch.zeros(len(acts) + 1, 2, AMAX_SLOTS, dtype=torch.float32, device=dev)        # one fill per step
                      if self.fp8 else None)
-        slot_pool = None               # zero rows the two-launch BatchNorm-backward chain adds its sums onto (one fill per step)
-        if FAST_BN_BWD and batch_stats and not precise and dev.type == 'cuda':
-            need = sum(STAT_SLOTS * 2 * acts[uc.out_index].CP for uc in ctx['units'] if uc.unit.main.has_bn and uc.unit.res is None)
-            if need:
-                slot_pool = [torch.zeros(need, dtype=torch.float32, device=dev), 0]
+        slot_pool = self._slot_pool    # zero rows the two-launch BatchNorm-backward chain adds its sums onto (backward())
         for uc in reversed(ctx['units']):
             u = uc.unit
             oi = uc.out_index
@@ -1132,8 +1142,12 @@ class StackEngine:
                 fast = False
                 if len(fused) == len(srcs) and ncomp == 2:
                     # every gradient source was a data-gradient convolution that formed the sums in its epilogue
+                    fused = list({id(t): t for t in fused}.values())      # (two consumers may have added onto ONE set of slot rows)
                     partial = fused[0] if len(fused) == 1 else torch.cat(fused, 0)
                     nb = partial.shape[0]
+                    # (on the step's slot rows: the dy pass with the finalize folded in takes them as they are)
+                    fast = bool(slot_pool is not None and len(fused) == 1 and slot_pool[2].get(id(uc)) is not None and g2 is None
+                                and lib.w2l_bn_bwd_fast_ok(C.byref(d), C.byref(g1), None))
                 elif (FAST_BN_BWD and batch_stats and not precise and g2 is None and ncomp == 2 and slot_pool is not None
                         and lib.w2l_bn_bwd_fast_ok(C.byref(d), C.byref(g1), None)):
                     # the two-launch chain: sums added onto STAT_SLOTS zero rows of the step's pool, finalize folded into the dy pass
@@ -1515,7 +1529,7 @@ class StackEngine:
             add(u.main, acts[u.src] if u.dw is None else uc.mid, uc.Tout, uc)
             if u.res is not None:
                 add(u.res, acts[u.res_src], uc.Tout, uc)
-        key = (tuple(seq), setting)
+        key = (tuple(seq), setting, WGROUP_MAX)
         groups = _wgroup_plans.get(key)
         if groups is None:
             groups = WG.parse_override(setting, len(seq))
@@ -1753,8 +1767,20 @@ class StackEngine:
         dev = dxp.device
         p = uc.unit.drop_p if (training and uc.mask is not None) else 0.0
         d = self._desc(uc, src.N, src.T, src.CP, p, uc.lens_out)
-        tiles = lib.w2l_conv_stat_tiles(1, flat_rows)
-        partial = torch.empty(tiles, 2, src.CP, dtype=torch.float32, device=dev)
+        pool = self._slot_pool
+        slots = pool is not None and uc.unit.res is None
+        if slots:                           # (w2l_conv_stats_mode(STAT_SLOTS) is in force: the epilogue ADDS onto these zero rows)
+            partial = pool[2].get(id(uc))   # a second consumer of the same activation (a residual branch) adds onto the same rows
+            if partial is None:
+                n = STAT_SLOTS * 2 * src.CP
+                partial = pool[0][pool[1]: pool[1] + n].view(STAT_SLOTS, 2, src.CP)
+                pool[1] += n
+                pool[2][id(uc)] = partial
+        else:
+            if pool is not None:
+                lib.w2l_conv_stats_mode(0)
+            tiles = lib.w2l_conv_stat_tiles(1, flat_rows)
+            partial = torch.empty(tiles, 2, src.CP, dtype=torch.float32, device=dev)
         row_off = halo - hb
         dy_ptr = C.c_void_p(dy_hi.data_ptr() + row_off * pk.coutp * 2)
         rows_total = total - row_off
@@ -1769,8 +1795,12 @@ class StackEngine:
                 _tune_state['dirty'] = True
                 check(lib.w2l_conv1d_dgrad_bnreduce_tune_ws(*args, TUNE_REPS, ptr(ws), ws.numel(), st),
                       'w2l_conv1d_dgrad_bnreduce_tune_ws')
+                if slots:
+                    partial.zero_()             # (the measuring launches ADDED to the rows)
         with _timed('conv_igemm_kernel/dgrad+bnreduce', flops):
             check(lib.w2l_conv1d_dgrad_bnreduce_ws(*args, ptr(ws), ws.numel(), st), 'w2l_conv1d_dgrad_bnreduce_ws')
+        if pool is not None and not slots:
+            lib.w2l_conv_stats_mode(STAT_SLOTS)
         return partial
 
     def _dgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, producer=None, amax=None):
