@@ -199,6 +199,22 @@ def _launcher():
     return mod
 
 
+def grad_byte_split(model, defer_k):
+    """fp32 gradient bytes of the conv weights whose gradient is held back for the next forward pass (optim.FusedSGD.defer_wgrad)
+    vs everything reduced inside the backward pass"""
+    try:
+        units = model.engine().units
+        spec = [int(v) for v in str(defer_k).split(',')] if ',' in str(defer_k) else int(defer_k)
+        n = len(units)
+        held = set(range(n - spec, n)) if isinstance(spec, int) else {(u if u >= 0 else n + u) for u in spec}
+        fwd = sum(c.weight.numel() * 4 for i, u in enumerate(units) if i in held for c in (u.main, u.res) if c is not None)
+        total = sum(p.numel() * 4 for p in model.parameters())
+        return {'total': total, 'reduced_beside_next_forward': fwd, 'reduced_in_backward': total - fwd,
+                'fraction_beside_next_forward': round(fwd / total, 4)}
+    except Exception as e:        # noqa: BLE001 -- a report field, never a reason to lose the record
+        return {'error': repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -605,10 +621,23 @@ def main():
                         achieved=f8['achieved'], frac=f8['frac'], launches_per_step=f8['launches_per_step'],
                         avg_launch_ms=f8['avg_launch_ms'], alg_gflop_per_launch=f8['alg_gflop_per_launch'])
             roof['bf16_launches'] = bf
-        if 'conv_wgrad_kernel' in agg:
-            fl2, tt2, cnt2 = agg['conv_wgrad_kernel']
+        if 'conv_wgrad_kernel' in agg or 'conv_wgrad3_kernel' in agg:
+            # bf16 weight gradients: the two kernel families side by side (conv_wgrad_kernel<..> = two taps per wave;
+            # w2l_wgrad3*_kernel = the three-tap code object with its accumulators in AGPRs), and their total.  A launch may
+            # cover a GROUP of layers (w2l_conv1d_wgrad_group): FLOPs of all its layers, one launch.
+            fam = {}
+            for key, label in (('conv_wgrad_kernel', 'two_tap_kernels'), ('conv_wgrad3_kernel', 'three_tap_agpr_kernels')):
+                if key in agg:
+                    f_, t_, c_ = agg[key]
+                    fam[label] = {'achieved': round(f_ / t_ / 1e12, 1), 'frac': round(f_ / t_ / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4),
+                                  'avg_launch_ms': round(t_ / c_ * 1e3, 4), 'launches_per_step': round(c_ / 3, 1),
+                                  'gflop_per_step': round(f_ / 3 / 1e9, 1)}
+            fl2 = sum(agg[k][0] for k in ('conv_wgrad_kernel', 'conv_wgrad3_kernel') if k in agg)
+            tt2 = sum(agg[k][1] for k in ('conv_wgrad_kernel', 'conv_wgrad3_kernel') if k in agg)
+            cnt2 = sum(agg[k][2] for k in ('conv_wgrad_kernel', 'conv_wgrad3_kernel') if k in agg)
             roof['wgrad_kernel'] = {'achieved': round(fl2 / tt2 / 1e12, 1), 'frac': round(fl2 / tt2 / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4),
-                                    'avg_launch_ms': round(tt2 / cnt2 * 1e3, 4), 'launches_per_step': cnt2 // 3}
+                                    'avg_launch_ms': round(tt2 / cnt2 * 1e3, 4), 'launches_per_step': round(cnt2 / 3, 1),
+                                    'by_kernel_family': fam}
             fl8, tt8, _ = agg.get('conv_igemm_fp8_kernel', (0.0, 0.0, 0))
             flw8, ttw8, cntw8 = agg.get('conv_wgrad_fp8_kernel', (0.0, 0.0, 0))
             if cntw8:
@@ -667,6 +696,9 @@ def main():
             # link's ~153 GB/s (point-to-point links: a ring is per-link bound) -- to read exposed_comm_ms against
             'expected_ring_ms': (None if world < 2 else round(
                 2.0 * (world - 1) / world * sum(p.numel() for p in model.parameters()) * 4 / 153e9 * 1e3, 3)),
+            # where the gradient bytes are reduced: the deferred units' weight gradients (and their all-reduces) run beside the
+            # NEXT forward pass, everything else inside the backward pass -- so a first multi-GPU curve explains itself
+            'grad_bytes': grad_byte_split(model, defer_k),
             'exposed_comm_ms_by_rank': exposed_by_rank,
             'tune_plans': (None if tune_shas is None else
                            {'shared_from_rank0': tune_path, 'sha16_by_rank': tune_shas, 'identical': len(set(tune_shas)) == 1}),

@@ -177,6 +177,8 @@ int w2l_conv1d_wgrad_tune_x(const void* dy, int64_t dy_bstride, const void* xp, 
                             void* ws, int64_t ws_bytes, int flags, void* stream);
 int w2l_wgrad_needs_zero_x(int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int64_t ws_bytes);
 int w2l_wgrad_dealt_segments(int tiles, int steps, int ranges, int* out, int max_blocks);
+/* the plan a launch of this problem will take (measured, or the cost model's): order bits | split / range count << 8 */
+int w2l_wgrad_plan(int N, int Cin, int Cout, int Tout, int Kw);
 
 /* A GROUP of layers' weight gradients in ONE launch (round 5): layers of the same N, Tout, stride 1 and dilation (any Cin,
  * Cout, Kw) whose [128 co x 128 ci] x tap-group tiles form one pool of equal-shaped work items -- layers whose own tile

@@ -254,6 +254,78 @@ def test_grad_reducer_gloo_world2():
         assert torch.equal(a, b)
 
 
+def _dp4_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from wav2letter_pytorch_amd.distributed import GradReducer, init_process_group_from_env
+    init_process_group_from_env(backend='gloo')
+    red = GradReducer(small_bytes=64)
+    out = []
+    for step in range(3):
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        # ---- "backward": the units top down; the top two units' weight gradients are held back (optim.FusedSGD.defer_wgrad),
+        # the others are reduced as they appear; rank 1 is late at every other launch, rank 3 at the flush of the small ones
+        held = [torch.randn(6, 5, 7, generator=g) for _ in range(2)]
+        body = [torch.randn(4, 6, 8, generator=g) for _ in range(5)]
+        smalls = [torch.randn(3 + i, generator=g) for i in range(4)]
+        pool = torch.randn(33, generator=g)
+        for i, t in enumerate(body):
+            if rank == 1 and i % 2 == 0:
+                time.sleep(0.05)
+            red.on_grad(None, t.permute(1, 2, 0), t)
+            red.on_grad(None, smalls[i % 4]) if i < 4 else None
+        red.on_flat(pool)
+        if rank == 3:
+            time.sleep(0.08)
+        red.finish()
+        # ---- "next forward": the held-back gradients are reduced one by one in forward order (engine.flush_deferred), each
+        # waited for before its update -- rank 2 arrives late, rank 0 is late between the two
+        if rank == 2:
+            time.sleep(0.06)
+        pend = []
+        for i, t in enumerate(reversed(held)):
+            pend.append(red.start(t))
+            if rank == 0 and i == 0:
+                time.sleep(0.04)
+        for p_ in pend:
+            p_.finish()
+        out.append([t.numpy().copy() for t in body + held + smalls + [pool]])
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_gloo_world4_deferred_and_delayed():
+    """four ranks, three steps of the data-parallel step's collective pattern with the deferral on -- large gradients as they
+    appear, small ones through the flattened bucket at the end of the backward pass, the per-channel pool, then the held-back
+    gradients one by one beside the 'next forward' -- while every rank is late somewhere else: nobody waits for a collective
+    another rank has not started in the same order (the run finishes), and every buffer holds the mean over the ranks"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp4_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for step in range(3):
+        gens = [torch.Generator().manual_seed(1000 * step + r) for r in range(4)]
+        exp = None
+        for g in gens:
+            held = [torch.randn(6, 5, 7, generator=g) for _ in range(2)]
+            body = [torch.randn(4, 6, 8, generator=g) for _ in range(5)]
+            smalls = [torch.randn(3 + i, generator=g) for i in range(4)]
+            pool = torch.randn(33, generator=g)
+            cur = body + held + smalls + [pool]
+            exp = cur if exp is None else [a + b for a, b in zip(exp, cur)]
+        for r in range(4):
+            for got, e in zip(res[r][step], exp):
+                assert np.allclose(got, (e / 4).numpy(), atol=1e-6)
+
+
 def test_novograd_matches_reference_fixture():
     """4 steps against tests/golden/novograd_cases.npz (generated from the reference's novograd.py)"""
     from wav2letter_pytorch_amd.novograd import Novograd

@@ -3,11 +3,15 @@
 # copied into profiles/ with the round prefix by hand -- delete the local gpurun_out/final first (gpurun MERGES: files of older
 # runs stay there): `rm -rf gpurun_out/final; gpurun ... bash tools/make_profiles.sh; for f in gpurun_out/final/*; do cp $f profiles/r03_$(basename $f); done`).
 # Stages are independent: a failing one leaves its file empty, the others still run.
+# Three stages (a gpurun call is limited to 20 minutes): `bash tools/make_profiles.sh headline`, `... kernels`, `... workloads`
+# (no argument: all three); each writes its own files under gpurun_out/final/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/final
-rm -rf $OUT && mkdir -p $OUT
-export W2L_TUNE_CACHE=$PWD/$OUT/tune_cache.txt   # the first run measures, the profiled runs reuse its choices
+mkdir -p $OUT
+STAGE=${1:-all}
+export W2L_TUNE_CACHE=$PWD/$OUT/tune_cache_$STAGE.txt   # the first run measures, the profiled runs reuse its choices
 last() { tail -1; }
+if [ "$STAGE" = headline ] || [ "$STAGE" = all ]; then
 # ---- headline (BASELINE config 2): bench line, rocprofv3 kernel statistics (overlapped = default, and serialised), PMC traffic
 python3 bench.py --steps 20 --warmup 5 2>/dev/null | last > $OUT/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_default -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/prof_default.log 2>&1
@@ -26,26 +30,35 @@ for spec in 0 6; do
   python3 tools/timeline.py $OUT/event_trace_defer$spec.csv --steps 4 --from 1 --gaps > $OUT/step_timeline_events_defer$spec.txt 2>&1
   rm -f $OUT/event_trace_defer$spec.csv
 done
-# same-box A/B of this round's two step-level changes: deferred weight gradients (0 vs 6 top units) and the three-tap AGPR
-# weight-gradient kernels (W2L_WGRAD_NO_TAPS3=1 keeps them out of the measured selection; separate tune caches)
-for rep in 1 2; do
-  for v in "0 1" "0 0" "6 1" "6 0"; do
-    set -- $v
-    W2L_TUNE_CACHE=$PWD/$OUT/tune_ab_$2.txt $( [ "$2" = 1 ] && echo env W2L_WGRAD_NO_TAPS3=1 ) python3 bench.py --no-cpu-baseline --no-live-traffic --defer-wgrad=$1 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('defer_wgrad=$1 no_taps3=$2 ms_per_step', d['ms_per_step'], 'wgrad TFLOP/s (serialised pass)', d['roofline']['wgrad_kernel']['achieved'])"
-  done
-done > $OUT/step_ab.txt 2>&1
-rm -f $OUT/tune_ab_0.txt $OUT/tune_ab_1.txt
+# same-box, same-process, interleaved A/B of this round's step-level switches (tools/step_ab.py): grouped weight gradients, the
+# two-launch BatchNorm-backward chain, where deferred launches go, the folded forward finalize, weight gradient after the data
+# gradient, round 4's configuration as a whole -- and the what-if probes (no weight gradients at all / no optimizer step)
+python3 tools/step_ab.py --rounds 6 --variants "base;nogroups=GROUPS:0;groups8=WGROUP_MAX:8;slowbn=FAST_BN_BWD:0;start=DEFER_SPREAD:start;foldfwd=FOLD_BN_FWD:1;late=WGRAD_AFTER_DGRAD:1;round4=GROUPS:0,FAST_BN_BWD:0,DEFER_SPREAD:start;base2" 2>/dev/null > $OUT/step_ab.txt
+python3 tools/step_ab.py --rounds 4 --variants "base;nowgrad=PROBE:nowgrad,DEFER:0;nosgd=PROBE:nosgd,DEFER:0;defer0=DEFER:0" 2>/dev/null >> $OUT/step_ab.txt
+python3 tools/step_ab.py --rounds 4 --batch 16 --variants "base;nogroups=GROUPS:0;groups8=WGROUP_MAX:8;slowbn=FAST_BN_BWD:0" 2>/dev/null >> $OUT/step_ab.txt
+python3 tools/step_ab.py --rounds 4 --model jasper10x5 --batch 16 --defer 4 --variants "base;nogroups=GROUPS:0;groups8=WGROUP_MAX:8;slowbn=FAST_BN_BWD:0;round4=GROUPS:0,FAST_BN_BWD:0,DEFER_SPREAD:start" 2>/dev/null >> $OUT/step_ab.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_bench_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
 python3 tools/prof_summary.py pmc $OUT/pmc_bench.json $OUT/pmc_bench_FETCH_SIZE $OUT/pmc_bench_WRITE_SIZE
 rm -rf $OUT/pmc_bench_FETCH_SIZE $OUT/pmc_bench_WRITE_SIZE $OUT/prof_default $OUT/prof_serial $OUT/prof_default.log $OUT/prof_serial.log
+fi
+if [ "$STAGE" = kernels ] || [ "$STAGE" = all ]; then
 # ---- one layer under the SQ / TCC counters (640 -> 640 k21)
 bash tools/pmc_conv.sh 11 > $OUT/pmc_layer11.txt 2>&1
 cp gpurun_out/pmc_11/summary.json $OUT/pmc_layer11.json
 # ---- per-layer conv kernels, Wav2Letter table shapes at N = 32 (config 2) and N = 16 (the shapes of Jasper 10x5, config 4)
 python3 tools/bench_conv.py --tune --fp8 > $OUT/conv_layers.txt 2>&1
 python3 tools/bench_conv.py --tune --n 16 > $OUT/conv_layers_n16.txt 2>&1
+# every weight-gradient plan class per layer (best split of each; + 32: its dealt stream-K form) -- the numbers DESIGN 3 quotes
+python3 tools/bench_conv.py --layers 5,6,7,8,9,10,11 --wgrad-plans --reps 20 --warm-s 1 > $OUT/wgrad_plans.txt 2>&1
+# grouped weight-gradient launches against the same layers one by one (tools/bench_wgrad_group.py), and the table's weight
+# gradients as the step would launch them with groups of at most three
+python3 tools/bench_wgrad_group.py --groups "12,11,10;9,8,7;15,14,13;13,12,11;6,5,4;3,2,1;18,17;18,17,16;9,8,7,6,5,4,3,2" > $OUT/wgrad_groups.txt 2>&1
+# the BatchNorm kernels alone: three-launch and two-launch backward chains, finalize + apply vs the folded forward kernel
+python3 tools/bench_elem.py > $OUT/bn_kernels.txt 2>&1
+fi
+if [ "$STAGE" = workloads ] || [ "$STAGE" = all ]; then
 # ---- the other workloads
 python3 bench.py --model jasper10x5 --batch 16 --steps 10 --warmup 4 2>/dev/null | last > $OUT/bench_jasper10x5.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_jasper -- python3 bench.py --model jasper10x5 --batch 16 --steps 8 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
@@ -66,4 +79,6 @@ W2L_STREAM_PROBE=0 python3 bench.py --force-dp --early-collective --steps 20 --w
 W2L_DP_NATIVE=1 python3 bench.py --force-dp --early-collective --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | last > $OUT/bench_force_dp_native_rccl.json
 python3 tools/stream_map.py 12 2>/dev/null > $OUT/stream_map.txt
 python3 tools/bench_features.py 2>/dev/null | last > $OUT/bench_features.txt
-cut -c1-1200 $OUT/bench.json
+python3 bench.py --ragged --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | last > $OUT/bench_ragged.json
+fi
+ls $OUT | head -80

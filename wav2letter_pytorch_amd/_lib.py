@@ -90,6 +90,7 @@ _SIGNATURES = {
     'w2l_conv1d_wgrad_tune_x': (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_i, c_p]),
     'w2l_wgrad_needs_zero_x': (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i64]),
     'w2l_wgrad_dealt_segments': (c_i, [c_i, c_i, c_i, c_p, c_i]),
+    'w2l_wgrad_plan': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'w2l_conv1d_wgrad_group': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'w2l_wgrad_group_tiles': (c_i, [c_i, c_i, c_i, c_i]),
     'w2l_conv1d_wgrad_tune': (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

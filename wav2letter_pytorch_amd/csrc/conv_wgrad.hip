@@ -188,6 +188,13 @@ extern "C" void w2l_wgrad_force_plan(int splits, int order) {
     g_force_order = order >= 0 ? (order & kOrderMask) : -1;
 }
 
+// the plan a launch of this problem will take: its order bits (see w2l_wgrad_force_plan) | split or range count << 8
+extern "C" int w2l_wgrad_plan(int N, int Cin, int Cout, int Tout, int Kw) {
+    int order = 0;
+    const int splits = plan_splits(N, Cin, Cout, Tout, Kw, nullptr, &order);
+    return (order & 0xff) | (splits << 8);
+}
+
 extern "C" int w2l_wgrad_needs_zero(int N, int Cin, int Cout, int Tout, int Kw) {
     int order = 0;
     const int splits = plan_splits(N, Cin, Cout, Tout, Kw, nullptr, &order);

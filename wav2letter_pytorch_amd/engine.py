@@ -1746,7 +1746,13 @@ class StackEngine:
                                                pk.cinp, pk.coutp, Tout, kw, conv.dilation, 1.0 / src.q_scale, ptr(f8[1]), 0, st),
                       'w2l_conv1d_wgrad_fp8')
         elif not self.precise:
-            with _timed('conv_wgrad_kernel', 2.0 * N * Tout * cout * cin * kw):
+            # (which kernel family: the three-tap AGPR code object -- plan order bit 4 on a stride-1, dilation <= 4 layer -- or the
+            # two-tap kernels; bench.py reports the two populations side by side)
+            label = 'conv_wgrad_kernel'
+            if KERNEL_TIMER is not None and conv.stride == 1 and conv.dilation <= 4 and kw >= 3 and \
+                    lib.w2l_wgrad_plan(N, pk.cinp, pk.coutp, Tout, kw) & 16:
+                label = 'conv_wgrad3_kernel'
+            with _timed(label, 2.0 * N * Tout * cout * cin * kw):
                 run(dy_hi, src.hi, 0)
         else:
             run(dy_hi, src.hi, 1)
