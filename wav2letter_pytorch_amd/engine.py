@@ -187,18 +187,35 @@ TUNE_REPS = int(os.environ.get('W2L_TUNE_REPS', '2'))      # timed launches per 
 # measured new shapes, so later processes (and the other DP ranks) skip the measuring launches.
 TUNE_CACHE = os.environ.get('W2L_TUNE_CACHE') or None
 _tune_state = {'dirty': False}
+_wgroup_plans = {}                 # (convolutions of a backward pass, W2L_WGRAD_GROUPS) -> groups (wgrad_groups.plan)
+_wgroup_forms = {}                 # group signature -> measured block form of its launch, -1: one by one
 
 
 def load_tune_cache(path: str) -> int:
     n = lib.w2l_tune_load(path.encode())
     if n < 0:
         check(1, 'w2l_tune_load')
+    # the step engine's own measured choices ride in the same file (lines the library skips): the block form of every
+    # grouped weight-gradient launch, -1 = its members one by one (StackEngine._wgrad_group_measure)
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if len(t) == 6 and t[0] == 'wgroup':
+                try:
+                    layers = tuple(tuple(int(v) for v in l.split(',')) for l in t[5].split(';'))
+                    _wgroup_forms[(layers, int(t[1]), int(t[2]), int(t[3]))] = int(t[4])
+                    n += 1
+                except ValueError:
+                    pass
     return n
 
 
 def save_tune_cache(path: str):
     tmp = '%s.tmp.%d' % (path, os.getpid())
     check(lib.w2l_tune_save(tmp.encode()), 'w2l_tune_save')
+    with open(tmp, 'a') as f:
+        for (layers, n, tout, dil), form in sorted(_wgroup_forms.items()):
+            f.write('wgroup %d %d %d %d %s\n' % (n, tout, dil, form, ';'.join(','.join(str(v) for v in l) for l in layers)))
     os.replace(tmp, path)
 
 
@@ -335,8 +352,6 @@ def _side_stream(dev, main=None) -> 'torch.cuda.Stream':
     return st
 
 
-_wgroup_plans = {}                 # (convolutions of a backward pass, W2L_WGRAD_GROUPS) -> groups (wgrad_groups.plan)
-_wgroup_forms = {}                 # group signature -> measured block form of its launch, -1: one by one
 # (the largest group: measured in the step -- tools/step_ab.py, profiles/r05_step_ab.txt -- groups of up to 3 layers are worth -0.16 ms
 # on the headline step and -0.18 on Jasper 10x5, groups of 8 the same on the headline but +0.13 at N = 16: long-lived
 # full-chip launches keep the data gradients of the main stream waiting)
@@ -349,7 +364,7 @@ DETERMINISTIC_WGRAD = os.environ.get('W2L_DETERMINISTIC', '0') == '1'
 # W2L_DEALT_WGRAD=0: no workspace for the weight gradients in the default mode, i.e. the dealt stream-K plans (include/w2l_hip.h)
 # are neither measured nor run (round 4's plan space; the A/B switch of profiles/r05_step_ab.txt)
 DEALT_WGRAD = os.environ.get('W2L_DEALT_WGRAD', '1') == '1'
-DEFER_SPREAD = os.environ.get('W2L_DEFER_SPREAD', 'even')      # StackEngine._defer_positions
+DEFER_SPREAD = os.environ.get('W2L_DEFER_SPREAD', 'start')      # StackEngine._defer_positions
 WGRAD_AFTER_DGRAD = os.environ.get('W2L_WGRAD_AFTER_DGRAD', '0') == '1'      # StackEngine._units_backward
 # W2L_FUSED_BN_REDUCE: the BatchNorm-backward reduction of a layer formed in the epilogue of the data-gradient convolution
 # that produces the gradient wrt its output (w2l_conv1d_dgrad_bnreduce_ws) instead of by w2l_bn_act_bwd_reduce: one kernel
@@ -1559,7 +1574,7 @@ class StackEngine:
         by one, if that measured faster for this group (decided once per group signature, during warm-up)"""
         dev = recs[0]['dy_hi'].device
         N, Tout, dil = recs[0]['src'].N, recs[0]['Tout'], recs[0]['conv'].dilation
-        key = (tuple((r['pk'].cinp, r['pk'].coutp, r['conv'].kernel) for r in recs), N, Tout, dil, dev.index)
+        key = (tuple((r['pk'].cinp, r['pk'].coutp, r['conv'].kernel) for r in recs), N, Tout, dil)
         form = _wgroup_forms.get(key)
         if form is None:
             form = self._wgrad_group_measure(recs, key) if AUTOTUNE and not torch.cuda.is_current_stream_capturing() else \

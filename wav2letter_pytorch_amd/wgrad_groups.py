@@ -39,18 +39,30 @@ def forms_for(dil: int) -> List[int]:
     return [f for f in FORMS if not (f & 16 and dil > THREE_TAP_MAX_DIL)]
 
 
+# one launch costs its own 12 us or so whatever it computes (a full round of 1 536 tap-tiles takes ~590 us: 0.38 us per unit), a
+# split launch a zero fill of dw on top, and its partial tiles (fp32 atomics) ~15 % of its time: what makes the narrow layers'
+# own plans (512 -> 512, k17: 908 TFLOP/s at split 3) lose to a shared launch.  (The model is deliberately pessimistic about
+# sparsely filled rounds: groups of the NARROWEST layers -- 384 / 256 wide -- win 30 % as launches and lose in the step, where
+# their long-lived blocks hold CUs the main stream's kernels wait for: measured, profiles/r05_step_ab.txt)
+LAUNCH_UNITS = 31.0
+FILL_UNITS = 26.0
+SPLIT_PENALTY = 1.15
+
+
 def launch_cost(layers: Sequence[Tuple[int, int, int]], form: int, splits: int = 1) -> float:
-    """cost of one launch in tap-tile units: whole rounds of the form's slots, a split's partial tiles priced at 8 %"""
+    """cost of one launch in tap-tile units: whole rounds of the form's slots + the launch itself (+ the zero fill and the
+    partial tiles of a split)"""
     kwblk, slots, speed = FORMS[form]
     n = sum(tiles(ci, co, kw, form) for ci, co, kw in layers) * splits
     rounds = -(-n // slots)
-    return rounds * slots * kwblk / splits / speed * (1.08 if splits > 1 else 1.0)
+    work = rounds * slots * kwblk / splits / speed
+    return work * (SPLIT_PENALTY if splits > 1 else 1.0) + LAUNCH_UNITS + (FILL_UNITS if splits > 1 else 0.0)
 
 
 def best_cost(layers: Sequence[Tuple[int, int, int]], dil: int, allow_split: bool) -> Tuple[float, int]:
     best = (float('inf'), 0)
     for f in forms_for(dil):
-        for s in ((1, 2, 3, 4, 6) if allow_split else (1,)):
+        for s in ((1, 2, 3, 4, 6, 8, 10) if allow_split else (1,)):
             c = launch_cost(layers, f, s)
             if c < best[0]:
                 best = (c, f)
