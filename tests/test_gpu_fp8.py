@@ -262,8 +262,10 @@ def _table_rows(norms, n):
                     for i in range(n))
 
 
-def test_w2l_full_table_fp8_gradients_vs_oracle():
-    """The 21-layer table in fp8 mode (e4m3 forward, data and weight gradients) at N=4 x T=1000, dropout on, the device's
+def test_w2l_full_table_fp8_gradients_vs_oracle(monkeypatch):
+    """(Run on the bit-reproducible statistics kernels -- W2L_FOLD_BN_FWD=0, W2L_FAST_BN_BWD=0 --: the bounds below were set
+    on them, and 20 chained e4m3 layers amplify the last-bit noise of atomically summed statistics past the 0.99 cosine.)
+    The 21-layer table in fp8 mode (e4m3 forward, data and weight gradients) at N=4 x T=1000, dropout on, the device's
     masks and gates replayed.  What can be asked of 20 chained e4m3 layers: a quantiser turns a perturbation d of its input
     into sqrt(d * ulp) of its output (a rounding decision flips with probability d / ulp), so two evaluations that differ by
     a bf16 rounding (2^-8) after the first layer differ by the full e4m3 noise (~2^-4) a few layers on -- the network is
@@ -278,6 +280,9 @@ def test_w2l_full_table_fp8_gradients_vs_oracle():
     noise.  (No absolute floor is asked of the 20-deep chain: the ABSOLUTE bound is per layer, teacher-forced --
     test_w2l_full_table_fp8_layerwise_vs_operand_model: every layer within 1.5e-2 / 0.03 / 0.999 of the model.)  The training
     signal as a whole is judged where it matters, on the loss curve: test_fp8_training_tracks_bf16."""
+    from wav2letter_pytorch_amd import engine as E_
+    monkeypatch.setattr(E_, 'FOLD_BN_FWD', '0')
+    monkeypatch.setattr(E_, 'FAST_BN_BWD', False)
     from gpu_helpers import device_dropout_masks, device_gates, device_step, l2_cos
     from oracle import w2l_oracle as O
     from wav2letter_pytorch_amd import engine as E

