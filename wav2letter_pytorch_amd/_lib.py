@@ -203,7 +203,7 @@ def require_device(*tensors):
 TRACE_NAMES = {
     'w2l_conv1d_igemm': 'conv_igemm_kernel', 'w2l_conv1d_igemm_ws': 'conv_igemm_kernel',
     'w2l_conv1d_dgrad_bnreduce_ws': 'conv_igemm_kernel/dgrad+bnreduce', 'w2l_conv1d_igemm_fp8': 'conv_igemm_fp8_kernel',
-    'w2l_conv1d_wgrad': 'conv_wgrad_kernel', 'w2l_conv1d_wgrad_ws': 'conv_wgrad_kernel', 'w2l_conv1d_wgrad_fp8': 'conv_wgrad_fp8_kernel',
+    'w2l_conv1d_wgrad': 'conv_wgrad_kernel', 'w2l_conv1d_wgrad_ws': 'conv_wgrad_kernel', 'w2l_conv1d_wgrad_group': 'conv_wgrad_kernel', 'w2l_conv1d_wgrad_fp8': 'conv_wgrad_fp8_kernel',
     'w2l_bn_finalize': 'bn_finalize_kernel', 'w2l_bn_act_fwd': 'bn_act_fwd_kernel', 'w2l_bn_act_fwd_q': 'bn_act_fwd_kernel',
     'w2l_bn_act_fwd_fin': 'bn_act_fwd_kernel', 'w2l_bn_act_bwd_reduce': 'bn_act_bwd_reduce_kernel',
     'w2l_bn_act_bwd_reduce_slots': 'bn_act_bwd_reduce_kernel', 'w2l_bn_act_bwd_apply_slots': 'bn_act_bwd_apply_kernel', 'w2l_bn_bwd_finalize': 'bn_bwd_finalize_kernel',
