@@ -228,7 +228,10 @@ struct FinBranch {
     float* shift;
 };
 
-constexpr int FWD_FIN_U = 4;                           // row groups (of 8 rows) per wave of bn_act_fwd_fin_kernel
+#ifndef W2L_FWD_FIN_U
+#define W2L_FWD_FIN_U 4
+#endif
+constexpr int FWD_FIN_U = W2L_FWD_FIN_U;               // row groups (of 8 rows) per wave of bn_act_fwd_fin_kernel
 __host__ __device__ inline int fwd_rows_per_block(int64_t rows, int C) {
     (void)rows; (void)C;
     return 4 * FWD_FIN_U * 8;                          // 4 waves x U groups x 8 rows: one batch of loads per wave
@@ -787,7 +790,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_fin_kernel(w2l_bnact_t d
 //   bn_bwd_apply_fast_kernel: every block re-reduces the S rows of its 64 channels (the finalize folded in; the blocks of
 //     row chunk 0 publish d beta / d gamma), then forms dy.
 // The separate finalize launch -- a 5 us kernel between two stream boundaries on the backward critical path -- is gone.
-constexpr int BWD_FAST_U = 4;                          // row groups (of 8 rows) per wave
+// Row groups (of 8 rows) per wave, measured (profiles/r05_bn_kernels.txt; C = 896: reduction 22.0 / 18.2 / 20.1 / 27.8 us and dy
+// pass 24.4 / 25.2 / 28.7 / 34.3 us at 1 / 2 / 4 / 8 groups): more rows per wave = more loads in flight per lane but fewer waves per
+// SIMD (their registers), and occupancy wins -- two groups for the reduction, one for the dy pass (two on the narrow layers).
 
 struct FastRow {
     u16x8 y, g, ga, gb;                                // conv output, gradient of the frame, of its reflected images (left / right halo)
@@ -838,6 +843,7 @@ __device__ __forceinline__ void fast_row_eval(const w2l_bnact_t& d, const FastRo
     }
 }
 
+template <int U>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(w2l_bnact_t d, w2l_gradsrc_t g1, float* partial, float inv_keep,
                                                                   int slots) {
     __shared__ float red[4][2][BWD_SLAB];
@@ -847,7 +853,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(w2l_bnact_t d, 
     const int cgl = lane & 7, rr = lane >> 3;
     const int cg = slab * (BWD_SLAB / 8) + cgl, c = cg * 8;
     const int64_t rows = (int64_t)d.N * d.T;
-    constexpr int U = BWD_FAST_U;
     const int64_t q0 = ((int64_t)chunk * 4 + wave) * (U * 8) + rr;
     FastRow r[U];
 #pragma unroll
@@ -884,6 +889,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(w2l_bnact_t d, 
     }
 }
 
+template <int U>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(w2l_bnact_t d, w2l_gradsrc_t g1, const float* partial, int nb,
                                                                  float* sums_out, bf16_raw* dy_hi, int h1, float inv_keep,
                                                                  float* amax) {
@@ -895,7 +901,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(w2l_bnact_t d, w
     const int cg = slab * (BWD_SLAB / 8) + cgl, c = cg * 8;
     const int T = d.T, N = d.N;
     const int64_t rows = (int64_t)N * T;
-    constexpr int U = BWD_FAST_U;
     const int64_t q0 = ((int64_t)chunk * 4 + wave) * (U * 8) + rr;
     FastRow r[U];
 #pragma unroll
@@ -1196,9 +1201,10 @@ extern "C" int w2l_bn_act_bwd_reduce_slots(const w2l_bnact_t* d, const w2l_grads
     W2L_CHECK_ARG(bwd_fast_ok(d, g1, nullptr), "bn_act_bwd_reduce_slots: bf16 y and gradient, one branch, one source, C %% 64 == 0 only");
     W2L_CHECK_ARG(g1->rows >= g1->pad_l + d->T + g1->pad_r, "bn_act_bwd_reduce_slots: gradient source has too few rows per utterance");
     const int64_t rows = (int64_t)d->N * d->T;
-    const int nchunks = (int)((rows + 4 * BWD_FAST_U * 8 - 1) / (4 * BWD_FAST_U * 8));
+    constexpr int U = 2;
+    const int nchunks = (int)((rows + 4 * U * 8 - 1) / (4 * U * 8));
     const float inv_keep = 1.f / (1.f - d->drop_p);
-    hipLaunchKernelGGL(bn_bwd_reduce_fast_kernel, dim3((unsigned)(nchunks * (d->C / BWD_SLAB))), dim3(256), 0, (hipStream_t)stream, *d,
+    hipLaunchKernelGGL(bn_bwd_reduce_fast_kernel<U>, dim3((unsigned)(nchunks * (d->C / BWD_SLAB))), dim3(256), 0, (hipStream_t)stream, *d,
                        *g1, partial, inv_keep, slots);
     W2L_CHECK_LAUNCH();
     return 0;
@@ -1212,10 +1218,15 @@ extern "C" int w2l_bn_act_bwd_apply_slots(const w2l_bnact_t* d, const w2l_gradsr
     W2L_CHECK_ARG(g1->rows >= g1->pad_l + d->T + g1->pad_r, "bn_act_bwd_apply_slots: gradient source has too few rows per utterance");
     const int64_t rows = (int64_t)d->N * d->T;
     W2L_CHECK_ARG((rows + (int64_t)halo * (d->N + 1)) * (d->C / 8) < (1LL << 31), "bn_act_bwd_apply_slots: tensor too large for 32-bit indexing");
-    const int nchunks = (int)((rows + 4 * BWD_FAST_U * 8 - 1) / (4 * BWD_FAST_U * 8));
+    const int U = d->C <= 384 ? 2 : 1;
+    const int nchunks = (int)((rows + 4 * U * 8 - 1) / (4 * U * 8));
     const float inv_keep = 1.f / (1.f - d->drop_p);
-    hipLaunchKernelGGL(bn_bwd_apply_fast_kernel, dim3((unsigned)(nchunks * (d->C / BWD_SLAB))), dim3(256), 0, (hipStream_t)stream, *d,
-                       *g1, partial, nrows, sums, (bf16_raw*)dy_hi, halo, inv_keep, amax);
+    if (U == 2)
+        hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<2>, dim3((unsigned)(nchunks * (d->C / BWD_SLAB))), dim3(256), 0, (hipStream_t)stream,
+                           *d, *g1, partial, nrows, sums, (bf16_raw*)dy_hi, halo, inv_keep, amax);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<1>, dim3((unsigned)(nchunks * (d->C / BWD_SLAB))), dim3(256), 0, (hipStream_t)stream,
+                           *d, *g1, partial, nrows, sums, (bf16_raw*)dy_hi, halo, inv_keep, amax);
     W2L_CHECK_LAUNCH();
     return 0;
 }
