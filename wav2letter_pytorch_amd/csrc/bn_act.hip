@@ -210,9 +210,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(w2l_bnact_t d, bf16_raw
 // channels (w2l_conv_stats_mode(S): the convolution's epilogue folds its per-tile sums onto S <= 64 rows with fp32 atomics --
 // 2 x S x 64 floats per block instead of 2 x 125 x C), derives mean / invstd / scale / shift exactly as bn_finalize_kernel
 // does, and the blocks of row chunk 0 publish them (the backward pass reads them) and update the running statistics.  Then
-// each wave walks its rows eight at a time, FOUR row groups per iteration with all their loads issued before the first use
-// (one load in flight per lane is what held the flat kernel at 3.4 TB/s).  bf16 y only (the fp32 parity mode keeps the
-// deterministic two-kernel path).
+// each wave walks its rows eight at a time in batches whose loads are all issued before the first use.  Measured
+// (profiles/r05_bn_kernels.txt, C = 896): 19.6-21 us whatever the batch size (1 / 2 / 4 row groups) and the blocks per launch
+// (1 280 / 2 560) -- 4.5 us more than the flat apply pass alone (15.1), i.e. the slab form runs at 2.9 instead of 3.8 TB/s; what
+// the fold saves is the finalize launch (6 us + a stream boundary).  bf16 y only (the fp32 parity mode keeps the deterministic
+// two-kernel path).
 struct FinBranch {
     const float* partial;      // [rows][2][C] sums / sums of squares; NULL: take scale / shift from the descriptor
     int rows;
@@ -229,12 +231,19 @@ struct FinBranch {
 };
 
 #ifndef W2L_FWD_FIN_U
-#define W2L_FWD_FIN_U 4
+#define W2L_FWD_FIN_U 1
 #endif
 constexpr int FWD_FIN_U = W2L_FWD_FIN_U;               // row groups (of 8 rows) per wave of bn_act_fwd_fin_kernel
+#ifndef W2L_FWD_FIN_BLOCKS
+#define W2L_FWD_FIN_BLOCKS 2560
+#endif
 __host__ __device__ inline int fwd_rows_per_block(int64_t rows, int C) {
-    (void)rows; (void)C;
-    return 4 * FWD_FIN_U * 8;                          // 4 waves x U groups x 8 rows: one batch of loads per wave
+    // batches of 4 waves x U groups x 8 rows; as many batches per block as leave ~W2L_FWD_FIN_BLOCKS blocks in the launch (one
+    // round of resident blocks: the prologue -- the statistics of the block's slab -- is paid once per block)
+    const int batch = 4 * FWD_FIN_U * 8;
+    int64_t nb = (rows * (C / BWD_SLAB) + (int64_t)batch * W2L_FWD_FIN_BLOCKS - 1) / ((int64_t)batch * W2L_FWD_FIN_BLOCKS);
+    nb = nb < 1 ? 1 : (nb > 16 ? 16 : nb);
+    return (int)nb * batch;
 }
 
 template <bool HAS2>
@@ -251,30 +260,34 @@ __global__ __launch_bounds__(256) void bn_act_fwd_fin_kernel(w2l_bnact_t d, FinB
     const int cg = slab * (BWD_SLAB / 8) + cgl, c = cg * 8;
     const int T = d.T;
     const int64_t rows = (int64_t)d.N * R;
-    constexpr int U = FWD_FIN_U;                       // row groups per wave: rpb = 4 waves x U x 8 rows, ONE batch per wave
-    const int64_t q0 = (int64_t)chunk * rpb + (int64_t)wave * (U * 8) + rr;
-    // ---- every load of the block's rows is issued FIRST: they do not depend on the statistics, and the prologue's own
-    // round trip (the partial rows, two barriers) hides behind them
+    constexpr int U = FWD_FIN_U;                       // row groups per batch: a wave walks rpb / 4 rows in batches of U x 8
+    const int nbatch = rpb / (4 * U * 8);
+    int64_t q0 = (int64_t)chunk * rpb + (int64_t)wave * (U * 8) + rr;        // (batch b of wave w: rows + b * 4 * U * 8)
+    // ---- every load of a batch is issued FIRST; the first batch's before the prologue: they do not depend on the statistics,
+    // and the prologue's own round trip (the partial rows, two barriers) hides behind them
     u16x8 ya[U], yb[U];
     int nn[U], tt[U], rw[U];
     bool ok[U];
+    auto load_batch = [&]() {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int64_t q = q0 + 8 * u;
-        ok[u] = false;
-        nn[u] = 0; tt[u] = 0; rw[u] = 0;
-        if (q < rows) {
-            const int n = (int)(q / R), r = (int)(q - (int64_t)n * R);
-            const int t = pad_src_row(r, T, pad_l, pad_r, pad_mode);
-            nn[u] = n; tt[u] = t; rw[u] = r;
-            ok[u] = t >= 0 && (!d.lens || t < d.lens[n]);
-            if (ok[u]) {
-                const int64_t src = ((int64_t)n * T + t) * d.C + c;
-                ya[u] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16_raw*>(d.y) + src);
-                if (HAS2) yb[u] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16_raw*>(d.y2) + src);
+        for (int u = 0; u < U; ++u) {
+            const int64_t q = q0 + 8 * u;
+            ok[u] = false;
+            nn[u] = 0; tt[u] = 0; rw[u] = 0;
+            if (q < rows) {
+                const int n = (int)(q / R), r = (int)(q - (int64_t)n * R);
+                const int t = pad_src_row(r, T, pad_l, pad_r, pad_mode);
+                nn[u] = n; tt[u] = t; rw[u] = r;
+                ok[u] = t >= 0 && (!d.lens || t < d.lens[n]);
+                if (ok[u]) {
+                    const int64_t src = ((int64_t)n * T + t) * d.C + c;
+                    ya[u] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16_raw*>(d.y) + src);
+                    if (HAS2) yb[u] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16_raw*>(d.y2) + src);
+                }
             }
         }
-    }
+    };
+    load_batch();
     // ---- prologue: this slab's statistics
     {
         const int cc = tid & 63, ch = slab * BWD_SLAB + cc;
@@ -336,6 +349,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_fin_kernel(w2l_bnact_t d, FinB
     const float q_limit = 448.f / q_scale;
     const bool drop = d.drop_p > 0.f;
     const uint64_t off = drop ? d.offset + (d.offset_dev ? *d.offset_dev : 0ull) : 0ull;
+    for (int bt = 0; bt < nbatch; ++bt) {
+    if (bt) load_batch();
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int64_t q = q0 + 8 * u;
@@ -368,6 +383,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_fin_kernel(w2l_bnact_t d, FinB
                 for (int j = 0; j < 8; ++j) clipped += fabsf(a[j]) > q_limit ? 1u : 0u;
             }
         }
+    }
+    q0 += 4 * U * 8;
     }
     if (out_q && d.q_clipped && __any(clipped != 0)) {
 #pragma unroll
