@@ -578,3 +578,45 @@ def test_dealt_stream_k_decomposition_covers_every_step_once(tiles, S, G):
     assert all(length[r] == W * (r + 1) // G - W * r // G for r in range(G))
     # no dealt form: more tiles than ranges, or fewer steps than ranges
     assert _lib.lib.w2l_wgrad_dealt_segments(G + 1, S, G, buf, 2 * G) == -1
+
+
+def test_wgrad_group_planner():
+    """wgrad_groups.plan (host arithmetic only): groups are consecutive among the groupable convolutions of the backward order,
+    share dilation and (N, T'), respect the size cap, never contain a non-groupable entry; the Wav2Letter table with its top
+    six units held back plans the partition that measured best in the step ({640 -> 768} with the classifier, {640 -> 640 x 2,
+    512 -> 640}, {512 -> 512 x 2, 384 -> 512}); tile counts agree with the library's; overrides parse"""
+    from wav2letter_pytorch_amd import _lib, wgrad_groups as G
+    sys.path.insert(0, ROOT)
+    from oracle.w2l_oracle import W2L_LAYERS
+    cins = [64] + [l[0] for l in W2L_LAYERS]
+    table = [(cins[i], l[0], l[1], l[2], l[3]) for i, l in enumerate(W2L_LAYERS)] + [(1024, 64, 1, 1, 1)]       # + the classifier
+    rows = list(range(len(table) - 1, -1, -1))                      # backward order: classifier, then the units top down
+
+    def seq_for(defer, N=32):
+        out = []
+        for r in rows:
+            cin, cout, kw, s, d = table[r]
+            held = r != len(table) - 1 and (len(table) - 2 - r) < defer
+            out.append(None if (s != 1 or held) else (cin, cout, kw, d, (N, 500)))
+        return out
+
+    for defer in (0, 4, 6):
+        for mx in (2, 3, 8):
+            seq = seq_for(defer)
+            groups = G.plan(seq, max_group=mx)
+            flat = [i for g in groups for i in g]
+            assert len(flat) == len(set(flat)) and all(2 <= len(g) <= mx for g in groups)
+            ok = [i for i, e in enumerate(seq) if e is not None]
+            for g in groups:
+                assert all(seq[i] is not None for i in g)
+                assert len({(seq[i][3], seq[i][4]) for i in g}) == 1
+                pos = [ok.index(i) for i in g]
+                assert pos == list(range(pos[0], pos[0] + len(g)))             # consecutive among the groupable entries
+    best = [[rows[i] for i in g] for g in G.plan(seq_for(6), max_group=3)]
+    assert best == [[20, 13], [12, 11, 10], [9, 8, 7]], best
+    for cin, cout, kw in [(640, 640, 21), (512, 640, 21), (896, 896, 29), (1024, 64, 1), (64, 256, 11)]:
+        for form in G.FORMS:
+            assert G.tiles(cin, cout, kw, form) == _lib.lib.w2l_wgrad_group_tiles(cin, cout, kw, form)
+    assert G.parse_override('auto', 10) is None and G.parse_override('0', 10) == [] and G.parse_override('off', 10) == []
+    assert G.parse_override('8,9,10;11,12', 21) == [[8, 9, 10], [11, 12]]
+    assert G.parse_override('3;4,99', 21) == []                        # singletons and out-of-range indices are dropped
