@@ -107,6 +107,13 @@ int w2l_conv1d_igemm_tune_ws(const void* xp, int64_t x_bstride, int64_t x_rows_t
                              const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout, int Kw, int stride,
                              int dil, int reps, void* splitk_ws, int64_t splitk_ws_bytes, void* stream);
 int64_t w2l_conv_splitk_workspace_bytes(int N, int Cout, int Tout);
+/* Stream-K configurations (indices 52 * 7 .. 52 * 8 - 1 of w2l_conv_force_tile_config; the tuner measures them beside the
+ * split-K ones wherever one block per tile fills the chip's last round badly): the launch is one block per resident slot,
+ * block r works on steps [W*r/G, W*(r+1)/G) of the tile-major (tile, step) space -- every block the same number of MFMA
+ * steps whatever the tile count -- and a tile cut by a range boundary is combined like a split-K tile (slabs summed in
+ * range order by the block that draws the tile's last ticket: deterministic).  Returns G for this problem and workspace,
+ * 0 where the launch would fall back to one block per tile. */
+int w2l_conv_streamk_ranges(int idx, int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int64_t ws_bytes);
 
 /* nn.Conv1d forward (wav2letter.py:35-36,42 / jasper.py:96-105) on OCP e4m3 operands -- BASELINE config 5 "fp8 MFMA":
  *   y[n][t][co] = descale * sum_{kw,ci} wq[kw][co][ci] * xq[n][t + kw*dil][ci] (+ bias[co]),

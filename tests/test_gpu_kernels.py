@@ -157,6 +157,64 @@ def test_conv_igemm_forward(L, case, precise):
 
 
 @pytest.mark.parametrize('with_stats', [True, False])
+def test_conv_igemm_stream_k(L, with_stats):
+    """the stream-K form of every block shape x both K-loop structures (split option 7: one block per resident slot, equal
+    shares of all (tile, step) pairs; tiles cut by a range boundary are combined through slabs in range order) on a problem
+    whose tiles are ragged in both dimensions: against the fp32 reference and against the one-block-per-tile launch of the
+    same shape, twice on the same workspace (bit-identical: the order is fixed; tickets back at zero), and on other data."""
+    N, Cin, Cout, T, Kw, d = 4, 512, 576, 620, 7, 2
+    pl = pr = (Kw - 1) * d // 2
+    x, w, b = conv_inputs(N, Cin, Cout, Kw, T, pl, pr, 12)
+    xp = to_ntc_padded(x, pl, pr, 1)
+    rows = xp.shape[1]
+    Tout = rows - (Kw - 1) * d
+    fh, _, _, _, coutp, cinp = pack(L, w, False)
+    xh = xp.to(torch.bfloat16).cuda()
+    bd = b.cuda()
+    ref = F.conv1d(F.pad(bf(x), (pl, pr), mode='reflect'), bf(w), b, dilation=d)
+    r1, r2 = ref.sum((0, 2)), (ref * ref).sum((0, 2))
+    tiles = L.lib.w2l_conv_stat_tiles(N, Tout)
+    ws = torch.zeros(int(L.lib.w2l_conv_splitk_workspace_bytes(N, coutp, Tout)), dtype=torch.uint8, device='cuda')
+
+    def run(idx, xin, bias, stats_on):
+        y = torch.full((N, Tout, coutp), float('nan'), dtype=torch.bfloat16, device='cuda')
+        stats = torch.zeros(tiles, 2, coutp, device='cuda')
+        L.lib.w2l_conv_force_tile_config(idx)
+        try:
+            rc = L.lib.w2l_conv1d_igemm_ws(L.ptr(xin), rows * cinp, N * rows, L.ptr(fh), L.ptr(y), 0, 0, bias,
+                                           L.ptr(stats) if stats_on else None, N, cinp, coutp, Tout, Kw, 1, d,
+                                           L.ptr(ws), ws.numel(), L.stream_ptr())
+        finally:
+            L.lib.w2l_conv_force_tile_config(-1)
+        torch.cuda.synchronize()
+        return rc, y, stats
+
+    ran = 0
+    for idx in range(52 * 7, 52 * 8):
+        if not L.lib.w2l_conv_streamk_ranges(idx, N, cinp, coutp, Tout, Kw, 1, d, ws.numel()):
+            continue
+        rc, y, stats = run(idx, xh, L.ptr(bd), with_stats)
+        if rc != 0:
+            continue                           # (statistics need 128-column tiles)
+        ran += 1
+        got = y.float().cpu().transpose(1, 2)
+        assert torch.isfinite(got).all(), idx
+        assert relerr(got, ref) < 1e-2, (idx, relerr(got, ref))
+        _, y1, _ = run(idx - 52 * 7, xh, L.ptr(bd), with_stats)           # one block per tile: the same sums, other fp32 order
+        assert (y.float() - y1.float()).abs().max() <= 2 ** -6 * ref.abs().max(), idx
+        if with_stats:
+            assert relerr(stats[:, 1].sum(0).cpu(), r2) < 2e-2, idx
+            assert (stats[:, 0].sum(0).cpu() - r1).abs().max() <= 5e-3 * r2.sqrt().max() * (N * Tout) ** 0.5, idx
+        _, yb, sb = run(idx, xh, L.ptr(bd), with_stats)
+        assert torch.equal(y, yb) and torch.equal(stats, sb), idx
+        assert not ws[:65536].any(), idx
+        _, ya, _ = run(idx, xh, None, False)
+        _, y2, _ = run(idx, xh * 2, None, False)
+        assert torch.equal(y2, ya * 2), idx
+    assert ran >= (10 if with_stats else 30), ran
+
+
+@pytest.mark.parametrize('with_stats', [True, False])
 def test_conv_igemm_every_configuration(L, with_stats):
     """every block shape x both K-loop structures x every split-K factor the autotuner may pick, on a problem with ragged
     edges in both tile dimensions (Cout = 320: 2.5 / 1.25 / 0.6 tiles; T = 300), stride 1 and the stride-2 shape.  Split

@@ -45,6 +45,11 @@ struct IgemmParams {
     int splits;
     float* slabs;             // [tiles][splits][BM*BN]
     unsigned* tickets;        // [tiles], zero between launches
+    // stream-K (SK kernels): the grid is sk_ranges blocks; block r owns steps [W*r/G, W*(r+1)/G) of the tile-major
+    // (tile, step) space, W = sk_total = tiles * steps per tile, and walks the tiles that range touches one after the other.
+    // A tile cut by range boundaries is combined exactly like a split-K tile (slab id = range + tile: unique, and the pieces
+    // of one tile are consecutive), a whole tile inside one range goes straight to the epilogue
+    int sk_ranges, sk_total;
     float descale;            // F8 kernels: y = acc * descale (+ bias), descale = 1 / (activation scale * weight scale)
     const float* descale_dev; // optional further factor in device memory (scale derived from a device-side amax)
     // EPI == 1 (data gradient fused with the BatchNorm-backward reduction of the layer that produced the conv's input):
@@ -85,8 +90,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base
 // F8: operands are OCP e4m3 bytes (x [.][rows][Cin], w [Kw][Cout][Cin], one byte per element): a 128-byte LDS row is 128
 // channels, a K step is one tap of a 128-channel chunk, and its MS x NS MFMAs are v_mfma_scale_f32_16x16x128_f8f6f4 (twice
 // the bf16 rate); LDS-DMA, swizzle, window reuse, split-K and the epilogue are the bf16 kernel's.  PIPE = 0 only.
-template <int MW, int NW, int MS, int NS, int S, int PIPE, bool F8 = false, int EPI = 0>
+template <int MW, int NW, int MS, int NS, int S, int PIPE, bool F8 = false, int EPI = 0, bool SK = false>
 __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams p) {
+    static_assert(!SK || (!F8 && EPI == 0 && S == 1), "stream-K is built for the plain bf16 stride-1 kernels");
     static_assert(!(F8 && PIPE != 0), "the e4m3 kernel is built for K-loop structure 0 only");
     static_assert(EPI == 0 || (!F8 && S == 1), "the fused BatchNorm-backward epilogue belongs to bf16 data gradients");
     constexpr int ESZ = F8 ? 1 : 2;                // bytes per operand element
@@ -101,8 +107,34 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
     // consecutive logical ids share an XCD (xcd_remap): the `splits` blocks of one tile run next to each other in time and
     // place, so their slabs meet in that XCD's L2
     const int lin = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = p.splits > 1 ? lin % p.splits : 0;
-    const int tile = p.splits > 1 ? lin / p.splits : lin;
+    // (consecutive ranges of a stream-K launch share tiles: the same remap keeps them on one XCD)
+    int w_cur = 0, w_end = 0;
+    if constexpr (SK) {
+        w_cur = (int)(((int64_t)p.sk_total * lin) / p.sk_ranges);
+        w_end = (int)(((int64_t)p.sk_total * (lin + 1)) / p.sk_ranges);
+    }
+    do {                                               // one pass per tile this block works on (exactly one unless SK)
+    int split, tile, nsplit, sk_begin = 0, sk_end = 0;
+    int64_t slab_base;
+    if constexpr (SK) {
+        __syncthreads();                               // the previous tile's LDS (ticket word, statistics scratch) is dead
+        const int S_ = (p.Cin / (ROWB / (F8 ? 1 : 2))) * p.Kw, G = p.sk_ranges, W = p.sk_total;
+        tile = w_cur / S_;
+        sk_begin = w_cur - tile * S_;
+        sk_end = sk_begin + (w_end - w_cur) < S_ ? sk_begin + (w_end - w_cur) : S_;
+        w_cur += sk_end - sk_begin;
+        // ranges holding the tile's first and last step: r(w) = ceil((w + 1) * G / W) - 1
+        const int r_lo = (int)((((int64_t)tile * S_ + 1) * G + W - 1) / W) - 1;
+        const int r_hi = (int)((((int64_t)tile * S_ + S_) * G + W - 1) / W) - 1;
+        nsplit = r_hi - r_lo + 1;
+        split = lin - r_lo;
+        slab_base = (int64_t)r_lo + tile;
+    } else {
+        nsplit = p.splits;
+        split = nsplit > 1 ? lin % nsplit : 0;
+        tile = nsplit > 1 ? lin / nsplit : lin;
+        slab_base = (int64_t)tile * nsplit;
+    }
     const int tm = tile / p.ncols;
     const int col = tile - tm * p.ncols;
     const int n = col / p.tiles_t;
@@ -166,8 +198,8 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
     const int nchunks = Cin / BKE;
     // this block's share of the nchunks * Kw (chunk-major) steps; a range may start in the middle of a chunk
     const int total_steps = nchunks * Kw;
-    const int s_begin = p.splits > 1 ? (int)(((int64_t)total_steps * split) / p.splits) : 0;
-    const int s_end = p.splits > 1 ? (int)(((int64_t)total_steps * (split + 1)) / p.splits) : total_steps;
+    const int s_begin = SK ? sk_begin : (nsplit > 1 ? (int)(((int64_t)total_steps * split) / nsplit) : 0);
+    const int s_end = SK ? sk_end : (nsplit > 1 ? (int)(((int64_t)total_steps * (split + 1)) / nsplit) : total_steps);
     const int nsteps = s_end - s_begin;
     const int c_first = s_begin / Kw, kw_first = s_begin - c_first * Kw;
 
@@ -335,8 +367,8 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
     // ---- split-K: publish the partial tile, draw a ticket; the last arriver sums all partials IN SPLIT ORDER (so the result
     // does not depend on which block arrived last) and goes on to the epilogue.  No block ever waits for another one.
     // (agent-scope release before the ticket, agent-scope acquire after it: correct for any placement of the blocks on XCDs)
-    if (p.splits > 1) {
-        float* slab = p.slabs + ((int64_t)tile * p.splits + split) * (BM * BN);
+    if (nsplit > 1) {
+        float* slab = p.slabs + (slab_base + split) * (BM * BN);
 #pragma unroll
         for (int mi = 0; mi < MS; ++mi)
 #pragma unroll
@@ -352,19 +384,19 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
         }
         __syncthreads();
         const unsigned ticket = *flag;
-        if (ticket != (unsigned)(p.splits - 1)) return;
+        if (ticket != (unsigned)(nsplit - 1)) continue;        // (not the last piece of this tile: on to the next tile, or out)
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(&p.tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
         }
         __syncthreads();
-        const float* base = p.slabs + (int64_t)tile * p.splits * (BM * BN);
+        const float* base = p.slabs + slab_base * (BM * BN);
 #pragma unroll
         for (int mi = 0; mi < MS; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NS; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < p.splits; ++sp) {
+        for (int sp = 0; sp < nsplit; ++sp) {
             const float* sl = base + (int64_t)sp * (BM * BN);
 #pragma unroll
             for (int mi = 0; mi < MS; ++mi)
@@ -550,6 +582,7 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
             }
         }
     }
+    } while (SK && w_cur < w_end);
 }
 
 struct TileCfg { int mw, nw, ms, ns; float eff; };
@@ -597,6 +630,13 @@ int launch_cfg1(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t strea
             return 1;
         }
     }
+    if (p.sk_ranges > 0) {
+        auto kern_sk = conv_igemm_kernel<MW, NW, MS, NS, 1, PIPE, false, 0, true>;
+        W2L_CHECK_HIP(w2l_allow_big_lds((const void*)kern_sk));
+        hipLaunchKernelGGL(kern_sk, dim3(p.sk_ranges), dim3(64 * MW * NW), lds, stream, p);
+        W2L_CHECK_LAUNCH();
+        return 0;
+    }
     auto kern = conv_igemm_kernel<MW, NW, MS, NS, 1, PIPE>;
     W2L_CHECK_HIP(w2l_allow_big_lds((const void*)kern));
     hipLaunchKernelGGL(kern, dim3(tiles_m * p.ncols), dim3(64 * MW * NW), lds, stream, p);
@@ -627,8 +667,11 @@ int launch_f8(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream)
 }  // namespace
 
 // A configuration index is (block shape) + kNumCfgs * (K-loop structure PIPE) + 2 * kNumCfgs * (split-K option).
-constexpr int kSplits[] = {1, 2, 3, 4, 5, 6, 8};
+// Split option 0 = stream-K (round 5): one block per resident slot, each an equal share of ALL the launch's (tile, step) pairs
+constexpr int kSplits[] = {1, 2, 3, 4, 5, 6, 8, 0};
 constexpr int kNumSplits = sizeof(kSplits) / sizeof(kSplits[0]);
+constexpr int kMaxSplit = 8;
+constexpr int kSkMinSteps = 8;                          // a stream-K range is at least this many steps
 constexpr int kBaseCfgs = 2 * kNumCfgs;
 constexpr size_t kTicketBytes = 64 * 1024;              // head of the split-K workspace: one counter per output tile
 // thread-local: the tuner (and the test hook below) force a configuration for launches made by the CALLING thread only --
@@ -705,6 +748,25 @@ static size_t splitk_bytes(int cfg_i, int splits, int N, int Cout, int Tout) {
     const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
     const size_t tiles = (size_t)((Cout + bm - 1) / bm) * N * ((Tout + bn - 1) / bn);
     return kTicketBytes + tiles * splits * bm * bn * sizeof(float);
+}
+
+// blocks of a stream-K launch of this shape: the slots the chip has for it (one or two blocks per CU)
+static int sk_ranges(const TileCfg& c, int stride, int Kw, int dil) {
+    const size_t lds = 2 * (size_t)(16 * c.mw * c.ms) * ROWB + 2 * (size_t)cfg_xrows(c, stride, Kw, dil) * ROWB;
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 8 / (c.mw * c.nw)) per_cu = 8 / (c.mw * c.nw);          // (eight waves per CU: what two 4-wave blocks hold)
+    return 256 * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+}
+
+static bool sk_feasible(int cfg_i, int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, const void* ws, int64_t ws_bytes) {
+    if (ws == nullptr || stride != 1) return false;
+    const TileCfg& c = kCfgs[cfg_i];
+    const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
+    const int64_t tiles = (int64_t)((Cout + bm - 1) / bm) * N * ((Tout + bn - 1) / bn);
+    const int64_t steps = (int64_t)(Cin / BK) * Kw, G = sk_ranges(c, stride, Kw, dil);
+    if (tiles * steps / G < kSkMinSteps || (tiles * steps + steps) * G >= (1LL << 31)) return false;
+    return tiles * (int64_t)sizeof(unsigned) <= (int64_t)kTicketBytes &&
+           (int64_t)kTicketBytes + (tiles + G) * bm * bn * (int64_t)sizeof(float) <= ws_bytes;
 }
 
 static bool split_feasible(int cfg_i, int splits, int N, int Cin, int Cout, int Tout, int Kw, const void* ws, int64_t ws_bytes) {
@@ -797,6 +859,15 @@ static int igemm_launch(const void* xp, int64_t x_bstride, int64_t x_rows_total,
     p.xrows_lds = cfg_xrows(c, stride, Kw, dil);
     // a split-K choice (measured with a workspace) silently degrades to one block per tile when the caller brings none
     int splits = kSplits[ci / kBaseCfgs];
+    p.sk_ranges = 0;
+    p.sk_total = 0;
+    if (splits == 0) {                                   // stream-K (never with the fused epilogue: cfg_feasible)
+        if (epi == 0 && sk_feasible(ci % kNumCfgs, N, Cin, Cout, Tout, Kw, stride, dil, splitk_ws, splitk_ws_bytes)) {
+            p.sk_ranges = sk_ranges(c, stride, Kw, dil);
+            p.sk_total = ((Cout + bm - 1) / bm) * p.ncols * ((Cin / BK) * Kw);
+        }
+        splits = 1;
+    }
     if (!split_feasible(ci % kNumCfgs, splits, N, Cin, Cout, Tout, Kw, splitk_ws, splitk_ws_bytes)) splits = 1;
     p.splits = splits;
     p.tickets = (unsigned*)splitk_ws;
@@ -851,10 +922,19 @@ extern "C" int w2l_conv1d_igemm(const void* xp, int64_t x_bstride, int64_t x_row
                                Kw, stride, dil, nullptr, 0, stream);
 }
 
+// blocks of the stream-K launch configuration idx would make of this problem with a workspace of ws_bytes; 0: the launch
+// falls back to one block per tile (no stream-K form of that configuration, ranges too short, workspace too small)
+extern "C" int w2l_conv_streamk_ranges(int idx, int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int64_t ws_bytes) {
+    if (!cfg_feasible(idx, Kw, stride, dil, false) || kSplits[idx / kBaseCfgs] != 0) return 0;
+    static const char dummy = 0;
+    if (!sk_feasible(idx % kNumCfgs, N, Cin, Cout, Tout, Kw, stride, dil, &dummy, ws_bytes)) return 0;
+    return sk_ranges(kCfgs[idx % kNumCfgs], stride, Kw, dil);
+}
+
 extern "C" int64_t w2l_conv_splitk_workspace_bytes(int N, int Cout, int Tout) {
     size_t need = 0;
     for (int i = 0; i < kNumCfgs; ++i) {
-        const size_t b = splitk_bytes(i, kSplits[kNumSplits - 1], N, Cout, Tout);
+        const size_t b = splitk_bytes(i, kMaxSplit, N, Cout, Tout);
         if (b > need) need = b;
     }
     return (int64_t)need;
@@ -900,7 +980,16 @@ extern "C" int w2l_conv1d_igemm_tune_ws(const void* xp, int64_t x_bstride, int64
     for (int i = 0; i < kBaseCfgs * kNumSplits; ++i) {
         if (!cfg_feasible(i, Kw, stride, dil, need128)) continue;
         const int ci = i % kNumCfgs, splits = kSplits[i / kBaseCfgs];
-        if (splits > 1) {
+        if (splits == 0) {
+            // stream-K where one block per tile fills the chip's last round badly (and never under the fused epilogue)
+            if (g_tune_bb != nullptr || !sk_feasible(ci, N, Cin, Cout, Tout, Kw, stride, dil, splitk_ws, splitk_ws_bytes)) continue;
+            const TileCfg& c = kCfgs[ci];
+            const int bm = 16 * c.mw * c.ms, bn = 16 * c.nw * c.ns;
+            const long slots = sk_ranges(c, stride, Kw, dil);
+            const long blocks = (long)((Cout + bm - 1) / bm) * N * ((Tout + bn - 1) / bn);
+            const double util = (double)blocks / (double)(((blocks + slots - 1) / slots) * slots);
+            if (util > 0.92 || blocks > 4 * slots) continue;
+        } else if (splits > 1) {
             // split-K is only a candidate where one block per tile leaves CUs idle (a partly filled last round, or fewer
             // tiles than CUs) and where it does not flood the chip with short blocks
             if (!split_feasible(ci, splits, N, Cin, Cout, Tout, Kw, splitk_ws, splitk_ws_bytes)) continue;
@@ -1025,6 +1114,7 @@ extern "C" int w2l_conv1d_igemm_fp8(const void* xq, int64_t x_bstride, int64_t x
     p.N = N; p.Cin = Cin; p.Cout = Cout; p.Tout = Tout; p.Kw = Kw; p.stride = 1; p.dil = dil;
     p.y_f32 = y_f32; p.accumulate = 0;
     p.splits = 1; p.slabs = nullptr; p.tickets = nullptr;
+    p.sk_ranges = 0; p.sk_total = 0;
     p.descale = descale;
     p.descale_dev = descale_dev;
     const int64_t need = (int64_t)(N - 1) * p.x_rows_per_utt + (int64_t)(Tout - 1) + (int64_t)(Kw - 1) * dil;
