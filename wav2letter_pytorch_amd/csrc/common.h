@@ -7,6 +7,10 @@
 #include <stdio.h>
 #include <stdarg.h>
 
+// measure-and-pick (the _tune entry points): the first pass ranks every candidate on `reps` launches, then the kFinalists fastest
+// are timed again, interleaved, kFinalRounds x 4 reps launches each (round 5: 5 x 3 x 4 reps instead of 3 x 2 x 2 reps -- the first pass's ranking
+// moves by more than the best candidates differ, and a mis-pick costs the step 0.5-1 % per layer)
+constexpr int kFinalists = 5, kFinalRounds = 3;
 typedef unsigned short bf16_raw;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

@@ -1007,15 +1007,15 @@ extern "C" int w2l_conv1d_igemm_tune_ws(const void* xp, int64_t x_bstride, int64
         if (ms >= 0.f) timed.emplace_back(ms, i);
     }
     // the first pass ranks ~50 candidates on `reps` launches each -- the clock the chip holds drifts over such a sweep by more
-    // than the best candidates differ --, so the three fastest are timed again, interleaved, on twice the launches
+    // than the best candidates differ --, so the kFinalists fastest are timed again, interleaved (common.h)
     std::sort(timed.begin(), timed.end());
     int best = timed.empty() ? -1 : timed[0].second;
-    const int finalists = timed.size() < 3 ? (int)timed.size() : 3;
+    const int finalists = timed.size() < kFinalists ? (int)timed.size() : kFinalists;
     if (finalists > 1) {
-        float total[3] = {0.f, 0.f, 0.f};
-        for (int round = 0; round < 2; ++round)
+        float total[kFinalists] = {};
+        for (int round = 0; round < kFinalRounds; ++round)
             for (int k = 0; k < finalists; ++k) {
-                const float ms = time_cfg(timed[k].second, 2 * reps);
+                const float ms = time_cfg(timed[k].second, 4 * reps);
                 total[k] += ms >= 0.f ? ms : 1e30f;
             }
         int kb = 0;

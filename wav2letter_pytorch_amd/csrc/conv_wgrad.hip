@@ -549,6 +549,12 @@ extern "C" int w2l_conv1d_wgrad_tune_x(const void* dy, int64_t dy_bstride, const
         if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.f;
+        // Plans that ADD their partial tiles with fp32 atomics are priced above their stand-alone time: back to back, the next
+        // launch's zero fill runs under this launch's tail (in the step it is one more dependent launch in front of its kernel:
+        // 8-9 us), and beside the data gradients of the step the atomics themselves run slower than alone -- 768 -> 896 at split 3
+        // measured level with the unsplit six-tap form alone (picked in two of five selections) and cost the step +0.09 ms = 17 %
+        // of that layer (tools/probe/plan_cmp.sh).  The narrow layers' split plans win by 30-100 % and are not affected.
+        if (zero) ms = ms * 1.08f + 0.008f * n;
         return ms;
     };
     std::vector<std::pair<float, int>> timed;                 // (ms, split count | order << 16)
@@ -589,16 +595,16 @@ extern "C" int w2l_conv1d_wgrad_tune_x(const void* dy, int64_t dy_bstride, const
                 }
         }
     }
-    // (the first pass ranks ~100 plans on `reps` launches each while the chip's clock drifts: the three fastest are timed again,
-    // interleaved, on twice the launches)
+    // (the first pass ranks ~100 plans on `reps` launches each while the chip's clock drifts: the kFinalists fastest are timed again,
+    // interleaved: common.h)
     std::sort(timed.begin(), timed.end());
     int best = timed.empty() ? -1 : timed[0].second;
-    const int finalists = timed.size() < 3 ? (int)timed.size() : 3;
+    const int finalists = timed.size() < kFinalists ? (int)timed.size() : kFinalists;
     if (finalists > 1) {
-        float total_ms[3] = {0.f, 0.f, 0.f};
-        for (int round = 0; round < 2; ++round)
+        float total_ms[kFinalists] = {};
+        for (int round = 0; round < kFinalRounds; ++round)
             for (int k = 0; k < finalists; ++k) {
-                const float ms = time_plan(timed[k].second & 0xffff, timed[k].second >> 16, 2 * reps);
+                const float ms = time_plan(timed[k].second & 0xffff, timed[k].second >> 16, 4 * reps);
                 total_ms[k] += ms >= 0.f ? ms : 1e30f;
             }
         int kb = 0;
