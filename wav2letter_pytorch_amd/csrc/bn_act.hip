@@ -139,6 +139,15 @@ __device__ __forceinline__ bool act_pass(float z, int act) {
 // device-side amax of dy (fp8 mode): W2L_AMAX_SLOTS partial maxima per tensor, the slot picked by the block index -- one
 // word for a whole launch serialises 16 000 atomics at one L2 address (measured: the dy kernel 33 -> 171 us)
 constexpr int AMAX_SLOTS = W2L_AMAX_SLOTS;
+// a wave's maximum onto its slot: same-address device-scope atomics run one after the other at ~0.1 us each (the dy pass of a
+// wide unit with one row group per wave makes 28 000 of them: +53 us per unit, measured as +1.07 ms per fp8 step), so a wave
+// first LOOKS (one device-coherent load: parallel, never stale in the unsafe direction -- the slot only grows) and adds its
+// atomic only if it would raise the slot: after the first few waves of a slot nearly none does
+__device__ __forceinline__ void amax_publish(float* amax, int slot, float mx) {
+    unsigned* p = reinterpret_cast<unsigned*>(amax) + slot;
+    const unsigned v = __float_as_uint(mx);
+    if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, v);
+}
 constexpr int BWD_SLAB = 64;             // channels per wave of the slab-form kernels (one 128-byte line per row)
 
 // 8 floats -> 8 OCP e4m3 bytes (round to nearest even, saturating at +-448), v * scale
@@ -642,8 +651,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(w2l_bnact_t d, w2
         }
         if ((threadIdx.x & 63) == 0) {
             const int slot = blockIdx.x & (AMAX_SLOTS - 1);
-            atomicMax(reinterpret_cast<unsigned*>(amax) + slot, __float_as_uint(mx1));
-            if (HAS2 && dy2_hi) atomicMax(reinterpret_cast<unsigned*>(amax) + AMAX_SLOTS + slot, __float_as_uint(mx2));
+            amax_publish(amax, slot, mx1);
+            if (HAS2 && dy2_hi) amax_publish(amax, AMAX_SLOTS + slot, mx2);
         }
     }
 }
@@ -792,8 +801,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_fin_kernel(w2l_bnact_t d
         }
         if (lane == 0) {
             const int slot = blockIdx.x & (AMAX_SLOTS - 1);
-            atomicMax(reinterpret_cast<unsigned*>(amax) + slot, __float_as_uint(mx1));
-            if (HAS2 && dy2_hi) atomicMax(reinterpret_cast<unsigned*>(amax) + AMAX_SLOTS + slot, __float_as_uint(mx2));
+            amax_publish(amax, slot, mx1);
+            if (HAS2 && dy2_hi) amax_publish(amax, AMAX_SLOTS + slot, mx2);
         }
     }
 }
@@ -911,6 +920,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(w2l_bnact_t d, w
                                                                  float* sums_out, bf16_raw* dy_hi, int h1, float inv_keep,
                                                                  float* amax) {
     __shared__ float ssum[2][BWD_SLAB];
+    __shared__ float smax[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = d.C >> 3, nslabs = d.C / BWD_SLAB;
     const int slab = blockIdx.x % nslabs, chunk = blockIdx.x / nslabs;
@@ -981,7 +991,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(w2l_bnact_t d, w
     if (amax) {
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(amax) + (blockIdx.x & (AMAX_SLOTS - 1)), __float_as_uint(mx));
+        if (lane == 0) smax[wave] = mx;
+        __syncthreads();                               // (amax is a kernel argument: uniform)
+        if (tid == 0) amax_publish(amax, blockIdx.x & (AMAX_SLOTS - 1), fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
     }
 }
 
@@ -1235,10 +1247,15 @@ extern "C" int w2l_bn_act_bwd_apply_slots(const w2l_bnact_t* d, const w2l_gradsr
     W2L_CHECK_ARG(g1->rows >= g1->pad_l + d->T + g1->pad_r, "bn_act_bwd_apply_slots: gradient source has too few rows per utterance");
     const int64_t rows = (int64_t)d->N * d->T;
     W2L_CHECK_ARG((rows + (int64_t)halo * (d->N + 1)) * (d->C / 8) < (1LL << 31), "bn_act_bwd_apply_slots: tensor too large for 32-bit indexing");
-    const int U = d->C <= 384 ? 2 : 1;
+    // (fp8 mode, amax: four groups -- a block ends in an atomic on one of W2L_AMAX_SLOTS words, and same-address atomics take
+    // ~0.1 us each one after the other: the fewer blocks the better; measured 9.0 against 10.1 ms per fp8 step)
+    const int U = amax ? 4 : (d->C <= 384 ? 2 : 1);
     const int nchunks = (int)((rows + 4 * U * 8 - 1) / (4 * U * 8));
     const float inv_keep = 1.f / (1.f - d->drop_p);
-    if (U == 2)
+    if (U == 4)
+        hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<4>, dim3((unsigned)(nchunks * (d->C / BWD_SLAB))), dim3(256), 0, (hipStream_t)stream,
+                           *d, *g1, partial, nrows, sums, (bf16_raw*)dy_hi, halo, inv_keep, amax);
+    else if (U == 2)
         hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<2>, dim3((unsigned)(nchunks * (d->C / BWD_SLAB))), dim3(256), 0, (hipStream_t)stream,
                            *d, *g1, partial, nrows, sums, (bf16_raw*)dy_hi, halo, inv_keep, amax);
     else
