@@ -62,9 +62,10 @@ def main():
         t_z = timeit(lambda: L.check(L.lib.w2l_bn_bwd_finalize(L.ptr(partial), nb, Cn, 2, L.ptr(sums), st)))
         t_a = timeit(lambda: L.check(L.lib.w2l_bn_act_bwd_apply(C.byref(d), C.byref(gs), None, L.ptr(sums), L.ptr(dy), None, h,
                                                                 None, None, 0, st)))
-        slots = torch.zeros(8, 2, Cn, device='cuda')
-        t_r2 = timeit(lambda: L.check(L.lib.w2l_bn_act_bwd_reduce_slots(C.byref(d), C.byref(gs), L.ptr(slots), 8, st)))
-        t_a2 = timeit(lambda: L.check(L.lib.w2l_bn_act_bwd_apply_slots(C.byref(d), C.byref(gs), L.ptr(slots), 8, L.ptr(sums), L.ptr(dy), h,
+        NS = int(os.environ.get('SLOTS', '8'))
+        slots = torch.zeros(NS, 2, Cn, device='cuda')
+        t_r2 = timeit(lambda: L.check(L.lib.w2l_bn_act_bwd_reduce_slots(C.byref(d), C.byref(gs), L.ptr(slots), NS, st)))
+        t_a2 = timeit(lambda: L.check(L.lib.w2l_bn_act_bwd_apply_slots(C.byref(d), C.byref(gs), L.ptr(slots), NS, L.ptr(sums), L.ptr(dy), h,
                                                                        None, st)))
         el = N * T * Cn
         print(f'C={Cn:5d}: bwd two-launch chain: reduce {t_r2:5.1f} us ({el * 4 / t_r2 / 1e6:5.2f} TB/s) + apply {t_a2:5.1f} us '
