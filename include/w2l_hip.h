@@ -114,6 +114,10 @@ int64_t w2l_conv_splitk_workspace_bytes(int N, int Cout, int Tout);
  * range order by the block that draws the tile's last ticket: deterministic).  Returns G for this problem and workspace,
  * 0 where the launch would fall back to one block per tile. */
 int w2l_conv_streamk_ranges(int idx, int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int64_t ws_bytes);
+/* the decomposition itself, run on the host by the same function the kernel runs: the pieces of `tiles` x `steps` over G
+ * ranges in range order, out[7 * i] = range, tile, first step, end step, ranges sharing the tile, place among them, slab id
+ * (-1: whole tile, no slab); returns the piece count or -1 (cap too small / sizes beyond the kernel's 32-bit arithmetic) */
+int w2l_conv_streamk_pieces(int tiles, int steps, int G, int* out, int cap);
 
 /* nn.Conv1d forward (wav2letter.py:35-36,42 / jasper.py:96-105) on OCP e4m3 operands -- BASELINE config 5 "fp8 MFMA":
  *   y[n][t][co] = descale * sum_{kw,ci} wq[kw][co][ci] * xq[n][t + kw*dil][ci] (+ bias[co]),

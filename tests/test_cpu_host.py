@@ -620,3 +620,41 @@ def test_wgrad_group_planner():
     assert G.parse_override('auto', 10) is None and G.parse_override('0', 10) == [] and G.parse_override('off', 10) == []
     assert G.parse_override('8,9,10;11,12', 21) == [[8, 9, 10], [11, 12]]
     assert G.parse_override('3;4,99', 21) == []                        # singletons and out-of-range indices are dropped
+
+
+@pytest.mark.parametrize('tiles,steps,G', [(140, 210, 256), (329, 406, 256), (60, 56, 512), (1, 300, 256), (700, 9, 256), (255, 257, 256)])
+def test_igemm_stream_k_pieces_cover_every_step_once(tiles, steps, G):
+    """w2l_conv_streamk_pieces runs the function the stream-K implicit GEMM runs per block (sk_piece, host + device): every
+    (tile, step) belongs to exactly one piece; the pieces of a cut tile are numbered 0..n-1 in step order with consecutive slab
+    ids, unique over the launch and below tiles + G (the workspace the launcher checks); whole tiles take no slab; every range
+    owns floor(W (r+1) / G) - floor(W r / G) steps."""
+    import numpy as np
+    from wav2letter_pytorch_amd import _lib
+    cap = tiles + 2 * G + 8
+    buf = np.zeros(7 * cap, dtype=np.int32)
+    n = _lib.lib.w2l_conv_streamk_pieces(tiles, steps, G, buf.ctypes.data, cap)
+    assert n > 0
+    pc = buf[:7 * n].reshape(n, 7)
+    W = tiles * steps
+    cover = np.zeros((tiles, steps), dtype=np.int32)
+    per_range = np.zeros(G, dtype=np.int64)
+    for r, t, b, e, ns, sp, slab in pc:
+        assert 0 <= t < tiles and 0 <= b < e <= steps and 0 <= sp < ns
+        cover[t, b:e] += 1
+        per_range[r] += e - b
+        assert (slab == -1) == (ns == 1)
+    assert (cover == 1).all()
+    assert (per_range == [W * (r + 1) // G - W * r // G for r in range(G)]).all()
+    assert (np.diff(pc[:, 0]) >= 0).all()                       # range order
+    slabs = pc[pc[:, 6] >= 0, 6]
+    assert len(set(slabs.tolist())) == len(slabs) and (slabs < tiles + G).all()
+    for t in range(tiles):
+        mine = pc[pc[:, 1] == t]
+        mine = mine[np.argsort(mine[:, 2])]
+        assert (mine[:, 4] == len(mine)).all() and (mine[:, 5] == np.arange(len(mine))).all()
+        assert mine[0, 2] == 0 and mine[-1, 3] == steps and (mine[1:, 2] == mine[:-1, 3]).all()
+        if len(mine) > 1:
+            assert (np.diff(mine[:, 6]) == 1).all()
+    assert _lib.lib.w2l_conv_streamk_pieces(tiles, steps, G, buf.ctypes.data, 1) == (-1 if n > 1 else 1)
+    assert _lib.lib.w2l_conv_streamk_pieces(1 << 20, 4096, 512, buf.ctypes.data, cap) == -1
+

@@ -78,6 +78,7 @@ _SIGNATURES = {
                                        c_i64, c_p]),
     'w2l_conv_splitk_workspace_bytes': (c_i64, [c_i, c_i, c_i]),
     'w2l_conv_streamk_ranges': (c_i, [c_i] * 8 + [c_i64]),
+    'w2l_conv_streamk_pieces': (c_i, [c_i, c_i, c_i, c_p, c_i]),
     'w2l_conv_force_tile_config': (None, [c_i]),
     'w2l_conv_force_fp8_config': (None, [c_i]),
     'w2l_wgrad_force_plan': (None, [c_i, c_i]),

@@ -90,6 +90,24 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base
 // F8: operands are OCP e4m3 bytes (x [.][rows][Cin], w [Kw][Cout][Cin], one byte per element): a 128-byte LDS row is 128
 // channels, a K step is one tap of a 128-channel chunk, and its MS x NS MFMAs are v_mfma_scale_f32_16x16x128_f8f6f4 (twice
 // the bf16 rate); LDS-DMA, swizzle, window reuse, split-K and the epilogue are the bf16 kernel's.  PIPE = 0 only.
+// One piece of a stream-K range: the tile the range's cursor w_cur is in, the steps [s_begin, s_end) of that tile the range owns,
+// how many ranges share the tile (nsplit), this range's place among them (split) and the first of the tile's consecutive slab ids.
+// Range r owns steps [W r / G, W (r + 1) / G) of the tile-major space, W = tiles * S_; the range holding step w is
+// ceil((w + 1) G / W) - 1.  Host and device run this same function (w2l_conv_streamk_pieces: the CPU test of the decomposition).
+struct SkPiece { int tile, s_begin, s_end, nsplit, split; int64_t slab_base; };
+__host__ __device__ inline SkPiece sk_piece(int W, int G, int S_, int r, int w_cur, int w_end) {
+    SkPiece q;
+    q.tile = w_cur / S_;
+    q.s_begin = w_cur - q.tile * S_;
+    q.s_end = q.s_begin + (w_end - w_cur) < S_ ? q.s_begin + (w_end - w_cur) : S_;
+    const int r_lo = (int)((((int64_t)q.tile * S_ + 1) * G + W - 1) / W) - 1;
+    const int r_hi = (int)((((int64_t)q.tile * S_ + S_) * G + W - 1) / W) - 1;
+    q.nsplit = r_hi - r_lo + 1;
+    q.split = r - r_lo;
+    q.slab_base = (int64_t)r_lo + q.tile;
+    return q;
+}
+
 template <int MW, int NW, int MS, int NS, int S, int PIPE, bool F8 = false, int EPI = 0, bool SK = false>
 __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams p) {
     static_assert(!SK || (!F8 && EPI == 0 && S == 1), "stream-K is built for the plain bf16 stride-1 kernels");
@@ -118,17 +136,14 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
     int64_t slab_base;
     if constexpr (SK) {
         __syncthreads();                               // the previous tile's LDS (ticket word, statistics scratch) is dead
-        const int S_ = (p.Cin / (ROWB / (F8 ? 1 : 2))) * p.Kw, G = p.sk_ranges, W = p.sk_total;
-        tile = w_cur / S_;
-        sk_begin = w_cur - tile * S_;
-        sk_end = sk_begin + (w_end - w_cur) < S_ ? sk_begin + (w_end - w_cur) : S_;
+        const SkPiece q = sk_piece(p.sk_total, p.sk_ranges, (p.Cin / (ROWB / (F8 ? 1 : 2))) * p.Kw, lin, w_cur, w_end);
+        tile = q.tile;
+        sk_begin = q.s_begin;
+        sk_end = q.s_end;
         w_cur += sk_end - sk_begin;
-        // ranges holding the tile's first and last step: r(w) = ceil((w + 1) * G / W) - 1
-        const int r_lo = (int)((((int64_t)tile * S_ + 1) * G + W - 1) / W) - 1;
-        const int r_hi = (int)((((int64_t)tile * S_ + S_) * G + W - 1) / W) - 1;
-        nsplit = r_hi - r_lo + 1;
-        split = lin - r_lo;
-        slab_base = (int64_t)r_lo + tile;
+        nsplit = q.nsplit;
+        split = q.split;
+        slab_base = q.slab_base;
     } else {
         nsplit = p.splits;
         split = nsplit > 1 ? lin % nsplit : 0;
@@ -929,6 +944,28 @@ extern "C" int w2l_conv_streamk_ranges(int idx, int N, int Cin, int Cout, int To
     static const char dummy = 0;
     if (!sk_feasible(idx % kNumCfgs, N, Cin, Cout, Tout, Kw, stride, dil, &dummy, ws_bytes)) return 0;
     return sk_ranges(kCfgs[idx % kNumCfgs], stride, Kw, dil);
+}
+
+// the pieces of a stream-K launch of `tiles` tiles x `steps` steps over G ranges, in range order, as the kernel walks them:
+// out[7 * i] = range, tile, first step, end step, ranges sharing the tile, this range's place among them, slab id (-1: the
+// tile is whole).  Returns the piece count, -1 if cap is too small or the sizes are out of the kernel's 32-bit range.
+extern "C" int w2l_conv_streamk_pieces(int tiles, int steps, int G, int* out, int cap) {
+    if (tiles <= 0 || steps <= 0 || G <= 0 || ((int64_t)tiles * steps + steps) * G >= (1LL << 31)) return -1;
+    const int W = tiles * steps;
+    int n = 0;
+    for (int r = 0; r < G; ++r) {
+        int w_cur = (int)(((int64_t)W * r) / G);
+        const int w_end = (int)(((int64_t)W * (r + 1)) / G);
+        while (w_cur < w_end) {
+            const SkPiece q = sk_piece(W, G, steps, r, w_cur, w_end);
+            if (n >= cap) return -1;
+            int* o = out + 7 * n++;
+            o[0] = r; o[1] = q.tile; o[2] = q.s_begin; o[3] = q.s_end; o[4] = q.nsplit; o[5] = q.split;
+            o[6] = q.nsplit > 1 ? (int)(q.slab_base + q.split) : -1;
+            w_cur += q.s_end - q.s_begin;
+        }
+    }
+    return n;
 }
 
 extern "C" int64_t w2l_conv_splitk_workspace_bytes(int N, int Cout, int Tout) {
