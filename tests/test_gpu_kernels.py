@@ -211,6 +211,20 @@ def test_conv_igemm_stream_k(L, with_stats):
         _, ya, _ = run(idx, xh, None, False)
         _, y2, _ = run(idx, xh * 2, None, False)
         assert torch.equal(y2, ya * 2), idx
+        if ran % 8 == 1:
+            # fp32 output accumulated onto what is there (the split-bf16 passes of the fp32 mode): prefill + the same sums
+            pre = torch.randn(N, Tout, coutp, device='cuda')
+            yf = pre.clone()
+            L.lib.w2l_conv_force_tile_config(idx)
+            try:
+                L.check(L.lib.w2l_conv1d_igemm_ws(L.ptr(xh), rows * cinp, N * rows, L.ptr(fh), L.ptr(yf), 1, 1, None, None, N, cinp, coutp,
+                                                  Tout, Kw, 1, d, L.ptr(ws), ws.numel(), L.stream_ptr()))
+            finally:
+                L.lib.w2l_conv_force_tile_config(-1)
+            torch.cuda.synchronize()
+            want = pre[:, :, :Cout] + (ref - b[None, :, None]).transpose(1, 2).cuda()
+            assert (yf[:, :, :Cout] - want).abs().max() <= 2e-3 * ref.abs().max(), idx
+            assert not ws[:65536].any(), idx
     assert ran >= (10 if with_stats else 30), ran
 
 
