@@ -333,7 +333,9 @@ int w2l_bn_act_fwd_fin(const w2l_bnact_t* d, const w2l_bnfin_t* f1, const w2l_bn
  * w2l_conv_force_tile_config): 0 (default) = one row per 128-column tile, plain stores (w2l_conv_stat_tiles rows,
  * bit-reproducible); S = 1..64: the per-tile sums are ADDED (fp32 atomics) onto row (tile mod S) of a [S][2][C] buffer the
  * caller zero-filled -- a handful of rows that w2l_bn_act_fwd_fin / w2l_bn_act_bwd_apply_fin re-reduce per block instead of
- * a finalize launch of their own.  Applies to w2l_conv1d_igemm*, w2l_conv1d_igemm_fp8 and w2l_conv1d_dgrad_bnreduce_ws. */
+ * a finalize launch of their own.  Applies to w2l_conv1d_igemm*, w2l_conv1d_igemm_fp8 and w2l_conv1d_dgrad_bnreduce_ws.
+ * With S > 0 the bf16 kernels may take ANY block shape for a launch with statistics (a block adds its whole tile's sums
+ * onto row (column tile mod S)); with 0 only the shapes of 128 or 256 columns, whose waves line up with the 128-column rows. */
 void w2l_conv_stats_mode(int slots);
 
 /* dst[i] = e4m3(src[i] * scale), src bf16 (src_f32 = 0) or fp32, n a multiple of 8: per-tensor quantisation of the conv

@@ -156,6 +156,55 @@ def test_conv_igemm_forward(L, case, precise):
     assert relerr(s2, r2) < (2e-2 if not precise else 1e-3)
 
 
+def test_conv_igemm_slot_statistics_every_block_shape(L):
+    """w2l_conv_stats_mode(8): the statistics of EVERY block shape -- also the 144 / 288 / 384 / 448-column ones that the
+    one-row-per-128-column layout excludes --, both K-loop structures, split-K and stream-K forms: the column sums added onto
+    the 8 slot rows equal the reference's, the output equals the launch without statistics"""
+    N, Cin, Cout, T, Kw, d = 3, 256, 320, 620, 7, 2
+    pl = pr = (Kw - 1) * d // 2
+    x, w, b = conv_inputs(N, Cin, Cout, Kw, T, pl, pr, 14)
+    xp = to_ntc_padded(x, pl, pr, 1)
+    rows = xp.shape[1]
+    Tout = rows - (Kw - 1) * d
+    fh, _, _, _, coutp, cinp = pack(L, w, False)
+    xh = xp.to(torch.bfloat16).cuda()
+    bd = b.cuda()
+    ref = F.conv1d(F.pad(bf(x), (pl, pr), mode='reflect'), bf(w), b, dilation=d)
+    r1, r2 = ref.sum((0, 2)), (ref * ref).sum((0, 2))
+    ws = torch.zeros(int(L.lib.w2l_conv_splitk_workspace_bytes(N, coutp, Tout)), dtype=torch.uint8, device='cuda')
+
+    def run(idx, stats):
+        y = torch.full((N, Tout, coutp), float('nan'), dtype=torch.bfloat16, device='cuda')
+        L.lib.w2l_conv_force_tile_config(idx)
+        L.lib.w2l_conv_stats_mode(8)
+        try:
+            rc = L.lib.w2l_conv1d_igemm_ws(L.ptr(xh), rows * cinp, N * rows, L.ptr(fh), L.ptr(y), 0, 0, L.ptr(bd),
+                                           L.ptr(stats) if stats is not None else None, N, cinp, coutp, Tout, Kw, 1, d,
+                                           L.ptr(ws), ws.numel(), L.stream_ptr())
+        finally:
+            L.lib.w2l_conv_stats_mode(0)
+            L.lib.w2l_conv_force_tile_config(-1)
+        torch.cuda.synchronize()
+        return rc, y
+
+    ran = wide = 0
+    for idx in list(range(52)) + list(range(52, 52 * 8, 5)):
+        slots = torch.zeros(8, 2, coutp, device='cuda')
+        rc, y = run(idx, slots)
+        if rc != 0:
+            continue                                       # (does not fit LDS / the spilling shape)
+        ran += 1
+        wide += idx % 26 in (6, 7, 8, 9, 17, 18, 19, 21, 22, 23, 24, 25)
+        _, y0 = run(idx, None)
+        assert torch.equal(y, y0), idx
+        assert relerr(y.float().cpu().transpose(1, 2)[:, :Cout], ref) < 1e-2, idx
+        got = slots.sum(0).cpu()
+        assert relerr(got[1, :Cout], r2) < 2e-2, idx
+        assert (got[0, :Cout] - r1).abs().max() <= 5e-3 * r2.sqrt().max() * (N * Tout) ** 0.5, idx
+        assert not got[:, Cout:].any(), idx
+    assert ran >= 90 and wide >= 40, (ran, wide)
+
+
 @pytest.mark.parametrize('with_stats', [True, False])
 def test_conv_igemm_stream_k(L, with_stats):
     """the stream-K form of every block shape x both K-loop structures (split option 7: one block per resident slot, equal

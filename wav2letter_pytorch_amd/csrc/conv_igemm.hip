@@ -573,6 +573,23 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
                 }
         }
         __syncthreads();
+        if (p.stats_slots) {
+            // w2l_conv_stats_mode(S): the block's sums -- all its NW column waves, whatever the block shape -- ADDED onto row
+            // (column tile mod S) of the zero-filled [S][2][Cout] buffer; its reader re-reduces the S rows
+            float* dst = p.stats + (((int64_t)n * p.tiles_t + tt) % p.stats_slots) * 2 * Cout;
+            for (int cl = tid; cl < BM; cl += NT) {
+                if (m0 + cl < Cout) {
+                    float a = 0.f, b = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        a += red[(w * 2 + 0) * BM + cl];
+                        b += red[(w * 2 + 1) * BM + cl];
+                    }
+                    atomicAdd(dst + m0 + cl, a);
+                    atomicAdd(dst + Cout + m0 + cl, b);
+                }
+            }
+        } else {
         const int tiles128 = (Tout + 127) / 128;
         for (int idx = tid; idx < BM * HALVES; idx += NT) {
             const int h = idx / BM, cl = idx - h * BM;
@@ -585,16 +602,11 @@ __global__ __launch_bounds__(64 * MW * NW, 2) void conv_igemm_kernel(IgemmParams
                     b += red[((h * WPH + w) * 2 + 1) * BM + cl];
                 }
                 const int64_t srow = (int64_t)n * tiles128 + trow;
-                if (p.stats_slots) {                       // w2l_conv_stats_mode(S): a handful of rows, re-reduced by their reader
-                    float* dst = p.stats + (srow % p.stats_slots) * 2 * Cout;
-                    atomicAdd(dst + m0 + cl, a);
-                    atomicAdd(dst + Cout + m0 + cl, b);
-                } else {
-                    float* dst = p.stats + srow * 2 * Cout;
-                    dst[m0 + cl] = a;
-                    dst[Cout + m0 + cl] = b;
-                }
+                float* dst = p.stats + srow * 2 * Cout;
+                dst[m0 + cl] = a;
+                dst[Cout + m0 + cl] = b;
             }
+        }
         }
     }
     } while (SK && w_cur < w_end);
@@ -622,7 +634,8 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 template <int MW, int NW, int MS, int NS, int PIPE>
 int launch_cfg1(const IgemmParams& p, int tiles_m, size_t lds, hipStream_t stream, int epi = 0) {
     if (epi == 1) {
-        if constexpr ((16 * NW * NS) % 128 == 0 && 16 * NW * NS <= 256) {        // statistics rows are per 128-column tile
+        // statistics rows are per 128-column tile -- unless the sums are added onto slot rows (w2l_conv_stats_mode): any shape then
+        if ((16 * NW * NS) % 128 == 0 && 16 * NW * NS <= 256 ? true : p.stats_slots > 0) {
             auto kern1 = conv_igemm_kernel<MW, NW, MS, NS, 1, PIPE, false, 1>;
             W2L_CHECK_HIP(w2l_allow_big_lds((const void*)kern1));
             hipLaunchKernelGGL(kern1, dim3(tiles_m * p.ncols), dim3(64 * MW * NW), lds, stream, p);
@@ -721,10 +734,15 @@ static bool cfg_feasible(int idx, int Kw, int stride, int dil, bool need_bn128) 
 
 // pick the block shape: a measured choice if this shape was tuned, else a cost model (whole rounds of
 // resident blocks on the 256 CUs, larger tiles preferred)
-static int choose_cfg(int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, bool need_bn128) {
+// statistics flag of a shape key: 0 none, 1 one row per 128-column tile (block shapes of 128 / 256 columns only), 2 added onto
+// slot rows (w2l_conv_stats_mode: every block shape)
+static int stats_flag(const float* stats_partial) { return stats_partial == nullptr ? 0 : (g_stats_slots > 0 ? 2 : 1); }
+
+static int choose_cfg(int N, int Cin, int Cout, int Tout, int Kw, int stride, int dil, int sflag) {
+    const bool need_bn128 = sflag == 1;
     if (g_force_cfg < 0) {
         std::lock_guard<std::mutex> lock(g_tuned_mu);
-        auto it = g_tuned.find(ShapeKey(N, Cin, Cout, Tout, Kw, stride, dil, need_bn128 ? 1 : 0));
+        auto it = g_tuned.find(ShapeKey(N, Cin, Cout, Tout, Kw, stride, dil, sflag));
         if (it != g_tuned.end()) return it->second;
     }
     if (g_force_cfg >= 0) return cfg_feasible(g_force_cfg, Kw, stride, dil, need_bn128) ? g_force_cfg : -1;
@@ -863,7 +881,7 @@ static int igemm_launch(const void* xp, int64_t x_bstride, int64_t x_rows_total,
     W2L_CHECK_ARG(need <= p.x_max_row, "conv1d_igemm: padded input too small (need row %lld, have %lld)",
                   (long long)need, (long long)p.x_max_row);
     // BatchNorm partial statistics are laid out per 128-row column tile (w2l_conv_stat_tiles)
-    const int ci = choose_cfg(N, Cin, Cout, Tout, Kw, stride, dil, stats_partial != nullptr);     // (a fused data gradient
+    const int ci = choose_cfg(N, Cin, Cout, Tout, Kw, stride, dil, stats_flag(stats_partial));     // (a fused data gradient
     // shares the table with forward launches: its N = 1, Tout = flat rows shape never coincides with one of theirs)
     W2L_CHECK_ARG(ci >= 0, "conv1d_igemm: no block shape fits LDS (Kw=%d dil=%d stride=%d)", Kw, dil, stride);
     const int pipe = (ci % kBaseCfgs) / kNumCfgs;
@@ -984,8 +1002,8 @@ extern "C" int w2l_conv1d_igemm_tune_ws(const void* xp, int64_t x_bstride, int64
                                         int y_f32, const float* bias, float* stats_partial, int N, int Cin, int Cout, int Tout,
                                         int Kw, int stride, int dil, int reps, void* splitk_ws, int64_t splitk_ws_bytes,
                                         void* stream) {
-    const bool need128 = stats_partial != nullptr;
-    const ShapeKey key(N, Cin, Cout, Tout, Kw, stride, dil, need128 ? 1 : 0);
+    const bool need128 = stats_flag(stats_partial) == 1;
+    const ShapeKey key(N, Cin, Cout, Tout, Kw, stride, dil, stats_flag(stats_partial));
     {
         std::lock_guard<std::mutex> lock(g_tuned_mu);
         if (g_tuned.count(key)) return 0;
@@ -1257,7 +1275,7 @@ bool w2l_igemm_fp8_tune_put(const int* v) {      // v[0..7] = key, v[8] = index 
 }
 
 bool w2l_igemm_tune_put(const int* v) {          // v[0..7] = key, v[8] = block-shape index
-    if (!cfg_feasible(v[8], v[4], v[5], v[6], v[7] != 0)) return false;
+    if (v[7] < 0 || v[7] > 2 || !cfg_feasible(v[8], v[4], v[5], v[6], v[7] == 1)) return false;
     std::lock_guard<std::mutex> lock(g_tuned_mu);
     g_tuned[ShapeKey(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])] = v[8];
     return true;
