@@ -832,7 +832,10 @@ def test_bn_act_fwd_bwd(L, N, T, C, pl, pr, mode, act, f32):
 
 @pytest.mark.parametrize('N,T,C,pl,pr,mode,act,p,lens,h', [
     (3, 150, 128, 12, 12, 1, 1, 0.0, False, 24), (2, 333, 192, 4, 5, 1, 1, 0.3, False, 51), (2, 90, 64, 3, 3, 0, 2, 0.0, True, 38),
-    (4, 500, 896, 28, 28, 1, 1, 0.4, False, 56), (1, 40, 64, 7, 7, 1, 0, 0.2, True, 24)])
+    (4, 500, 896, 28, 28, 1, 1, 0.4, False, 56), (1, 40, 64, 7, 7, 1, 0, 0.2, True, 24),
+    # 12 000 rows and 8 M elements on: the LOOPED kernels (a wave walks four row groups, the next one's loads in flight) -- utterance
+    # boundaries inside a wave's rows (T = 500 and 997 are no multiples of 8 x 4), reflect folds, length masks, ReLU / clamp / none
+    (26, 500, 640, 20, 20, 1, 1, 0.2, False, 40), (13, 997, 640, 6, 6, 0, 2, 0.0, True, 12), (25, 500, 704, 28, 28, 1, 0, 0.3, True, 56)])
 def test_bn_bwd_two_launch_chain_equals_three(L, N, T, C, pl, pr, mode, act, p, lens, h):
     """the backward chain's fast path (w2l_bn_act_bwd_reduce_slots + w2l_bn_act_bwd_apply_slots: sums added onto 8 slot rows,
     the finalize folded into the dy pass) against reduce + finalize + apply: the same sums (up to the order of the fp32

@@ -851,25 +851,41 @@ __device__ __forceinline__ void fast_row_load(const w2l_bnact_t& d, const w2l_gr
     }
 }
 
-// gated gradient and normalised input of one row's 8 channels
-__device__ __forceinline__ void fast_row_eval(const w2l_bnact_t& d, const FastRow& r, const Chan& ch, float inv_keep, float g[8],
-                                              float xh[8]) {
-    const float gk = d.drop_p > 0.f ? inv_keep : 1.f;
+// gated gradient and normalised input of one row's 8 channels.  The activation and whether there is dropout are template
+// parameters: these kernels are bound by their instruction count, not by HBM (a plain copy of the same bytes runs at twice
+// their rate: tools/probe/hbm_ceiling.py), and a run-time switch on d.act costs two scalar branches per ELEMENT
+template <int ACT, bool DROP>
+__device__ __forceinline__ void fast_row_eval(const FastRow& r, const Chan& ch, float inv_keep, float g[8], float xh[8]) {
+    float gv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gv[j] = bf16_bits_to_f32(r.g[j]);
+    if (r.fa) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[j] += bf16_bits_to_f32(r.ga[j]);
+    }
+    if (r.fb) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[j] += bf16_bits_to_f32(r.gb[j]);
+    }
+    const float gk = DROP ? inv_keep : 1.f;
+    const bool row_ok = !r.masked;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float y = bf16_bits_to_f32(r.y[j]);
         float z = y * ch.sc[j] + ch.sh[j];
-        const bool keep = (r.bits >> j) & 1u;
-        if (d.drop_p > 0.f) z = keep ? z * inv_keep : 0.f;
-        float gv = bf16_bits_to_f32(r.g[j]);
-        if (r.fa) gv += bf16_bits_to_f32(r.ga[j]);
-        if (r.fb) gv += bf16_bits_to_f32(r.gb[j]);
-        g[j] = (!r.masked && keep && act_pass(z, d.act)) ? gv * gk : 0.f;
+        bool pass = row_ok;
+        if (DROP) {
+            pass = pass && ((r.bits >> j) & 1u);
+            z *= inv_keep;                             // (a dropped element's z is never looked at: pass is false)
+        }
+        if (ACT == 1) pass = pass && z >= 0.f && z <= 20.f;      // torch.clamp passes 1 on the CLOSED interval
+        else if (ACT == 2) pass = pass && z > 0.f;
+        g[j] = pass ? gv[j] * gk : 0.f;
         xh[j] = (y - ch.m[j]) * ch.is[j];
     }
 }
 
-template <int U>
+template <int U, int ACT, bool DROP>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(w2l_bnact_t d, w2l_gradsrc_t g1, float* partial, float inv_keep,
                                                                   int slots) {
     __shared__ float red[4][2][BWD_SLAB];
@@ -892,7 +908,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(w2l_bnact_t d, 
     for (int u = 0; u < U; ++u) {
         if (!r[u].live) continue;
         float g[8], xh[8];
-        fast_row_eval(d, r[u], ch, inv_keep, g, xh);
+        fast_row_eval<ACT, DROP>(r[u], ch, inv_keep, g, xh);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s0[j] += g[j]; s1[j] += g[j] * xh[j]; }
     }
@@ -915,7 +931,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(w2l_bnact_t d, 
     }
 }
 
-template <int U>
+template <int U, int ACT, bool DROP>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(w2l_bnact_t d, w2l_gradsrc_t g1, const float* partial, int nb,
                                                                  float* sums_out, bf16_raw* dy_hi, int h1, float inv_keep,
                                                                  float* amax) {
@@ -959,7 +975,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(w2l_bnact_t d, w
     for (int u = 0; u < U; ++u) {
         if (!r[u].live) continue;
         float g[8], xh[8], o[8];
-        fast_row_eval(d, r[u], ch, inv_keep, g, xh);
+        fast_row_eval<ACT, DROP>(r[u], ch, inv_keep, g, xh);
         if (d.mean) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = ch.sc[j] * (g[j] - sg[j] * invM - xh[j] * sgx[j] * invM);
@@ -993,6 +1009,195 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(w2l_bnact_t d, w
         for (int m = 1; m < 64; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
         if (lane == 0) smax[wave] = mx;
         __syncthreads();                               // (amax is a kernel argument: uniform)
+        if (tid == 0) amax_publish(amax, blockIdx.x & (AMAX_SLOTS - 1), fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
+    }
+}
+
+// ---- looped forms (round 5, late): the kernels above give a wave 8-32 rows and then pay, per wave, the channel constants, the
+// index arithmetic, the prologue / the cross-lane reduction: 550-670 vector instructions for 8-16 elements per lane -- and 14 000-
+// 28 000 such waves take as long to ISSUE on 1 024 SIMDs as the kernels run (17-28 us).  Here a wave walks `iters` row groups of
+// its slab with the next group's loads in flight while it works on the current one, so the per-wave work is paid once per
+// iters x 8 rows.
+// row cursor of a lane: the row's index, (utterance, frame) and the three addresses it reads, advanced by 8 rows at a time with
+// additions only (no division, no 64-bit multiply per row; T >= 8: at most one utterance boundary per step -- the launcher checks)
+struct RowCur {
+    int64_t row;
+    int n, t;
+    const bf16_raw* py;                                // y[row][c]
+    const bf16_raw* pg;                                // gradient source row of frame t: dxp[n][pad_l + t][c]
+    const uint8_t* pm;                                 // dropout keep bits of the row's channel group
+};
+__device__ __forceinline__ void rowcur_init(RowCur& q, const w2l_bnact_t& d, const w2l_gradsrc_t& s, int64_t row, int c, int cg, int G) {
+    q.row = row;
+    q.n = (int)(row / d.T);
+    q.t = (int)(row - (int64_t)q.n * d.T);
+    q.py = reinterpret_cast<const bf16_raw*>(d.y) + row * d.C + c;
+    q.pg = reinterpret_cast<const bf16_raw*>(s.dxp) + ((int64_t)q.n * s.rows + q.t + s.pad_l) * d.C + c;
+    q.pm = d.mask ? d.mask + row * G + cg : nullptr;
+}
+__device__ __forceinline__ void rowcur_step(RowCur& q, const w2l_bnact_t& d, const w2l_gradsrc_t& s, int G) {
+    q.row += 8;
+    q.t += 8;
+    q.py += 8 * (int64_t)d.C;
+    q.pg += 8 * (int64_t)d.C;
+    if (q.pm) q.pm += 8 * G;
+    if (q.t >= d.T) {
+        q.t -= d.T;
+        ++q.n;
+        q.pg += (int64_t)(s.rows - d.T) * d.C;
+    }
+}
+__device__ __forceinline__ void fast_row_load_cur(const w2l_bnact_t& d, const w2l_gradsrc_t& s, const RowCur& q, bool live, FastRow& o) {
+    o.live = live;
+    o.fa = o.fb = o.masked = false;
+    o.bits = 0xFFu;
+    o.n = q.n; o.t = q.t;
+    if (!live) return;
+    const int T = d.T, t = q.t;
+    o.y = *reinterpret_cast<const u16x8*>(q.py);
+    if (d.drop_p > 0.f) o.bits = *q.pm;
+    o.masked = d.lens && t >= d.lens[q.n];
+    o.g = *reinterpret_cast<const u16x8*>(q.pg);
+    if (s.pad_mode == 1) {                             // the reflected halo rows' gradient folds back onto its source frame
+        o.fa = t >= 1 && t <= s.pad_l;
+        o.fb = t <= T - 2 && t >= T - 1 - s.pad_r;
+        if (o.fa) o.ga = *reinterpret_cast<const u16x8*>(q.pg - 2 * (int64_t)t * d.C);                    // padded row pad_l - t
+        if (o.fb) o.gb = *reinterpret_cast<const u16x8*>(q.pg + 2 * (int64_t)(T - 1 - t) * d.C);          // pad_l + 2 (T-1) - t
+    }
+}
+
+template <int ACT, bool DROP>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_loop_kernel(w2l_bnact_t d, w2l_gradsrc_t g1, float* partial, float inv_keep,
+                                                                  int slots, int iters) {
+    __shared__ float red[4][2][BWD_SLAB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = d.C >> 3, nslabs = d.C / BWD_SLAB;
+    const int slab = blockIdx.x % nslabs, chunk = blockIdx.x / nslabs;
+    const int cgl = lane & 7, rr = lane >> 3;
+    const int cg = slab * (BWD_SLAB / 8) + cgl, c = cg * 8;
+    const int64_t rows = (int64_t)d.N * d.T;
+    RowCur q;
+    rowcur_init(q, d, g1, ((int64_t)chunk * 4 + wave) * ((int64_t)iters * 8) + rr, c, cg, G);
+    FastRow cur, nxt;
+    fast_row_load_cur(d, g1, q, q.row < rows, cur);
+    Chan ch;
+    load_chan(ch, d.scale, d.shift, d.mean, d.invstd, c);
+    float s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+    for (int it = 0; it < iters; ++it) {
+        rowcur_step(q, d, g1, G);
+        fast_row_load_cur(d, g1, q, it + 1 < iters && q.row < rows, nxt);
+        if (cur.live) {
+            float g[8], xh[8];
+            fast_row_eval<ACT, DROP>(cur, ch, inv_keep, g, xh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s0[j] += g[j]; s1[j] += g[j] * xh[j]; }
+        }
+        cur = nxt;
+    }
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s0[j] += __shfl_xor(s0[j], m, 64);
+            s1[j] += __shfl_xor(s1[j], m, 64);
+        }
+    if (rr == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[wave][0][cgl * 8 + j] = s0[j]; red[wave][1][cgl * 8 + j] = s1[j]; }
+    }
+    __syncthreads();
+    if (tid < 2 * BWD_SLAB) {
+        const int k = tid >> 6, cc = tid & 63;
+        const float t4 = (red[0][k][cc] + red[1][k][cc]) + (red[2][k][cc] + red[3][k][cc]);
+        atomicAdd(partial + ((int64_t)(chunk % slots) * 2 + k) * d.C + slab * BWD_SLAB + cc, t4);
+    }
+}
+
+template <int ACT, bool DROP>
+__global__ __launch_bounds__(256) void bn_bwd_apply_loop_kernel(w2l_bnact_t d, w2l_gradsrc_t g1, const float* partial, int nb,
+                                                                 float* sums_out, bf16_raw* dy_hi, int h1, float inv_keep,
+                                                                 float* amax, int iters) {
+    __shared__ float ssum[2][BWD_SLAB];
+    __shared__ float smax[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = d.C >> 3, nslabs = d.C / BWD_SLAB;
+    const int slab = blockIdx.x % nslabs, chunk = blockIdx.x / nslabs;
+    const int cgl = lane & 7, rr = lane >> 3;
+    const int cg = slab * (BWD_SLAB / 8) + cgl, c = cg * 8;
+    const int T = d.T, N = d.N;
+    const int64_t rows = (int64_t)N * T;
+    RowCur q;
+    rowcur_init(q, d, g1, ((int64_t)chunk * 4 + wave) * ((int64_t)iters * 8) + rr, c, cg, G);
+    bf16_raw* pdy = dy_hi + ((int64_t)h1 + (int64_t)q.n * (T + h1) + q.t) * d.C + c;      // dy row of the cursor's frame
+    FastRow cur, nxt;
+    fast_row_load_cur(d, g1, q, q.row < rows, cur);                                // before the prologue's round trip
+    if (tid < 2 * BWD_SLAB) {                          // column sums of partial[nb][2][C] over this slab's channels, fixed order
+        const int k = tid >> 6, cc = tid & 63;
+        float a = 0.f;
+        int j = 0;
+        for (; j + 8 <= nb; j += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[((int64_t)(j + u) * 2 + k) * d.C + slab * BWD_SLAB + cc];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; j < nb; ++j) a += partial[((int64_t)j * 2 + k) * d.C + slab * BWD_SLAB + cc];
+        ssum[k][cc] = a;
+        if (chunk == 0) sums_out[(int64_t)k * d.C + slab * BWD_SLAB + cc] = a;
+    }
+    __syncthreads();
+    Chan ch;
+    load_chan(ch, d.scale, d.shift, d.mean, d.invstd, c);
+    const float invM = 1.f / ((float)N * (float)T);
+    float sg[8], sgx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sg[j] = ssum[0][cgl * 8 + j] * invM; sgx[j] = ssum[1][cgl * 8 + j] * invM; }
+    float mx = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        bf16_raw* const pdy_cur = pdy;
+        pdy += (int64_t)(q.t + 8 >= T ? 8 + h1 : 8) * d.C;                           // (an utterance boundary skips its halo rows)
+        rowcur_step(q, d, g1, G);
+        fast_row_load_cur(d, g1, q, it + 1 < iters && q.row < rows, nxt);
+        if (cur.live) {
+            float g[8], xh[8], o[8];
+            fast_row_eval<ACT, DROP>(cur, ch, inv_keep, g, xh);
+            if (d.mean) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = ch.sc[j] * (g[j] - sg[j] - xh[j] * sgx[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = g[j] * ch.sc[j];
+            }
+            store8_split(pdy_cur, nullptr, 0, o);
+            if (amax) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(o[j]));
+            }
+        }
+        cur = nxt;
+    }
+    if (h1 > 0) {                                      // halo rows of the shared-halo layout: this block's share
+        const int nchunks = gridDim.x / nslabs;
+        float z[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = 0.f;
+        const int total = h1 * (N + 1);
+        const int per = (total + nchunks - 1) / nchunks;
+        int e = (chunk + 1) * per;
+        if (e > total) e = total;
+        for (int hr = chunk * per + wave * 8 + rr; hr < e; hr += 32) {
+            const int gap = hr / h1, rw = hr - gap * h1;
+            store8_split(dy_hi, nullptr, ((int64_t)gap * (T + h1) + rw) * d.C + c, z);
+        }
+    }
+    if (amax) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        if (lane == 0) smax[wave] = mx;
+        __syncthreads();
         if (tid == 0) amax_publish(amax, blockIdx.x & (AMAX_SLOTS - 1), fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
     }
 }
@@ -1220,6 +1425,19 @@ static bool bwd_fast_ok(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l
     return !d->y_f32 && !d->y2 && g1 && !g1->f32 && g2 == nullptr && d->C % BWD_SLAB == 0 && d->scale != nullptr;
 }
 
+// row groups per wave of the looped backward kernels; 0 = the one-shot kernels.  Measured (tools/bench_elem.py, N x T = 16 000 rows;
+// reduce / dy pass, us): C = 256 one-shot 6.3 / 7.2, looped (4) 6.5 / 7.8; C = 512 11.5 / 15.6 -> 10.9 / 12.7; C = 896 16.6 / 23.6 ->
+// 16.9 / 20.7; C = 1 024 17.2 / 24.7 -> 17.8 / 21.9; 8 groups no better, 16 worse; in the step -0.07 ms at N = 32, +0.07 on Jasper
+// 10x5 N = 16 (8 000 rows) when everything is looped: looped from 8 M elements per activation and 12 000 rows on.
+// W2L_BN_LOOP_ITERS=<n> forces n everywhere (0 = never): experiment switch.
+static int bn_loop_iters(int64_t rows, int T, int C) {
+    static const int forced = getenv("W2L_BN_LOOP_ITERS") ? atoi(getenv("W2L_BN_LOOP_ITERS")) : -1;
+    int it = forced >= 0 ? forced : ((rows >= 12000 && rows * C >= 8000000) ? 4 : 0);
+    if (T < 8) it = 0;                                  // (the row cursor steps 8 rows with at most one utterance boundary)
+    while (it > 1 && rows < 4LL * it * 8 * 4) it >>= 1; // short activations: keep at least a few chunks
+    return it;
+}
+
 extern "C" int w2l_bn_bwd_fast_ok(const w2l_bnact_t* d, const w2l_gradsrc_t* g1, const w2l_gradsrc_t* g2) {
     return d && bwd_fast_ok(d, g1, g2) ? 1 : 0;
 }
@@ -1230,11 +1448,32 @@ extern "C" int w2l_bn_act_bwd_reduce_slots(const w2l_bnact_t* d, const w2l_grads
     W2L_CHECK_ARG(bwd_fast_ok(d, g1, nullptr), "bn_act_bwd_reduce_slots: bf16 y and gradient, one branch, one source, C %% 64 == 0 only");
     W2L_CHECK_ARG(g1->rows >= g1->pad_l + d->T + g1->pad_r, "bn_act_bwd_reduce_slots: gradient source has too few rows per utterance");
     const int64_t rows = (int64_t)d->N * d->T;
+    const float inv_keep = 1.f / (1.f - d->drop_p);
+    const bool drop = d->drop_p > 0.f;
+    const int iters = bn_loop_iters(rows, d->T, d->C);
+    if (iters > 0) {
+        const int nch = (int)((rows + 4LL * iters * 8 - 1) / (4LL * iters * 8));
+        const dim3 lgrid((unsigned)(nch * (d->C / BWD_SLAB)));
+#define W2L_REDL(A, D) hipLaunchKernelGGL((bn_bwd_reduce_loop_kernel<A, D>), lgrid, dim3(256), 0, (hipStream_t)stream, *d, *g1, partial, inv_keep, slots, iters)
+        switch (d->act) {
+            case 1: if (drop) W2L_REDL(1, true); else W2L_REDL(1, false); break;
+            case 2: if (drop) W2L_REDL(2, true); else W2L_REDL(2, false); break;
+            default: if (drop) W2L_REDL(0, true); else W2L_REDL(0, false); break;
+        }
+#undef W2L_REDL
+        W2L_CHECK_LAUNCH();
+        return 0;
+    }
     constexpr int U = 2;
     const int nchunks = (int)((rows + 4 * U * 8 - 1) / (4 * U * 8));
-    const float inv_keep = 1.f / (1.f - d->drop_p);
-    hipLaunchKernelGGL(bn_bwd_reduce_fast_kernel<U>, dim3((unsigned)(nchunks * (d->C / BWD_SLAB))), dim3(256), 0, (hipStream_t)stream, *d,
-                       *g1, partial, inv_keep, slots);
+    const dim3 grid((unsigned)(nchunks * (d->C / BWD_SLAB)));
+#define W2L_RED(A, D) hipLaunchKernelGGL((bn_bwd_reduce_fast_kernel<U, A, D>), grid, dim3(256), 0, (hipStream_t)stream, *d, *g1, partial, inv_keep, slots)
+    switch (d->act) {
+        case 1: if (drop) W2L_RED(1, true); else W2L_RED(1, false); break;
+        case 2: if (drop) W2L_RED(2, true); else W2L_RED(2, false); break;
+        default: if (drop) W2L_RED(0, true); else W2L_RED(0, false); break;
+    }
+#undef W2L_RED
     W2L_CHECK_LAUNCH();
     return 0;
 }
@@ -1249,18 +1488,35 @@ extern "C" int w2l_bn_act_bwd_apply_slots(const w2l_bnact_t* d, const w2l_gradsr
     W2L_CHECK_ARG((rows + (int64_t)halo * (d->N + 1)) * (d->C / 8) < (1LL << 31), "bn_act_bwd_apply_slots: tensor too large for 32-bit indexing");
     // (fp8 mode, amax: four groups -- a block ends in an atomic on one of W2L_AMAX_SLOTS words, and same-address atomics take
     // ~0.1 us each one after the other: the fewer blocks the better; measured 9.0 against 10.1 ms per fp8 step)
+    const float inv_keep = 1.f / (1.f - d->drop_p);
+    const int iters = bn_loop_iters(rows, d->T, d->C);
+    if (iters > 0) {
+        const int nch = (int)((rows + 4LL * iters * 8 - 1) / (4LL * iters * 8));
+        const dim3 lgrid((unsigned)(nch * (d->C / BWD_SLAB)));
+        const bool dropl = d->drop_p > 0.f;
+#define W2L_APPL(A, D) hipLaunchKernelGGL((bn_bwd_apply_loop_kernel<A, D>), lgrid, dim3(256), 0, (hipStream_t)stream, *d, *g1, partial, nrows, sums, (bf16_raw*)dy_hi, halo, inv_keep, amax, iters)
+        switch (d->act) {
+            case 1: if (dropl) W2L_APPL(1, true); else W2L_APPL(1, false); break;
+            case 2: if (dropl) W2L_APPL(2, true); else W2L_APPL(2, false); break;
+            default: if (dropl) W2L_APPL(0, true); else W2L_APPL(0, false); break;
+        }
+#undef W2L_APPL
+        W2L_CHECK_LAUNCH();
+        return 0;
+    }
     const int U = amax ? 4 : (d->C <= 384 ? 2 : 1);
     const int nchunks = (int)((rows + 4 * U * 8 - 1) / (4 * U * 8));
-    const float inv_keep = 1.f / (1.f - d->drop_p);
-    if (U == 4)
-        hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<4>, dim3((unsigned)(nchunks * (d->C / BWD_SLAB))), dim3(256), 0, (hipStream_t)stream,
-                           *d, *g1, partial, nrows, sums, (bf16_raw*)dy_hi, halo, inv_keep, amax);
-    else if (U == 2)
-        hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<2>, dim3((unsigned)(nchunks * (d->C / BWD_SLAB))), dim3(256), 0, (hipStream_t)stream,
-                           *d, *g1, partial, nrows, sums, (bf16_raw*)dy_hi, halo, inv_keep, amax);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<1>, dim3((unsigned)(nchunks * (d->C / BWD_SLAB))), dim3(256), 0, (hipStream_t)stream,
-                           *d, *g1, partial, nrows, sums, (bf16_raw*)dy_hi, halo, inv_keep, amax);
+    const dim3 grid((unsigned)(nchunks * (d->C / BWD_SLAB)));
+#define W2L_APP(UU, A, D) hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<UU, A, D>), grid, dim3(256), 0, (hipStream_t)stream, *d, *g1, partial, nrows, sums, (bf16_raw*)dy_hi, halo, inv_keep, amax)
+#define W2L_APP_U(A, D) do { if (U == 4) W2L_APP(4, A, D); else if (U == 2) W2L_APP(2, A, D); else W2L_APP(1, A, D); } while (0)
+    const bool drop = d->drop_p > 0.f;
+    switch (d->act) {
+        case 1: if (drop) W2L_APP_U(1, true); else W2L_APP_U(1, false); break;
+        case 2: if (drop) W2L_APP_U(2, true); else W2L_APP_U(2, false); break;
+        default: if (drop) W2L_APP_U(0, true); else W2L_APP_U(0, false); break;
+    }
+#undef W2L_APP_U
+#undef W2L_APP
     W2L_CHECK_LAUNCH();
     return 0;
 }
