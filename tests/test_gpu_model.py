@@ -485,18 +485,20 @@ def test_trainer_fit_loop_and_checkpoint(tmp_path, defer, monkeypatch):
 _TRAINER_RUNS = {}
 
 
-def test_deferred_weight_gradients_fp8_and_jasper():
+def test_deferred_weight_gradients_fp8_and_jasper(monkeypatch):
     """the deferred mode on the other two engine paths: (a) ``precision: fp8`` with e4m3 weight gradients -- the held-back
     launch keeps dy's e4m3 copy and its device-side scale alive until the next forward pass; (b) a Jasper stack whose top
     units carry a residual 1x1 branch (both convolutions of the last unit are deferred).  Same parameters after three steps as
-    the plain FusedSGD step on an identical model."""
+    the plain FusedSGD step on an identical model.  (The BatchNorm sums take their bit-reproducible kernels here: with the
+    atomic ones, one run in a few dozen amplified a last-bit difference through the e4m3 copies to 3e-3 of scale.)"""
     from gpu_helpers import build_jasper
+    _bit_reproducible_engine(monkeypatch)
     from oracle import w2l_oracle as O
     from wav2letter_pytorch_amd import engine as E
     from wav2letter_pytorch_amd.optim import FusedSGD
     kw = dict(lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-3)
 
-    def run(models, batch, tol=1e-4):
+    def run(models, batch, tol=1e-4, chaotic=False):
         x, il, tg, tl = batch
         opts = []
         for i, m in enumerate(models):
@@ -505,26 +507,47 @@ def test_deferred_weight_gradients_fp8_and_jasper():
             if i == 0:
                 o.defer_wgrad(m, 2)
             opts.append(o)
-        for it in range(3):
+
+        def step():
             for m, o in zip(models, opts):
                 o.zero_grad(set_to_none=True)
                 out, ol = m(x.cuda(), il)
                 m.criterion(out.transpose(0, 1), tg, ol, tl).backward()
                 o.step()
-        for o in opts:
-            o.join()
-        assert models[0].engine().defer_wgrad == 2
-        for (k, pa), (_, pb) in zip(models[0].named_parameters(), models[1].named_parameters()):
-            assert scale_err(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()) < tol, k
+
+        def worst():
+            for o in opts:
+                o.join()
+            assert models[0].engine().defer_wgrad == 2
+            errs = {k: scale_err(pa.detach().cpu().numpy(), pb.detach().cpu().numpy())
+                    for (k, pa), (_, pb) in zip(models[0].named_parameters(), models[1].named_parameters())}
+            k = max(errs, key=errs.get)
+            return k, errs[k]
+
+        step()
+        if chaotic:
+            # fp8: split weight gradients add their pieces with fp32 atomics, and from the SECOND forward on a last-bit difference
+            # in a weight can move its e4m3 copy by a whole step -- two identical PLAIN models then end 1e-2 of scale apart after
+            # three steps in one run out of three (tools/probe/dbg_fp8_defer2.py).  So the exact comparison is made where no
+            # such forward has happened yet: one step each, then ONE MORE FORWARD of the deferred model -- at whose start its
+            # held-back gradients (dy's e4m3 copy and scale kept alive since the backward) are launched and applied
+            assert len(models[0].engine()._deferred) == 2
+            models[0](x.cuda(), il)
+            assert not models[0].engine()._deferred
+            k, e = worst()
+            assert e < tol, (k, e)
+        step()
+        step()
+        k, e = worst()
+        assert e < (0.25 if chaotic else tol), (k, e)          # (chaotic: a guard against garbage only)
+        assert all(torch.isfinite(p).all() for m in models for p in m.parameters())
 
     layers = [(128, 11, 2, 1, 0.0), (256, 13, 1, 1, 0.0), (128, 5, 1, 2, 0.0)]
     sd = O.init_wav2letter_state(layers, seed=91)
     E.FP8_DGRAD = E.FP8_WGRAD = '1'
     try:
-        # (fp8: the two models' split weight gradients add their pieces in different orders -- fp32 atomics --, and a last-bit
-        # difference in a weight can move its e4m3 copy by a whole step of 1/8: measured 0.5e-4 .. 1.2e-4 of scale after three
-        # steps, run to run; the bf16 Jasper leg below stays at 1e-4)
-        run([build_w2l(layers, sd, 'fp8').train() for _ in range(2)], O.synthetic_batch(4, 300, seed=92, s_lo=8, s_hi=25), tol=5e-4)
+        run([build_w2l(layers, sd, 'fp8').train() for _ in range(2)], O.synthetic_batch(4, 300, seed=92, s_lo=8, s_hi=25), tol=2e-5,
+            chaotic=True)
     finally:
         E.FP8_DGRAD = E.FP8_WGRAD = 'auto'
     z = load('jasper_dense.npz')
