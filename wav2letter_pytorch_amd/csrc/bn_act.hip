@@ -129,6 +129,13 @@ __device__ __forceinline__ float activate(float z, int act) {
     if (act == 2) return fmaxf(z, 0.f);
     return z;
 }
+// (the apply kernels take the activation as a template parameter: a run-time switch costs them scalar branches per element)
+template <int ACT>
+__device__ __forceinline__ float activate_t(float z) {
+    if (ACT == 1) return fminf(fmaxf(z, 0.f), 20.f);
+    if (ACT == 2) return fmaxf(z, 0.f);
+    return z;
+}
 // gradient gate: torch.clamp passes 1 on the CLOSED interval [0,20]; ReLU passes on z > 0
 __device__ __forceinline__ bool act_pass(float z, int act) {
     if (act == 1) return z >= 0.f && z <= 20.f;
@@ -165,7 +172,7 @@ __device__ __forceinline__ uint2 quant8_e4m3(const float v[8], float scale) {
 // ---------------------------------------------------------------- forward
 // out_q (optional): the same padded activation once more as e4m3 bytes, a * q_scale -- the operand of the next
 // convolution's forward pass in fp8 mode (w2l_conv1d_igemm_fp8); the bf16 copy stays the weight gradient's operand
-template <bool F32, bool HAS2>
+template <bool F32, bool HAS2, int ACT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(w2l_bnact_t d, bf16_raw* out_hi, bf16_raw* out_lo, int R,
                                                           int pad_l, int pad_r, int pad_mode, uint32_t thresh,
                                                           float inv_keep, uint8_t* out_q, float q_scale, float inv_g) {
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(w2l_bnact_t d, bf16_raw
             preact8<F32, HAS2>(d, c1, c2, (int64_t)n * d.T + t, cg, G, z, y1, y2v, thresh, inv_keep, /*gen_mask=*/true,
                          /*write_mask=*/r - pad_l == t);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = activate(z[j], d.act);
+            for (int j = 0; j < 8; ++j) a[j] = activate_t<ACT>(z[j]);
         }
         store8_split(out_hi, out_lo, (int64_t)orow * d.C + cg * 8, a);
         if (out_q) {
@@ -255,7 +262,7 @@ __host__ __device__ inline int fwd_rows_per_block(int64_t rows, int C) {
     return (int)nb * batch;
 }
 
-template <bool HAS2>
+template <bool HAS2, int ACT>
 __global__ __launch_bounds__(256) void bn_act_fwd_fin_kernel(w2l_bnact_t d, FinBranch f1, FinBranch f2, bf16_raw* out_hi, int R,
                                                               int pad_l, int pad_r, int pad_mode, uint32_t thresh, float inv_keep,
                                                               uint8_t* out_q, float q_scale, int rpb) {
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_fin_kernel(w2l_bnact_t d, FinB
                 for (int j = 0; j < 8; ++j) z[j] = (bits >> j) & 1u ? z[j] * inv_keep : 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = activate(z[j], d.act);
+            for (int j = 0; j < 8; ++j) a[j] = activate_t<ACT>(z[j]);
         }
         store8_split(out_hi, nullptr, q * d.C + c, a);
         if (out_q) {
@@ -1331,13 +1338,15 @@ extern "C" int w2l_bn_act_fwd_q(const w2l_bnact_t* d, void* out_hi, void* out_lo
     W2L_CHECK_ARG(per_utt < (1 << 24) && d->N <= 65535, "bn_act_fwd: more than 2^24 channel groups per utterance or N > 65535");
     const dim3 grid((unsigned)((per_utt + 255) / 256), (unsigned)d->N);
     const float inv_g = 1.f / (float)(d->C / 8);
-#define W2L_FWD(F, H)                                                                                        \
-    hipLaunchKernelGGL((bn_act_fwd_kernel<F, H>), grid, dim3(256), 0, (hipStream_t)stream, *d,                  \
+#define W2L_FWD_A(F, H, A)                                                                                   \
+    hipLaunchKernelGGL((bn_act_fwd_kernel<F, H, A>), grid, dim3(256), 0, (hipStream_t)stream, *d,               \
                        (bf16_raw*)out_hi, (bf16_raw*)out_lo, out_rows, pad_l, pad_r, pad_mode, thresh, inv_keep,    \
                        (uint8_t*)out_q, q_scale, inv_g)
+#define W2L_FWD(F, H) do { if (d->act == 1) W2L_FWD_A(F, H, 1); else if (d->act == 2) W2L_FWD_A(F, H, 2); else W2L_FWD_A(F, H, 0); } while (0)
     if (d->y_f32) { if (d->y2) W2L_FWD(true, true); else W2L_FWD(true, false); }
     else { if (d->y2) W2L_FWD(false, true); else W2L_FWD(false, false); }
 #undef W2L_FWD
+#undef W2L_FWD_A
     W2L_CHECK_LAUNCH();
     return 0;
 }
@@ -1370,12 +1379,13 @@ extern "C" int w2l_bn_act_fwd_fin(const w2l_bnact_t* d, const w2l_bnfin_t* f1, c
     const int rpb = fwd_rows_per_block(rows, d->C);
     const int nchunks = (int)((rows + rpb - 1) / rpb);
     const dim3 grid((unsigned)(nchunks * (d->C / BWD_SLAB)));
-    if (d->y2)
-        hipLaunchKernelGGL((bn_act_fwd_fin_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, *d, b[0], b[1], (bf16_raw*)out_hi,
-                           out_rows, pad_l, pad_r, pad_mode, thresh, inv_keep, (uint8_t*)out_q, q_scale, rpb);
-    else
-        hipLaunchKernelGGL((bn_act_fwd_fin_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, *d, b[0], b[1], (bf16_raw*)out_hi,
-                           out_rows, pad_l, pad_r, pad_mode, thresh, inv_keep, (uint8_t*)out_q, q_scale, rpb);
+#define W2L_FIN_A(H, A)                                                                                                      \
+    hipLaunchKernelGGL((bn_act_fwd_fin_kernel<H, A>), grid, dim3(256), 0, (hipStream_t)stream, *d, b[0], b[1], (bf16_raw*)out_hi, \
+                       out_rows, pad_l, pad_r, pad_mode, thresh, inv_keep, (uint8_t*)out_q, q_scale, rpb)
+#define W2L_FIN(H) do { if (d->act == 1) W2L_FIN_A(H, 1); else if (d->act == 2) W2L_FIN_A(H, 2); else W2L_FIN_A(H, 0); } while (0)
+    if (d->y2) W2L_FIN(true); else W2L_FIN(false);
+#undef W2L_FIN
+#undef W2L_FIN_A
     W2L_CHECK_LAUNCH();
     return 0;
 }
