@@ -13,10 +13,13 @@
 namespace {
 
 // ---------------------------------------------------------------- Philox4x32-10
+#ifndef W2L_PHILOX_ROUNDS
+#define W2L_PHILOX_ROUNDS 10           // (experiment switch: 7, the fewest rounds that pass the Crush batteries, measured -0.6 us of 14.9)
+#endif
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t out[4]) {
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
+    for (int i = 0; i < W2L_PHILOX_ROUNDS; ++i) {
         // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a mul_lo / mul_hi pair: the multiplies are the
         // forward BN-apply kernel's longest dependent chain
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
