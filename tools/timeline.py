@@ -18,9 +18,9 @@ MFMA = ('conv_igemm', 'conv_wgrad')          # (w2l_wgrad3* -- the three-tap cod
 def family(name):
     if 'w2l_wgrad3' in name:
         return 'conv_wgrad'
-    if 'bn_bwd_reduce_fast' in name:             # (round 5's two-launch backward chain)
+    if 'bn_bwd_reduce_fast' in name or 'bn_bwd_reduce_loop' in name:      # (round 5's two-launch backward chain, one-shot / looped)
         return 'bn_act_bwd_reduce'
-    if 'bn_bwd_apply_fast' in name:
+    if 'bn_bwd_apply_fast' in name or 'bn_bwd_apply_loop' in name:
         return 'bn_act_bwd_apply'
     for key in ('conv_igemm_fp8', 'conv_wgrad_fp8', 'conv_igemm', 'conv_wgrad', 'bn_act_fwd', 'bn_act_bwd_reduce', 'bn_act_bwd_apply',
                 'bn_bwd_finalize', 'bn_finalize', 'sgd_pack', 'ctc_', 'log_softmax', 'nct_to_ntc', 'pad_cast', 'quantize', 'dw_',
