@@ -329,6 +329,10 @@ extern "C" int64_t w2l_wgrad_workspace_bytes(int Cin, int Cout, int Kw) {
 // three taps with AGPR accumulators)
 static int wgrad_dispatch(const WgradParams& p, dim3 grid, bool tg2, bool m32, bool taps3, int kwb, int stride, size_t lds, void* stream) {
     dim3 block(tg2 ? 512 : 256);
+    // experiment switch: W2L_WGRAD_LDS_PAD=<bytes> of unused dynamic LDS per block of the two-tap kernels -- with > 40 KB only ONE
+    // four-wave block fits a CU, which leaves half its register file to the main stream's kernels
+    static const size_t lds_pad = getenv("W2L_WGRAD_LDS_PAD") ? (size_t)atoll(getenv("W2L_WGRAD_LDS_PAD")) : 0;
+    if (!taps3 && lds + lds_pad <= 160 * 1024) lds += lds_pad;
 #define W2L_WGRAD_LAUNCH(K, S1_, SK_)                                                                     \
     do {                                                                                                  \
         W2L_CHECK_HIP(w2l_allow_big_lds((const void*)conv_wgrad_kernel<K, S1_, SK_>));                    \
