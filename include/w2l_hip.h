@@ -220,6 +220,11 @@ int w2l_wgrad_group_tiles(int Cin, int Cout, int Kw, int form);
  * the library); a combination the shape does not admit falls back to the nearest built variant) for launches made by the
  * calling thread (thread-local, like w2l_conv_force_tile_config). */
 void w2l_wgrad_force_plan(int splits, int order);
+/* W2L_DETERMINISTIC=1 (engine.py): on != 0 makes every later launch of w2l_conv1d_wgrad_ws (and w2l_wgrad_needs_zero_x) ignore
+ * plan bit 6, i.e. a split reduction handed a workspace goes through slabs summed in a fixed order whatever the measured plan
+ * (or a plan cache written by a default-mode run) says: bit-reproducible weight gradients.  Process-wide, not thread-local:
+ * the weight gradients are launched from autograd's worker threads. */
+void w2l_wgrad_deterministic(int on);
 
 /* Autotune of the split-K factor and block order, like w2l_conv1d_igemm_tune (SYNCHRONISING, warm-up only); dw_scratch is a
  * throw-away [Kw][Cout][Cin] fp32 buffer.  Call before w2l_wgrad_needs_zero() / w2l_conv1d_wgrad for the shape. */

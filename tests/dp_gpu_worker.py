@@ -22,6 +22,8 @@ def main_steps(out_path, defer, steps=3):
     torch.cuda.set_device(0)
     rank, world = init_process_group_from_env(backend='gloo')
     layers = [(128, 11, 2, 1, 0.0), (256, 13, 1, 1, 0.0), (128, 29, 1, 2, 0.0)]
+    if os.environ.get('W2L_TEST_GROUP_STACK'):        # two consecutive stride-1, dilation-1 layers: a group of the backward pass
+        layers = [(128, 11, 2, 1, 0.0), (256, 13, 1, 1, 0.0), (256, 13, 1, 1, 0.0), (128, 29, 1, 2, 0.0)]
     sd = O.init_wav2letter_state(layers, seed=60 + rank)
     model = build_w2l(layers, sd, 'bf16').train()
     broadcast_parameters(model)
@@ -40,7 +42,8 @@ def main_steps(out_path, defer, steps=3):
         opt.step()
     opt.join()
     torch.cuda.synchronize()
-    np.savez(out_path + f'.rank{rank}.npz', held=np.array(held),
+    grouped = sorted(set(v[0] for v in getattr(model.engine(), '_wg_seen', {}).values()))
+    np.savez(out_path + f'.rank{rank}.npz', held=np.array(held), grouped=np.array(grouped),
              **{'p/' + k: v.detach().cpu().numpy() for k, v in model.named_parameters()})
     dist.barrier()
     dist.destroy_process_group()

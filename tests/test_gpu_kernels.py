@@ -500,6 +500,66 @@ def test_conv_wgrad_every_plan(L, Kw, s, d):
             L.lib.w2l_wgrad_force_plan(0, -1)
 
 
+def test_wgrad_slabs_stress_bit_exact(L):
+    """the slab + ticket reduction of the split weight gradients (classic split and dealt stream-K) under load: 240 launches
+    back to back on a side stream, alternating between two inputs so that every launch re-writes every slab with OTHER
+    data, while the main stream streams 256 MB copies through HBM and the L2s -- every result must equal, bit for bit, what
+    the same plan produced alone (conv_wgrad_kernel.h: the slabs move through sc1 = agent-scope accesses only; a stale line
+    would show as a wrong tile).  Also: w2l_wgrad_deterministic(1) strips plan bit 6 (atomics although a workspace is given)."""
+    N, Cin, Cout, T, Kw, d = 4, 256, 384, 500, 7, 1
+    g = torch.Generator().manual_seed(5)
+    hb = (Kw - 1) * d
+    Tout = T
+    ha = max(hb, (Tout + 63) // 64 * 64 - Tout)
+    xh = torch.randn(N, T + hb, Cin, generator=g).to(torch.bfloat16).cuda()
+    dys = [torch.zeros(N, hb + Tout + ha, Cout), torch.zeros(N, hb + Tout + ha, Cout)]
+    for t in dys:
+        t[:, hb:hb + Tout] = torch.randn(N, Tout, Cout, generator=g)
+    dys = [t.to(torch.bfloat16).cuda() for t in dys]
+    rows, drows = xh.shape[1], dys[0].shape[1]
+    ws = torch.zeros(max(int(L.lib.w2l_wgrad_workspace_bytes(Cin, Cout, Kw)), int(L.lib.w2l_wgrad_dealt_workspace_bytes(Cin, Cout, Kw))),
+                     dtype=torch.uint8, device='cuda')
+    side = torch.cuda.Stream()
+    big_a = torch.randn(64 << 20, device='cuda')
+    big_b = torch.empty_like(big_a)
+
+    def launch(dy, dw, stream):
+        L.check(L.lib.w2l_conv1d_wgrad_ws(C.c_void_p(dy.data_ptr() + hb * Cout * 2), drows * Cout, L.ptr(xh), rows * Cin, N * rows,
+                                          L.ptr(dw), N, Cin, Cout, Tout, Kw, 1, d, 0, L.ptr(ws), ws.numel(), C.c_void_p(stream.cuda_stream)))
+
+    for splits, order in ((5, 1), (7, 17), (256, 33), (256, 49)):
+        L.lib.w2l_wgrad_force_plan(splits, order)
+        try:
+            assert L.lib.w2l_wgrad_needs_zero_x(N, Cin, Cout, Tout, Kw, 1, d, ws.numel()) == 0, (splits, order)
+            want = []
+            for dy in dys:
+                dw = torch.full((Kw, Cout, Cin), float('nan'), device='cuda')
+                launch(dy, dw, torch.cuda.current_stream())
+                torch.cuda.synchronize()
+                want.append(dw)
+            assert not torch.equal(want[0], want[1])
+            outs = [torch.full((Kw, Cout, Cin), float('nan'), device='cuda') for _ in range(60)]
+            torch.cuda.synchronize()
+            for i, dw in enumerate(outs):
+                launch(dys[i & 1], dw, side)               # no synchronisation between launches: one workspace, one stream
+                if i % 4 == 0:
+                    big_b.copy_(big_a)                     # main stream: 512 MB of HBM traffic beside them
+            torch.cuda.synchronize()
+            for i, dw in enumerate(outs):
+                assert torch.equal(dw, want[i & 1]), (splits, order, i)
+            assert not ws[:65536].any(), (splits, order)
+        finally:
+            L.lib.w2l_wgrad_force_plan(0, -1)
+    L.lib.w2l_wgrad_force_plan(3, 64 | 1)
+    try:
+        assert L.lib.w2l_wgrad_needs_zero_x(N, Cin, Cout, Tout, Kw, 1, d, ws.numel()) == 1
+        L.lib.w2l_wgrad_deterministic(1)
+        assert L.lib.w2l_wgrad_needs_zero_x(N, Cin, Cout, Tout, Kw, 1, d, ws.numel()) == 0
+    finally:
+        L.lib.w2l_wgrad_deterministic(0)
+        L.lib.w2l_wgrad_force_plan(0, -1)
+
+
 @pytest.mark.parametrize('d', [1, 2, 4])
 def test_conv_wgrad_group_launch(L, d):
     """w2l_conv1d_wgrad_group: the weight gradients of several layers (different Cin / Cout / Kw, same N, Tout, dilation) in ONE

@@ -666,7 +666,9 @@ def test_deterministic_mode_is_bit_reproducible(monkeypatch):
         torch.cuda.synchronize()
         return [p.grad.detach().clone() for p in model.parameters()]
 
-    a, b, c = grads(True), grads(True), grads(False)
+    # the default-mode step runs FIRST: its measured plans (classic splits that add atomically although a workspace is at
+    # hand, plan bit 6) are in the plan table when the deterministic steps run -- they must not bring the atomics back
+    c, a, b = grads(False), grads(True), grads(True)
     for ga, gb, gc in zip(a, b, c):
         assert torch.equal(ga, gb)
         # (the default path also sums the BatchNorm statistics / backward sums with fp32 atomics -- the folded finalize, the
@@ -841,6 +843,37 @@ def test_data_parallel_deferred_wgrad_two_ranks(tmp_path):
     for k in [k for k in res[2][0].files if k.startswith('p/')]:
         np.testing.assert_array_equal(res[2][0][k], res[2][1][k])
         assert scale_err(res[2][0][k], res[0][0][k]) < 5e-5, k
+
+
+def test_data_parallel_grouped_wgrad_two_ranks(tmp_path):
+    """grouped weight gradients (w2l_conv1d_wgrad_group: ONE side-stream launch for two layers) under data parallelism: the
+    members' gradients are handed to the reducer on the stream that wrote them (its ordering event must cover the group
+    kernel).  Two gloo ranks on cuda:0, three steps, once with backward-order layers 2 and 3 forced into a group
+    (W2L_WGRAD_GROUPS='2,3', no autotune so the group launch is what runs) and once one by one: replicas bit-identical across
+    the ranks, both modes on the same parameters."""
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for groups in ('2,3', '0'):
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        base = str(tmp_path / f'dpg{groups[0]}')
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                       W2L_AUTOTUNE='0', W2L_WGRAD_GROUPS=groups, W2L_TEST_GROUP_STACK='1')
+            procs.append(subprocess.Popen([sys.executable, os.path.join(here, 'dp_gpu_worker.py'), base, '0'], env=env))
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+        res[groups] = [np.load(base + f'.rank{r}.npz') for r in range(2)]
+    assert len(res['2,3'][0]['grouped']) == 1 and len(res['0'][0]['grouped']) == 0
+    for k in [k for k in res['0'][0].files if k.startswith('p/')]:
+        np.testing.assert_array_equal(res['2,3'][0][k], res['2,3'][1][k])
+        assert scale_err(res['2,3'][0][k], res['0'][0][k]) < 5e-5, k
 
 
 def test_bench_two_rank_command_line(tmp_path):

@@ -82,6 +82,7 @@ _SIGNATURES = {
     'w2l_conv_force_tile_config': (None, [c_i]),
     'w2l_conv_force_fp8_config': (None, [c_i]),
     'w2l_wgrad_force_plan': (None, [c_i, c_i]),
+    'w2l_wgrad_deterministic': (None, [c_i]),
     'w2l_wgrad_needs_zero': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'w2l_conv1d_wgrad': (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'w2l_conv1d_wgrad_ws': (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p]),

@@ -19,6 +19,7 @@
 #include "../../include/w2l_hip.h"
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -87,6 +88,10 @@ constexpr int kOrderMask = 127;
 constexpr int kDealtFallbackSplits = 2;
 constexpr int kResidentBlocks = 512;       // 256 CUs x 2 blocks (LDS and registers both allow two)
 thread_local bool g_last_dealt = false;    // did the calling thread's last launch take the dealt path? (the tuner asks)
+// w2l_wgrad_deterministic(1): plans that add their partial tiles with fp32 atomics although a workspace is at hand (bit 6) lose
+// that bit when resolved -- a plan cache written by a default-mode run must not switch atomics back on in a run that asked
+// for bit-reproducible gradients.  Process-wide (the weight gradients are launched from autograd's worker thread).
+std::atomic<int> g_deterministic{0};
 
 // second-segment blocks of a dealt launch, longest first (WgradParams::dealt_perm); cached per geometry: 21 launches per step
 // must not sort 512 ranges each
@@ -179,6 +184,8 @@ int plan_splits(int N, int Cin, int Cout, int Tout, int Kw, int* tsteps_out, int
 }
 
 }  // namespace
+
+extern "C" void w2l_wgrad_deterministic(int on) { g_deterministic.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 // testing / profiling hook: pin the split count (0 = automatic) and the block order (-1 = automatic)
 extern "C" void w2l_wgrad_force_plan(int splits, int order) {
@@ -275,6 +282,7 @@ static WgradResolved wgrad_resolve(int N, int Cin, int Cout, int Tout, int Kw, i
     WgradResolved r;
     r.order = 0;
     r.splits = plan_splits(N, Cin, Cout, Tout, Kw, &r.tsteps, &r.order);
+    if (g_deterministic.load(std::memory_order_relaxed)) r.order &= ~kAtomicSplit;
     const int order = r.order;
     int G = 0;
     if ((order & kDealt) && !(order & kStreamK)) { G = r.splits; r.splits = kDealtFallbackSplits; }

@@ -660,6 +660,13 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, char* smem
     // to the tile's agent-scope ticket, and the block whose add came last reads only behind another barrier.  No release
     // fence (a buffer_wbl2 of the XCD's whole L2 per block: 2-7 us each with a freshly written 192 KB slab in it -- rounds
     // 2-4 paid it on every partial tile) and no acquire (a buffer_inv per tile).  Correct wherever the tile's blocks ran.
+    // The ISA guarantee relied on (gfx942 / gfx950 memory model, LLVM AMDGPUUsage "Memory Model gfx942"): an access carrying
+    // sc1 IS an agent-scope access -- it is the code LLVM itself emits for `load / store atomic monotonic syncscope("agent")`
+    // (global / buffer load sc1=1, store sc1=1): the store is written through to the level all XCDs share, the load is served
+    // from that level, never from a non-coherent line.  A fence's buffer_wbl2 / buffer_inv exist to make OTHER, plain accesses
+    // visible / fresh; there are none here -- every slab byte moves through sc1 instructions, ordered against the ticket by
+    // s_waitcnt vmcnt(0) + the block barrier on both sides.  tests/test_gpu_kernels.py::test_wgrad_slabs_stress_bit_exact runs
+    // hundreds of back-to-back split launches beside main-stream traffic and compares them bit for bit.
     if (!SK && p.slabs != nullptr && nsplit > 1) {            // (the stream-K launch has no workspace form)
         constexpr int TILE_F = KWBLK * BM * BNC;
         const int tid_t = tid & 255;                   // thread inside its tap group

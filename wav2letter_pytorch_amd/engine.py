@@ -361,6 +361,7 @@ _retired_ws = []                   # outgrown workspaces (grown only while shape
 # W2L_DETERMINISTIC=1: split weight-gradient reductions go through slabs summed in a fixed order instead of fp32 atomics
 # (bit-reproducible gradients, no zero fills) -- measured 6 % slower on the Wav2Letter table (943 vs 1004 TFLOP/s), so opt-in
 DETERMINISTIC_WGRAD = os.environ.get('W2L_DETERMINISTIC', '0') == '1'
+lib.w2l_wgrad_deterministic(int(DETERMINISTIC_WGRAD))      # (a default-mode plan cache must not bring the atomics back)
 # W2L_DEALT_WGRAD=0: no workspace for the weight gradients in the default mode, i.e. the dealt stream-K plans (include/w2l_hip.h)
 # are neither measured nor run (round 4's plan space; the A/B switch of profiles/r05_step_ab.txt)
 DEALT_WGRAD = os.environ.get('W2L_DEALT_WGRAD', '1') == '1'
@@ -623,6 +624,13 @@ class StackEngine:
     def forward(self, x: torch.Tensor, lens: Optional[torch.Tensor], training: bool, softmax_mode: int = 0,
                 want_input_grad: bool = False):
         """x fp32 [N, C, T] on device -> (out fp32 [N, T', n_labels], lens_out or None)."""
+        try:
+            return self._forward(x, lens, training, softmax_mode, want_input_grad)
+        finally:
+            lib.w2l_conv_stats_mode(0)      # thread-local library state: never left in slot mode, whatever was raised
+            self._stat_pool = None
+
+    def _forward(self, x, lens, training, softmax_mode, want_input_grad):
         _lib.require_device(x)
         global _dropout_calls
         if self._deferred:
@@ -1022,6 +1030,13 @@ class StackEngine:
     def backward(self, ctx, g_out: torch.Tensor):
         """g_out: gradient wrt the (log_)softmax output [N, T', n_labels].  Returns the list of
         parameter gradients in ``self.parameters()`` order."""
+        try:
+            return self._backward(ctx, g_out)
+        finally:
+            lib.w2l_conv_stats_mode(0)      # (thread-local: this -- the autograd -- thread's)
+            self._slot_pool = None
+
+    def _backward(self, ctx, g_out: torch.Tensor):
         acts: List[Act] = ctx['acts']
         out = ctx['out']
         N = out.shape[0]
@@ -1048,6 +1063,7 @@ class StackEngine:
             if need:
                 self._slot_pool = [torch.zeros(need, dtype=torch.float32, device=dev), 0, {}]
         lib.w2l_conv_stats_mode(STAT_SLOTS if self._slot_pool is not None else 0)
+        lib.w2l_wgrad_deterministic(int(DETERMINISTIC_WGRAD))
         act_grads: List[List[tuple]] = [[] for _ in acts]
         if self.head is None:
             # open stack: the caller's gradient wrt the fp32 [N, C, T'] result becomes the (unpadded, fp32) gradient source
@@ -1377,8 +1393,9 @@ class StackEngine:
         that unit's convolution).  All of them at the start (round 4) run as one burst of long-lived full-chip kernels in
         the first ~3 ms of the forward -- the BatchNorm chains of the early, narrow layers are over-covered, those of the wide
         layers at the end (and the classifier / CTC tail) meet no matrix work at all -- and the forward's small dependent
-        kernels queue behind whole rounds of their blocks.  W2L_DEFER_SPREAD: 'start' = round 4; 'la:K' = K units ahead of
-        the layer whose update it carries (just in time, with margin); 'even' (default) = evenly over the units in front of
+        kernels queue behind whole rounds of their blocks.  W2L_DEFER_SPREAD: 'start' (the default: where a held-back gradient is
+        launched inside the forward pass measured +-0.02 ms, profiles/r05_step_ab.txt) = round 4; 'la:K' = K units ahead of
+        the layer whose update it carries (just in time, with margin); 'even' = evenly over the units in front of
         the first deferred layer.  A gradient is always launched strictly before its own layer's convolution."""
         mode = DEFER_SPREAD
         uis = []
@@ -1563,6 +1580,7 @@ class StackEngine:
         for gi, g in enumerate(groups):
             for i in g:
                 self._wg_of[id(convs[i])] = (gi, len(g))
+        self._wg_seen = dict(self._wg_of)          # (what the last backward pass planned: read by tests)
 
     def _wgrad_single(self, r, grads, sink=None):
         """one member of a group through the ordinary path (its own measured plan)"""
@@ -1598,13 +1616,17 @@ class StackEngine:
                 self._side = _side_stream(dev, main)
             fork = (main, self._side)
         dws = self._wgrad_group_launch(recs, form, fork)
-        for r, dw in zip(recs, dws):
-            w = r['conv'].weight
-            cout, cin, kw = w.shape
-            g = dw.permute(1, 2, 0)                     # logical [CoutP, CinP, Kw]
-            if not (r['pk'].coutp == cout and r['pk'].cinp == cin):
-                g = g[:cout, :cin, :]
-            self._set(grads, w, g, storage=dw)
+        # the gradients are handed over ON THE STREAM THAT WROTE THEM: a data-parallel reducer (distributed.GradReducer.on_grad)
+        # orders its all-reduce behind an event it records on the current stream -- on the caller's stream that event would
+        # say nothing about the group kernel, and the collective could read (and overwrite in place) dW while it is written
+        with torch.cuda.stream(fork[1]) if fork is not None else _nullctx():
+            for r, dw in zip(recs, dws):
+                w = r['conv'].weight
+                cout, cin, kw = w.shape
+                g = dw.permute(1, 2, 0)                     # logical [CoutP, CinP, Kw]
+                if not (r['pk'].coutp == cout and r['pk'].cinp == cin):
+                    g = g[:cout, :cin, :]
+                self._set(grads, w, g, storage=dw)
 
     def _wgrad_group_launch(self, recs, form, fork):
         dev = recs[0]['dy_hi'].device
@@ -1614,6 +1636,9 @@ class StackEngine:
         for it, r in zip(items, recs):
             conv, pk, src, halo = r['conv'], r['pk'], r['src'], r['halo']
             row_off = src.pad_l - conv.pad_l
+            # (a group launch stores whole tiles: a zero-filled buffer optim.FusedSGD left on the weight is of no use here --
+            # dropped, so that it does not stay alive beside the gradient)
+            conv.weight.__dict__.pop('_w2l_dw_zeroed', None)
             dw = torch.empty(conv.kernel, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)      # (on the caller's stream)
             dws.append(dw)
             it.dy = r['dy_hi'].data_ptr() + halo * pk.coutp * 2
@@ -1814,17 +1839,19 @@ class StackEngine:
         rows_total = total - row_off
         ws = _splitk_workspace(dev, 1, pk.cinp, flat_rows)
         st = stream_ptr()
-        args = (dy_ptr, rows_total, ptr(pk.dgr_hi), ptr(dxp), ptr(partial), C.byref(d), conv.pad_l, conv.pad_r, conv.pad_mode,
-                per, pk.coutp, flat_rows, conv.kernel, conv.dilation)
+        tail = (C.byref(d), conv.pad_l, conv.pad_r, conv.pad_mode, per, pk.coutp, flat_rows, conv.kernel, conv.dilation)
+        args = (dy_ptr, rows_total, ptr(pk.dgr_hi), ptr(dxp), ptr(partial)) + tail
         if AUTOTUNE:
             key = ('dgrad+bn', pk.coutp, pk.cinp, flat_rows, conv.kernel, conv.dilation, dev.index)
             if key not in _tuned_shapes:
                 _tuned_shapes.add(key)
                 _tune_state['dirty'] = True
-                check(lib.w2l_conv1d_dgrad_bnreduce_tune_ws(*args, TUNE_REPS, ptr(ws), ws.numel(), st),
+                # the measuring launches ADD to slot rows: they get rows of their own -- the step's rows may already hold the
+                # sums another consumer of the same activation (a residual branch) has added
+                scratch = torch.zeros_like(partial) if slots else partial
+                check(lib.w2l_conv1d_dgrad_bnreduce_tune_ws(dy_ptr, rows_total, ptr(pk.dgr_hi), ptr(dxp), ptr(scratch), *tail,
+                                                            TUNE_REPS, ptr(ws), ws.numel(), st),
                       'w2l_conv1d_dgrad_bnreduce_tune_ws')
-                if slots:
-                    partial.zero_()             # (the measuring launches ADDED to the rows)
         with _timed('conv_igemm_kernel/dgrad+bnreduce', flops):
             check(lib.w2l_conv1d_dgrad_bnreduce_ws(*args, ptr(ws), ws.numel(), st), 'w2l_conv1d_dgrad_bnreduce_ws')
         if pool is not None and not slots:
