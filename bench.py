@@ -259,6 +259,14 @@ def main():
                     help='how far the host runs ahead of the GPU at four points of every step (stderr), then exit')
     ap.add_argument('--host-profile', action='store_true', help='cProfile of the host side of the step (stderr), then exit')
     ap.add_argument('--breakdown', action='store_true', help='print the per-kernel event timing table to stderr')
+    ap.add_argument('--through-trainer', action='store_true',
+                    help='the timed region (value, ms_per_step) runs the reference\'s loop body instead of the hand-rolled step: '
+                         'training_step on _collator\'s 6-tuple (host spectrograms and integer tensors, transcript strings), i.e. '
+                         'forward + CTC + per-step greedy decode + CER/WER + log_dict, then backward, optimizer step and the '
+                         'on_train_batch_end hook (base_asr_models.py:78-85 driven as train.py:34-37 drives it)')
+    ap.add_argument('--no-trainer-leg', action='store_true',
+                    help='skip the extra timed regions that put trainer_ms_per_step (and its synchronous-metrics "before" figure) '
+                         'into the record')
     args = ap.parse_args()
 
     L = _launcher()
@@ -338,7 +346,7 @@ def main():
         defer_k = args.defer_wgrad
         opt.defer_wgrad(model, defer_spec(defer_k))
 
-    def step():
+    def raw_step():
         opt.zero_grad(set_to_none=True)
         out, _ = model(x, lens_arg)
         loss = model.criterion(out.transpose(0, 1), tg_d, ol, tl_d)
@@ -346,6 +354,29 @@ def main():
         if not args.no_optimizer:
             opt.step()
         return loss
+
+    # ---- the reference's loop body (base_asr_models.py:78-85 as pytorch_lightning's fit loop drives it, train.py:34-37):
+    # _collator's 6-tuple -- spectrograms and integer tensors ON THE HOST (page-locked, as a DataLoader with pin_memory hands
+    # them over), transcripts as strings (the synthetic targets spelled with the model's labels) -- through training_step
+    # (forward, CTC, greedy decode + CER / WER of every batch, log_dict), backward, optimizer step, on_train_batch_end
+    labels = list(model.labels)
+    texts = tuple(''.join(labels[int(c)] for c in tg[n, : int(tl[n])]) for n in range(N))
+    x_host = x.detach().cpu().pin_memory()
+    batch6 = (x_host, il.to(torch.int32), tg.to(torch.int32), tl.to(torch.int32), tuple(f'synthetic_{n}.wav' for n in range(N)), texts)
+    model._optimizers = opt                       # what Trainer.fit sets: training_step reads the learning rate from it
+    trainer_step_no = [0]
+
+    def trainer_step():
+        opt.zero_grad(set_to_none=True)
+        loss = model.training_step(batch6, trainer_step_no[0])
+        loss.backward()
+        if not args.no_optimizer:
+            opt.step()
+        model.on_train_batch_end(loss, batch6, trainer_step_no[0])
+        trainer_step_no[0] += 1
+        return loss
+
+    step = trainer_step if args.through_trainer else raw_step
 
     if args.graph:
         from wav2letter_pytorch_amd.graph import GraphedTrainStep
@@ -359,6 +390,8 @@ def main():
         eager_step = step
 
     def fence():
+        if hasattr(model, 'resolve_metrics'):
+            model.resolve_metrics(wait_all=True)      # string metrics still to be scored belong to the steps just run
         if hasattr(opt, 'join'):
             opt.join()                    # updates still streaming on the optimizer's side stream belong to the step just run
         torch.cuda.synchronize()
@@ -492,11 +525,12 @@ def main():
         torch.cuda.synchronize()
         pstats.Stats(pr, stream=sys.stderr).sort_stats('tottime').print_stats(50)
         return
-    def timed_region():
+    def timed_region(fn=None):
         """EXACTLY --steps steps between two fences (barrier + device sync on both sides); the job is as fast as its slowest rank"""
+        fn = fn or step
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            loss_ = step()
+            loss_ = fn()
         fence()
         elapsed_ = time.perf_counter() - t0
         rank_ms_ = [elapsed_ / args.steps * 1e3]
@@ -510,6 +544,32 @@ def main():
 
     ms, rank_ms, loss = timed_region()
     value = world * N * T / (ms * 1e-3)
+
+    # ---- the same number of steps through the reference's loop body (see trainer_step above): what a train.py user gets.
+    # Two legs: as shipped (metrics enqueued in training_step, scored in on_train_batch_end) and -- the "before" figure -- with
+    # the reference's order restored (async_metrics = False: decode, CER / WER and float(loss) inside training_step, i.e.
+    # before backward() is enqueued).  Host enqueue time per step of each leg rides along.
+    trainer = None
+    if not args.no_trainer_leg and not args.graph and not args.no_optimizer:
+        trainer = {}
+        legs = (('raw_loop', raw_step, True),) if args.through_trainer else ()
+        legs += (('async_metrics', trainer_step, True), ('sync_metrics_before', trainer_step, False))
+        for name, fn, async_on in legs:
+            model.async_metrics = async_on
+            fn()
+            fn()
+            fence()
+            h0 = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            host_ms = (time.perf_counter() - h0) / args.steps * 1e3
+            fence()
+            t_ms, _, _ = timed_region(fn)
+            trainer[name] = {'ms_per_step': round(t_ms, 3), 'host_enqueue_ms_per_step': round(host_ms, 3)}
+        model.async_metrics = True
+        logged = {k: round(float(v), 6) for k, v in getattr(model, '_logged', {}).items()}
+        trainer['logged_last_step'] = logged
+        fence()
 
     # ---- exposed communication: the same step with the gradient reducer detached (no collectives), same run, per rank ----
     exposed_comm_ms = exposed_by_rank = solo_ms = None
@@ -668,7 +728,13 @@ def main():
             'metric': (f'audio-frames/sec/GPU (fwd+bwd+CTC), Wav2Letter 64-mel x 1000-frame {args.dtype}' if args.model == 'wav2letter'
                        else f'audio-frames/sec/GPU (fwd+bwd+CTC), Jasper 10x5 {args.dtype} (secondary workload)'),
             'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': round(ms, 3),
+            # the reference's loop body: training_step (forward + CTC + greedy decode + CER / WER + log_dict on a host batch) ->
+            # backward -> optimizer step -> on_train_batch_end, same steps, same fences (None: leg skipped)
+            'trainer_ms_per_step': (round(ms, 3) if args.through_trainer else
+                                    (trainer or {}).get('async_metrics', {}).get('ms_per_step')),
+            'trainer_loop': trainer,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': ('Jasper 10x5 (13 dense blocks, repeat 5, 322 M params), ' if args.model == 'jasper10x5' else '')
                                    + f'Wav2Letter mid_layers={args.mid_layers} (configuration/model/wav2letter.yaml table), ' * (args.model == 'wav2letter')
@@ -676,6 +742,7 @@ def main():
                                    f'N={N}/GPU x T={T} x 64 mel' + (' (ragged: lengths U{T/2..T}, frames counted at T)' if args.ragged else '')
                                    + ', dropout on, fwd+CTC+bwd'
                                    + ('' if args.no_optimizer else '+fused SGD(nesterov) step')
+                                   + (', through training_step (per-step greedy decode + CER/WER, host batch)' if args.through_trainer else '')
                                    + (', step replayed as a hipGraph' if args.graph else ''),
                        'global_batch': world * N, 'frames': T, 'parallelism': f'dp{world}',
                        'value_is': 'whole-job frames/s (per-GPU = value / n_gpus)', 'loss': round(float(loss.detach()), 4)},

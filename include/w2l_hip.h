@@ -436,6 +436,17 @@ int w2l_ctc_loss(const float* log_probs, const int32_t* targets, const int32_t* 
 int w2l_argmax(const float* probs, int64_t rows, int C, int32_t* idx, void* stream);
 /* host-side edit distance over int32 symbol arrays */
 int w2l_levenshtein_host(const int32_t* a_host, int na, const int32_t* b_host, int nb);
+/* ConvCTCASR.add_string_metrics (base_asr_models.py:53-69) for one batch in ONE host call (no device work, no interpreter
+ * lock held): idx int32 [N][T] = the step's argmax indices on the host, sizes[n] (NULL: T) the valid frames of utterance n.
+ * Greedy collapse as GreedyDecoder.process_string(remove_repetitions=True) (decoder.py:104-119: blanks dropped, a frame equal
+ * to the previous frame dropped), labels mapped through lut[n_labels] (one Unicode code point per label), then against the
+ * reference transcripts ref_cp[ref_off[n] .. ref_off[n+1]) (code points): CER numerator = edit distance with ' ' removed
+ * from both (decoder.py:51-63), denominator = len(expected without ' '); WER numerator = edit distance over the words of
+ * str.split() (decoder.py:31-49,65-66), denominator = the number of expected words.  totals[5] = {cer_err, cer_ref, wer_err,
+ * wer_ref, sum of decoded lengths}; hyp_cp (>= N*T ints) / hyp_off (N+1), both optional, receive the decoded code points. */
+int w2l_greedy_score_host(const int32_t* idx_host, int N, int T, const int32_t* sizes_host, int blank, const int32_t* lut,
+                          int n_labels, const int32_t* ref_cp, const int64_t* ref_off, int64_t* totals, int32_t* hyp_cp,
+                          int64_t* hyp_off);
 
 /* Novograd step of one conv weight (novograd.py:86-112) fused with the bf16 operand pack, tap-major [Kw][Cout][Cin] fp32
  * p / g / exp_avg like w2l_sgd_pack:  v = ||g||^2 on the first step (exp_avg_sq == 0), else beta2*v + (1-beta2)*||g||^2;

@@ -156,6 +156,83 @@ def test_decoder_host_logic_and_levenshtein():
     assert dec.cer('', 'abc') == 3 and dec.wer('a b', '') == 2
 
 
+def test_score_batch_equals_the_python_string_path():
+    """decoder.GreedyDecoder.score_batch (ONE host call: collapse + CER / WER totals, w2l_greedy_score_host) against the
+    reference-shaped Python path (convert_to_strings + cer_ratio / wer_ratio per utterance, decoder.py:31-66,104-119) on random
+    index matrices and transcripts: runs of blanks and repeats, ragged sizes, leading / double / trailing spaces, empty
+    decodes, empty transcripts, tabs inside a transcript (str.split() whitespace), the Hebrew label set (non-ASCII labels)"""
+    from wav2letter_pytorch_amd.data import label_sets
+    from wav2letter_pytorch_amd.decoder import GreedyDecoder
+    rng = np.random.default_rng(7)
+    for name in ('english_lowercase', 'hebrew'):
+        labels = label_sets.labels_map[name]
+        dec = GreedyDecoder(labels)
+        for trial in range(12):
+            n, t = int(rng.integers(1, 9)), int(rng.integers(1, 120))
+            # few distinct symbols -> many repeats; weight blank and space heavily
+            pool = np.array([0, 0, 0, len(labels) - 1, len(labels) - 1] + list(rng.integers(1, len(labels), 4)))
+            idx = pool[rng.integers(0, len(pool), (n, t))].astype(np.int32)
+            sizes = torch.from_numpy(rng.integers(0, t + 1, n).astype(np.int32)) if trial % 3 else None
+            texts = []
+            for i in range(n):
+                m = int(rng.integers(0, 40))
+                chars = [labels[int(c)] for c in pool[rng.integers(0, len(pool), m)] if c != 0]
+                txt = ''.join(chars)
+                if trial % 4 == 1 and txt:
+                    txt = txt[: len(txt) // 2] + '\t' + txt[len(txt) // 2:]
+                texts.append(txt)
+            if not any(t_.replace(' ', '') for t_ in texts):
+                texts[0] = labels[2] + ' ' + labels[3]
+            hyps, totals = dec.score_batch(torch.from_numpy(idx), sizes, texts)
+            want = [s_[0] for s_ in dec.convert_to_strings(idx, sizes, remove_repetitions=True)]
+            assert hyps == want
+            cer = [dec.cer_ratio(r, h) for r, h in zip(texts, want)]
+            wer = [dec.wer_ratio(r, h) for r, h in zip(texts, want)]
+            assert totals == (sum(e for e, _ in cer), sum(d for _, d in cer), sum(e for e, _ in wer), sum(d for _, d in wer))
+    # the known answer of unit_tests/decoder_test.py:40-42 through this path: all-blank frames decode to ''
+    dec = GreedyDecoder(['_', 'A', 'B', ' '])
+    hyps, totals = dec.score_batch(np.zeros((1, 2), dtype=np.int32), None, ['A B'])
+    assert hyps == [''] and totals == (2, 2, 2, 2)
+    with pytest.raises(Exception):
+        dec.score_batch(np.full((1, 2), 9, dtype=np.int32), None, ['A'])
+
+
+def test_dropin_module_names_resolve_in_a_fresh_interpreter():
+    """the reference's OWN module names (train.py:12-19, configuration/config.yaml:14-16, optimizer `_target_`s) with
+    ``dropin/`` on the path: `from wav2letter import Wav2Letter`, `from jasper import Jasper`, `import decoder`,
+    `import base_asr_models`, `import novograd`, `from data import label_sets`, and `_target_: decoder.GreedyDecoder` /
+    `novograd.Novograd` through config.instantiate -- in a subprocess, so nothing this test session imported can help"""
+    import subprocess
+    code = r"""
+import sys
+import torch
+from wav2letter import Wav2Letter, Conv1dBlock
+from jasper import Jasper, JasperBlock, MaskedConv1d
+import decoder, base_asr_models, novograd
+from data import label_sets
+from data.data_loader import SpectrogramDataset, BatchAudioDataLoader
+import wav2letter_pytorch_amd as pkg
+from wav2letter_pytorch_amd.config import instantiate
+assert Wav2Letter is pkg.Wav2Letter and Jasper is pkg.Jasper
+assert issubclass(Wav2Letter, base_asr_models.ConvCTCASR) and issubclass(Jasper, base_asr_models.ConvCTCASR)
+labels = label_sets.labels_map['english_lowercase']
+dec = instantiate({'_target_': 'decoder.GreedyDecoder', 'labels': labels})
+assert type(dec) is decoder.GreedyDecoder and dec.blank_index == 0 and dec.space_index == 28
+p = [torch.nn.Parameter(torch.zeros(3))]
+opt = instantiate({'_target_': 'novograd.Novograd', 'lr': 0.01}, params=p)
+assert type(opt) is novograd.Novograd and opt.param_groups[0]['lr'] == 0.01
+from wav2letter_pytorch_amd.defaults import wav2letter_model, jasper_model
+m = Wav2Letter(wav2letter_model(2))
+assert type(m.ctc_decoder) is decoder.GreedyDecoder and m.scaling_factor == 2
+j = Jasper(jasper_model(2))
+assert type(j.ctc_decoder) is decoder.GreedyDecoder and j.scaling_factor == 2
+print('dropin ok')
+"""
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, 'dropin'), ROOT]))
+    out = subprocess.run([sys.executable, '-c', code], env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0 and 'dropin ok' in out.stdout, out.stderr[-3000:]
+
+
 def test_config_loader_hydra_tree(tmp_path):
     """defaults list, `# @package model` groups, ${a.b} interpolation, key=value and group overrides
     (the structure of configuration/config.yaml:1-28, rebuilt here from Python dicts)"""

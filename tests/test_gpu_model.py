@@ -57,6 +57,12 @@ def check(errs, stats, precision, grad_tol=None):
         assert ws[0] < t['stat'], ws
 
 
+# model-level agreement of the greedy indices with the reference's argmax matrix in fp32 (split-bf16) mode, per fixture: the
+# floor is what was MEASURED on MI355X (round 6), 1.0 = every frame identical; below 1.0 only where two labels of a frame are
+# within the 1e-3 logit tolerance of each other and the device's rounding falls the other way
+ARGMAX_AGREEMENT_FLOOR = {'w2l_ml1': 0.995, 'w2l_ml3': 0.995, 'w2l_mix5': 0.995}
+
+
 @pytest.mark.parametrize('case', ['w2l_ml1', 'w2l_ml3', 'w2l_mix5'])
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_w2l_golden(case, precision):
@@ -96,7 +102,18 @@ def test_w2l_golden(case, precision):
         from wav2letter_pytorch_amd.decoder import argmax_indices
         idx = argmax_indices(out).cpu().numpy()
         agree = (idx == z['argmax']).mean()
-        assert agree > 0.995          # identical unless two labels are within 1e-3 of each other
+        valid = np.arange(idx.shape[1])[None, :] < out_lens.numpy()[:, None]
+        agree_valid = (idx == z['argmax'])[valid].mean()
+        # the measured agreement with the reference's argmax matrix, reported (pytest -s, and gpurun_out/argmax_agreement.txt
+        # when that directory exists), not only bounded: north_star asks for bit-exact greedy indices
+        line = (f'[argmax agreement] {case} fp32 mode: {agree * 100:.4f} % of all {idx.size} frames, {agree_valid * 100:.4f} % of '
+                f'the {int(valid.sum())} valid frames ({int((idx != z["argmax"]).sum())} frames differ)')
+        print(line)
+        rec = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+        if os.path.isdir(rec):
+            with open(os.path.join(rec, 'argmax_agreement.txt'), 'a') as f:
+                f.write(line + '\n')
+        assert agree >= ARGMAX_AGREEMENT_FLOOR[case], line
         # decoded strings: every utterance whose argmax path equals the reference's must decode to the reference's string,
         # and at least one such utterance must exist (a near-tie between two labels may flip single frames elsewhere)
         decoded = model.ctc_decoder.decode(out, out_lens)
@@ -483,6 +500,109 @@ def test_trainer_fit_loop_and_checkpoint(tmp_path, defer, monkeypatch):
 
 
 _TRAINER_RUNS = {}
+
+
+@pytest.mark.parametrize('mode', ['async', 'sync'])
+def test_lightning_base_class_branch(mode):
+    """base_asr_models takes `ptl.LightningModule` as its base class when pytorch_lightning is importable (reference
+    base_asr_models.py:15-17).  The image has no Lightning, so a subprocess injects a minimal one (tests/lightning_shim_worker.py:
+    LightningModule = nn.Module + log_dict / optimizers / hooks, Trainer.fit = automatic optimisation in Lightning's hook
+    order, as train.py:34-37 calls it) BEFORE importing the package: the class hierarchy, tensor-valued log_dict (the
+    synchronous order logs the loss TENSOR, as the reference does), `self.optimizers()`, a plain optimizer step over
+    un-deferred gradients (every p.grad present between backward() and step()), on_train_batch_end / on_train_epoch_end
+    resolving the asynchronous metrics, validation_step in eval mode."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, 'lightning_shim_worker.py'), mode], capture_output=True, text=True,
+                         timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert len(d['train_loss']) == 10 and d['train_loss'][-1] < d['train_loss'][0] and d['n_val'] == 2
+    assert d['train_keys'] == ['learning_rate', 'train_cer', 'train_len_ratio', 'train_loss', 'train_wer']
+    assert d['val_keys'] == ['val_cer', 'val_len_ratio', 'val_loss', 'val_wer']
+    assert all(d['grads_seen']) and d['moved'] >= 6 and d['pending'] == 0
+    assert d['tensor_valued'] == (mode == 'sync')
+    assert d['lr'][0] == 0.05 and abs(d['lr'][-1] - 0.05 * 0.999) < 1e-12        # ExponentialLR stepped once per epoch
+
+
+@pytest.mark.parametrize('kind', ['w2l', 'jasper'])
+def test_training_step_async_metrics_equal_synchronous(kind, monkeypatch):
+    """training_step only ENQUEUES the string metrics (argmax kernel + asynchronous copy + event) and on_train_batch_end logs
+    them behind backward() / optimizer.step(): the values logged for step i must be exactly -- bit for bit -- what the
+    reference's order (score inside training_step: async_metrics = False) logs for the same step, for every step of a short
+    run: train_loss, learning_rate, train_cer, train_wer, train_len_ratio.  Two identical models, identical batches (three
+    different ones in rotation, the last with ragged lengths), FusedSGD with deferred weight gradients as the trainer runs it."""
+    from gpu_helpers import build_jasper
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd import engine as E
+    # (bit-for-bit equality of two runs needs the step's bit-reproducible kernels: no fp32 atomics anywhere)
+    _bit_reproducible_engine(monkeypatch)
+    monkeypatch.setattr(E, 'DETERMINISTIC_WGRAD', True)
+    if kind == 'w2l':
+        layers = [(128, 11, 2, 1, 0.0), (128, 11, 1, 1, 0.0)]
+        sd = O.init_wav2letter_state(layers, seed=91)
+        make = lambda: build_w2l(layers, sd, 'bf16')         # noqa: E731
+    else:
+        z = load('jasper_dense.npz')
+        meta = ast.literal_eval(str(z['meta']))
+        sdj = {k[3:]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith('p0/')}
+        make = lambda: build_jasper(meta['blocks'], sdj, 'bf16')        # noqa: E731
+    batches = []
+    for b, (n, t) in enumerate(((4, 200), (3, 260), (4, 200))):
+        x, il, tg, tl = O.synthetic_batch(n, t, seed=92 + b, s_lo=5, s_hi=12)
+        if b == 2:
+            il = torch.tensor([200, 150, 180, 120], dtype=torch.int32)
+            tl = torch.minimum(tl, torch.tensor(20, dtype=torch.int32))
+        texts = tuple(''.join(O.ENGLISH_LOWERCASE[int(i)] for i in tg[k, :int(tl[k])]) for k in range(n))
+        batches.append((x, il, tg, tl, tuple('f%d' % k for k in range(n)), texts))
+    logs = {}
+    for mode in (True, False):
+        torch.manual_seed(5)
+        model = make().cuda().train()
+        model.check_nan = False
+        model.async_metrics = mode
+        model._cfg.optimizer.lr = 0.02
+        opt = model.configure_optimizers()[0][0]
+        model._optimizers = opt
+        opt.overlap = True
+        seen = []
+        for i in range(6):
+            batch = batches[i % 3]
+            opt.zero_grad(set_to_none=True)
+            loss = model.training_step(batch, i)
+            if mode:
+                assert len(model._pending_metrics) >= 1            # nothing was scored inside training_step
+            loss.backward()
+            opt.step()
+            model.on_train_batch_end(loss, batch, i)
+            if not mode:
+                seen.append(dict(model._logged))
+            else:
+                model.resolve_metrics(wait_all=True)
+                seen.append(dict(model._logged))
+        opt.join()
+        logs[mode] = seen
+    keys = {'train_loss', 'learning_rate', 'train_cer', 'train_wer', 'train_len_ratio'}
+    for a, b in zip(logs[True], logs[False]):
+        assert set(a) >= keys and set(b) >= keys
+        for k in keys:
+            assert a[k] == b[k], (k, a[k], b[k])
+    # and without the explicit resolve: the hook alone never leaves more than one batch outstanding, an epoch end none
+    model.async_metrics = True
+    for i in range(4):
+        opt.zero_grad(set_to_none=True)
+        loss = model.training_step(batches[i % 3], i)
+        loss.backward()
+        opt.step()
+        model.on_train_batch_end(loss, batches[i % 3], i)
+        assert len(model._pending_metrics) <= 1
+    model.on_train_epoch_end()
+    assert not model._pending_metrics
+    opt.join()
+
+
 
 
 def test_deferred_weight_gradients_fp8_and_jasper(monkeypatch):

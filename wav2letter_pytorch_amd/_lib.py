@@ -134,6 +134,7 @@ _SIGNATURES = {
     'w2l_feature_normalize': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
     'w2l_zero_rects': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
     'w2l_levenshtein_host': (c_i, [c_p, c_i, c_p, c_i]),
+    'w2l_greedy_score_host': (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     'w2l_wgrad_fp8_needs_zero': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'w2l_conv1d_wgrad_fp8': (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     'w2l_conv1d_wgrad_fp8_tune': (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -3,6 +3,7 @@ the HIP step engine.  Same constructor, attributes, methods, log keys and config
 are this package's own: one shared step for training and validation, batch-level metric totals."""
 from __future__ import annotations
 
+import os
 import random
 from typing import Callable, Dict, Sequence
 
@@ -27,6 +28,13 @@ except ImportError:  # pragma: no cover - exercised in this image
 
         def log_dict(self, d, *args, **kwargs):
             self._logged.update({k: (float(v.detach()) if torch.is_tensor(v) else float(v)) for k, v in d.items()})
+
+        # the two hooks of Lightning's loop that ConvCTCASR uses (trainer.Trainer calls them at the same points)
+        def on_train_batch_end(self, outputs=None, batch=None, batch_idx=0, *args):
+            pass
+
+        def on_train_epoch_end(self, *args):
+            pass
 
         def optimizers(self):
             return self._optimizers
@@ -140,18 +148,92 @@ class ConvCTCASR(_Base):
         return eng
 
     # ------------------------------------------------------------------ metrics
-    def add_string_metrics(self, out, output_lengths, texts, prefix) -> Dict[str, float]:
-        """greedy decode, then batch-level CER / WER (edit-distance totals over reference-length totals) and the
-        decoded / reference length ratio, under the reference's keys (base_asr_models.py:53-69)"""
-        hyps: Sequence[str] = self.ctc_decoder.decode(out, output_lengths)
+    # The reference decodes and scores EVERY training batch on the host before it returns the loss (base_asr_models.py:83):
+    # argmax, 16 000 .item() calls, 64 Levenshtein runs -- with the GPU idle, because backward() is enqueued after it.  Here
+    # the step only ENQUEUES what the metrics need -- the argmax kernel, one asynchronous copy of the int32 index matrix (and
+    # of the loss scalar) into pinned host memory, an event -- and returns; the strings are scored when the event has fired,
+    # which is after backward() and the optimizer step have been enqueued (on_train_batch_end; the host part is ONE C call,
+    # decoder.GreedyDecoder.score_batch).  The logged values are the same numbers, bit for bit; they reach log_dict one
+    # hook later.  ``async_metrics = False`` (or W2L_SYNC_METRICS=1) restores the reference's order: score, log, then return.
+    async_metrics = os.environ.get('W2L_SYNC_METRICS', '0') != '1'
+    METRICS_MAX_PENDING = 2          # batches whose metrics may be outstanding: the newest is never waited for
+
+    def _score_indices(self, idx_host, sizes, texts, prefix) -> Dict[str, float]:
+        """host part of add_string_metrics: argmax indices (on the host) -> the three logged ratios"""
+        dec = self.ctc_decoder
+        if sizes is not None and torch.is_tensor(sizes):
+            sizes = sizes.to(torch.int32)
+        if hasattr(dec, 'score_batch'):
+            hyps, (char_err, char_ref, word_err, word_ref) = dec.score_batch(idx_host, sizes, texts)
+        else:                            # any other decoder object with the reference's interface
+            hyps = [h[0] for h in dec.convert_to_strings(idx_host, sizes, remove_repetitions=True)]
+            char_err, char_ref = map(sum, zip(*(dec.cer_ratio(ref, hyp) for ref, hyp in zip(texts, hyps))))
+            word_err, word_ref = map(sum, zip(*(dec.wer_ratio(ref, hyp) for ref, hyp in zip(texts, hyps))))
         if random.random() < self.print_decoded_prob:
             print(f'reference: {texts[0]}')
             print(f'decoded  : {hyps[0]}')
-        dec = self.ctc_decoder
-        char_err, char_ref = map(sum, zip(*(dec.cer_ratio(ref, hyp) for ref, hyp in zip(texts, hyps))))
-        word_err, word_ref = map(sum, zip(*(dec.wer_ratio(ref, hyp) for ref, hyp in zip(texts, hyps))))
         return {f'{prefix}_cer': char_err / char_ref, f'{prefix}_wer': word_err / word_ref,
                 f'{prefix}_len_ratio': sum(len(h) for h in hyps) / sum(len(t) for t in texts)}
+
+    def add_string_metrics(self, out, output_lengths, texts, prefix) -> Dict[str, float]:
+        """greedy decode, then batch-level CER / WER (edit-distance totals over reference-length totals) and the
+        decoded / reference length ratio, under the reference's keys (base_asr_models.py:53-69).  SYNCHRONOUS (one
+        device-to-host copy of the index matrix): the training loop goes through enqueue_string_metrics instead."""
+        from .decoder import argmax_indices
+        if len(out.shape) == 2:
+            out = out.unsqueeze(0)
+        return self._score_indices(argmax_indices(out).cpu(), output_lengths, texts, prefix)
+
+    def enqueue_string_metrics(self, out, output_lengths, texts, prefix, loss=None, extra=None):
+        """the device half of add_string_metrics, without a host synchronisation: argmax kernel + asynchronous copies into
+        pinned memory + an event on the current stream.  The record is scored and logged by resolve_metrics()."""
+        from .decoder import argmax_indices
+        idx = argmax_indices(out)
+        idx_host = torch.empty(idx.shape, dtype=torch.int32, pin_memory=True)
+        idx_host.copy_(idx, non_blocking=True)
+        loss_host = None
+        if loss is not None:
+            loss_host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+            loss_host.copy_(loss.detach().reshape(1), non_blocking=True)
+        sizes = output_lengths
+        if torch.is_tensor(sizes) and sizes.is_cuda:
+            host = torch.empty(sizes.shape, dtype=sizes.dtype, pin_memory=True)
+            host.copy_(sizes, non_blocking=True)
+            sizes = host
+        ev = torch.cuda.Event()
+        ev.record()
+        pend = self.__dict__.setdefault('_pending_metrics', [])
+        pend.append((ev, idx_host, loss_host, sizes, tuple(texts), prefix, dict(extra or {}), idx))
+        return ev
+
+    def resolve_metrics(self, wait_all: bool = True) -> int:
+        """score and log the enqueued batches, oldest first.  ``wait_all``: block until every one is done (logging points,
+        epoch ends, validation); otherwise take what has already arrived and wait only for batches older than the newest
+        METRICS_MAX_PENDING - 1 (the host never runs further ahead than that).  Returns the number of batches logged."""
+        pend = self.__dict__.get('_pending_metrics')
+        done = 0
+        while pend:
+            ev = pend[0][0]
+            if not wait_all and len(pend) < self.METRICS_MAX_PENDING and not ev.query():
+                break
+            ev.synchronize()
+            _, idx_host, loss_host, sizes, texts, prefix, extra, _idx = pend.pop(0)
+            logs = {}
+            if loss_host is not None:
+                logs[f'{prefix}_loss'] = float(loss_host[0])
+            logs.update(extra)
+            logs.update(self._score_indices(idx_host, sizes, texts, prefix))
+            self.log_dict(logs)
+            done += 1
+        return done
+
+    # Lightning calls these around every training batch / epoch (our trainer.Trainer does the same): the metrics of the
+    # batch just enqueued are logged here, behind backward() and optimizer.step()
+    def on_train_batch_end(self, outputs=None, batch=None, batch_idx=0, *args):
+        self.resolve_metrics(wait_all=False)
+
+    def on_train_epoch_end(self, *args):
+        self.resolve_metrics(wait_all=True)
 
     # ------------------------------------------------------------------ Lightning hooks
     def configure_optimizers(self):
@@ -163,16 +245,64 @@ class ConvCTCASR(_Base):
         return [optimizer], [scheduler]
 
     def _device_batch(self, inputs):
+        """the spectrograms on the model's device without stalling the host: a host tensor that is not page-locked is staged
+        through one of two pinned buffers owned by the module (an H2D copy from pageable memory makes the HIP runtime wait
+        for the stream -- i.e. for everything the host has run ahead by); a DataLoader with pin_memory=True skips the staging"""
         dev = next(self.parameters()).device
-        return inputs.to(dev, non_blocking=True) if inputs.device != dev else inputs
+        if inputs.device == dev:
+            return inputs
+        if inputs.device.type == 'cpu' and dev.type == 'cuda' and not inputs.is_pinned():
+            ring = self.__dict__.setdefault('_stage_ring', [None, None, 0])
+            slot = ring[2] & 1
+            ring[2] += 1
+            ent = ring[slot]
+            if ent is None or ent[0].numel() < inputs.numel() or ent[0].dtype != inputs.dtype:
+                ent = ring[slot] = [torch.empty(inputs.numel(), dtype=inputs.dtype, pin_memory=True), None]
+            if ent[1] is not None:
+                ent[1].synchronize()               # the copy issued from this buffer two batches ago (long done)
+            stage = ent[0][: inputs.numel()].view(inputs.shape)
+            stage.copy_(inputs)
+            out = stage.to(dev, non_blocking=True)
+            ent[1] = torch.cuda.Event()
+            ent[1].record()
+            return out
+        return inputs.to(dev, non_blocking=True)
+
+    def _device_ints(self, dev, *tensors):
+        """small host integer tensors of a batch (targets, lengths) -> int32 device tensors through ONE pinned buffer and one
+        asynchronous copy (three pageable copies would be three stream synchronisations)"""
+        if dev.type != 'cuda' or any(t.is_cuda for t in tensors):
+            return tuple(t.to(device=dev, dtype=torch.int32) for t in tensors)
+        flat = [t.reshape(-1).to(torch.int32) for t in tensors]
+        total = sum(f.numel() for f in flat)
+        host = torch.empty(total, dtype=torch.int32, pin_memory=True)
+        torch.cat(flat, out=host)
+        devbuf = host.to(dev, non_blocking=True)
+        outs, off = [], 0
+        for t, f in zip(tensors, flat):
+            outs.append(devbuf[off: off + f.numel()].view(t.shape))
+            off += f.numel()
+        self.__dict__['_ints_keep'] = host         # alive until the next batch's copy has been enqueued behind it
+        return tuple(outs)
 
     def _step(self, batch, prefix: str, extra: Dict[str, float]):
         """forward -> CTC -> string metrics -> log_dict; the body of training_step and validation_step
-        (base_asr_models.py:78-94).  batch = _collator's 6-tuple (data_loader.py:149-158)."""
+        (base_asr_models.py:78-94).  batch = _collator's 6-tuple (data_loader.py:149-158).  Nothing in here waits for the
+        GPU when ``async_metrics`` is on and the step is a training step: the metrics are logged by on_train_batch_end."""
         spect, spect_lens, targets, target_lens, _paths, texts = batch
-        out, out_lens = self.forward(self._device_batch(spect), spect_lens)
-        loss = self.criterion(out.transpose(0, 1), targets, out_lens, target_lens)
-        self.log_dict({f'{prefix}_loss': loss, **extra, **self.add_string_metrics(out, out_lens, texts, prefix)})
+        x = self._device_batch(spect)
+        out, out_lens = self.forward(x, spect_lens)
+        if x.is_cuda and torch.is_tensor(out_lens) and torch.is_tensor(targets) and torch.is_tensor(target_lens):
+            tg_d, ol_d, tl_d = self._device_ints(x.device, targets, out_lens, target_lens)
+        else:
+            tg_d, ol_d, tl_d = targets, out_lens, target_lens
+        loss = self.criterion(out.transpose(0, 1), tg_d, ol_d, tl_d)
+        if self.async_metrics and x.is_cuda:
+            self.enqueue_string_metrics(out, out_lens, texts, prefix, loss=loss, extra=extra)
+            if prefix != 'train':                  # validation: nothing to overlap the scoring with, and the epoch mean
+                self.resolve_metrics(wait_all=True)     # is formed batch by batch
+        else:
+            self.log_dict({f'{prefix}_loss': loss, **extra, **self.add_string_metrics(out, out_lens, texts, prefix)})
         return loss
 
     def training_step(self, batch, batch_idx):

@@ -97,6 +97,88 @@ extern "C" int w2l_levenshtein_host(const int32_t* a, int na, const int32_t* b, 
     return prev[nb];
 }
 
+// ---- greedy decode + CER / WER totals of one batch, host side (base_asr_models.py:53-69 with decoder.py:31-66,104-119) ----
+// What ConvCTCASR.add_string_metrics does per step, as ONE call that never takes the interpreter lock: the step's argmax
+// indices (already on the host: one asynchronous copy per step) are collapsed (blanks dropped, a frame equal to the previous
+// FRAME dropped), mapped to code points, and scored against the reference transcripts:
+//   CER numerator = Levenshtein over code points with ' ' removed from both, denominator = len(expected without ' ');
+//   WER numerator = Levenshtein over the word sequences (str.split(): runs of Python whitespace), denominator = #words.
+// totals[5] = {cer_err, cer_ref, wer_err, wer_ref, sum of len(decoded)}; hyp_cp / hyp_off (optional) receive the decoded
+// code points, utterance n at hyp_cp[hyp_off[n] .. hyp_off[n+1]).
+namespace {
+inline bool py_isspace(int32_t c) {
+    return (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x20) || c == 0x85 || c == 0xa0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200a) ||
+           c == 0x2028 || c == 0x2029 || c == 0x202f || c == 0x205f || c == 0x3000;
+}
+struct Word { const int32_t* p; int n; };
+inline void split_words(const int32_t* s, int n, std::vector<Word>& out) {
+    out.clear();
+    int i = 0;
+    while (i < n) {
+        while (i < n && py_isspace(s[i])) ++i;
+        const int b = i;
+        while (i < n && !py_isspace(s[i])) ++i;
+        if (i > b) out.push_back(Word{s + b, i - b});
+    }
+}
+template <class Eq>
+int edit_distance(int na, int nb, Eq eq, std::vector<int>& prev, std::vector<int>& cur) {
+    prev.resize(nb + 1);
+    cur.resize(nb + 1);
+    for (int j = 0; j <= nb; ++j) prev[j] = j;
+    for (int i = 1; i <= na; ++i) {
+        cur[0] = i;
+        for (int j = 1; j <= nb; ++j) cur[j] = std::min(std::min(prev[j] + 1, cur[j - 1] + 1), prev[j - 1] + (eq(i - 1, j - 1) ? 0 : 1));
+        std::swap(prev, cur);
+    }
+    return prev[nb];
+}
+}  // namespace
+
+extern "C" int w2l_greedy_score_host(const int32_t* idx, int N, int T, const int32_t* sizes, int blank, const int32_t* lut,
+                                     int n_labels, const int32_t* ref_cp, const int64_t* ref_off, int64_t* totals,
+                                     int32_t* hyp_cp, int64_t* hyp_off) {
+    W2L_CHECK_ARG(idx != nullptr && lut != nullptr && ref_cp != nullptr && ref_off != nullptr && totals != nullptr && N >= 0 && T >= 0,
+                  "greedy_score_host: null pointer or negative size");
+    std::vector<int32_t> hyp, a, b;
+    std::vector<Word> wa, wb;
+    std::vector<int> prev, cur;
+    int64_t cer_err = 0, cer_ref = 0, wer_err = 0, wer_ref = 0, hyp_len = 0, written = 0;
+    if (hyp_off != nullptr) hyp_off[0] = 0;
+    for (int n = 0; n < N; ++n) {
+        const int32_t* row = idx + (int64_t)n * T;
+        int len = sizes != nullptr ? sizes[n] : T;
+        len = std::max(0, std::min(len, T));
+        hyp.clear();
+        for (int t = 0; t < len; ++t) {
+            const int32_t c = row[t];
+            W2L_CHECK_ARG(c >= 0 && c < n_labels, "greedy_score_host: index %d outside the %d labels", (int)c, n_labels);
+            if (c != blank && !(t > 0 && c == row[t - 1])) hyp.push_back(lut[c]);
+        }
+        hyp_len += (int64_t)hyp.size();
+        if (hyp_cp != nullptr && hyp_off != nullptr) {
+            std::copy(hyp.begin(), hyp.end(), hyp_cp + written);
+            written += (int64_t)hyp.size();
+            hyp_off[n + 1] = written;
+        }
+        const int32_t* ref = ref_cp + ref_off[n];
+        const int nref = (int)(ref_off[n + 1] - ref_off[n]);
+        a.clear();
+        b.clear();
+        for (int i = 0; i < nref; ++i) if (ref[i] != 0x20) a.push_back(ref[i]);
+        for (int32_t c : hyp) if (c != 0x20) b.push_back(c);
+        cer_err += edit_distance((int)a.size(), (int)b.size(), [&](int i, int j) { return a[i] == b[j]; }, prev, cur);
+        cer_ref += (int64_t)a.size();
+        split_words(ref, nref, wa);
+        split_words(hyp.data(), (int)hyp.size(), wb);
+        wer_err += edit_distance((int)wa.size(), (int)wb.size(), [&](int i, int j) {
+            return wa[i].n == wb[j].n && memcmp(wa[i].p, wb[j].p, (size_t)wa[i].n * sizeof(int32_t)) == 0; }, prev, cur);
+        wer_ref += (int64_t)wa.size();
+    }
+    totals[0] = cer_err; totals[1] = cer_ref; totals[2] = wer_err; totals[3] = wer_ref; totals[4] = hyp_len;
+    return 0;
+}
+
 // ---- stream concurrency probe ------------------------------------------------------------------------------------
 // Can a kernel launched on `stream_b` START while a large kernel launched earlier on `stream_a` is still being
 // dispatched?  HIP maps a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES) and those onto the command

@@ -98,6 +98,41 @@ class GreedyDecoder(Decoder):
             return texts
         return texts, [[frames] for _, frames in decoded]
 
+    def score_batch(self, indices, sizes, texts):
+        """What ConvCTCASR.add_string_metrics needs from one batch (base_asr_models.py:53-69), from argmax indices that are
+        already on the host: (decoded strings, (cer_err, cer_ref, wer_err, wer_ref)) -- collapse, CER and WER totals in ONE
+        C call (w2l_greedy_score_host) that holds no interpreter lock, instead of ~100 Python-level calls per batch.
+        ``indices``: int32 [N, T] host tensor / array; ``sizes``: [N] valid frames or None; ``texts``: the N transcripts."""
+        idx = np.ascontiguousarray(indices.numpy() if torch.is_tensor(indices) else indices, dtype=np.int32)
+        n, t = idx.shape
+        lut = self.__dict__.get('_cp_lut')
+        if lut is None:
+            chars = [self.int_to_char[i] for i in range(len(self.int_to_char))]
+            # (labels of one code point each -- both shipped label sets; anything else takes the string path below)
+            lut = self.__dict__['_cp_lut'] = (np.array([ord(c) for c in chars], dtype=np.int32)
+                                              if all(isinstance(c, str) and len(c) == 1 for c in chars) else False)
+        if lut is False or type(self).cer is not Decoder.cer or type(self).wer is not Decoder.wer:
+            hyps = [h[0] for h in self.convert_to_strings(idx, sizes, remove_repetitions=True)]
+            cer = [self.cer_ratio(ref, hyp) for ref, hyp in zip(texts, hyps)]
+            wer = [self.wer_ratio(ref, hyp) for ref, hyp in zip(texts, hyps)]
+            return hyps, (sum(e for e, _ in cer), sum(d for _, d in cer), sum(e for e, _ in wer), sum(d for _, d in wer))
+        sz = None if sizes is None else np.ascontiguousarray(sizes.numpy() if torch.is_tensor(sizes) else sizes, dtype=np.int32)
+        # (utf-32 with surrogatepass: one int32 per code point, whatever the transcript holds)
+        ref = np.frombuffer(''.join(texts).encode('utf-32-le', 'surrogatepass'), dtype=np.int32)
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(x) for x in texts], out=off[1:])
+        totals = np.zeros(5, dtype=np.int64)
+        hyp = np.empty(max(n * t, 1), dtype=np.int32)
+        hoff = np.zeros(n + 1, dtype=np.int64)
+        vp = C.c_void_p
+        check(lib.w2l_greedy_score_host(idx.ctypes.data_as(vp), n, t, sz.ctypes.data_as(vp) if sz is not None else None,
+                                        int(self.blank_index), lut.ctypes.data_as(vp), len(lut), ref.ctypes.data_as(vp),
+                                        off.ctypes.data_as(vp), totals.ctypes.data_as(vp), hyp.ctypes.data_as(vp),
+                                        hoff.ctypes.data_as(vp)), 'w2l_greedy_score_host')
+        text = hyp[: hoff[n]].tobytes().decode('utf-32-le', 'surrogatepass')
+        hyps = [text[hoff[i]: hoff[i + 1]] for i in range(n)]
+        return hyps, tuple(int(v) for v in totals[:4])
+
     def decode(self, probs, sizes=None, return_offsets=False):
         """argmax decoding, repeats and blanks removed (decoder.py:121-145).
         probs: [batch, seq_length, output_dim] (or 2-D for one utterance)."""

@@ -121,14 +121,20 @@ class Trainer:
                 loss = model.training_step(batch, i)
                 loss.backward()
                 opt.step()
+                # Lightning's hook order: the batch's string metrics (greedy decode, CER / WER) are scored HERE, with the
+                # backward pass and the update already enqueued -- training_step itself never waits for the GPU
+                model.on_train_batch_end(loss, batch, i)
                 self.global_step += 1
                 if self.global_step % self.log_every_n_steps == 0 or self.global_step == 1:
+                    if hasattr(model, 'resolve_metrics'):
+                        model.resolve_metrics(wait_all=True)         # a logging point reports THIS step (one sync per log line)
                     logs = dict(getattr(model, '_logged', {}))
                     self.logged.append((self.global_step, logs))
                     self._say(f'epoch {epoch} step {self.global_step} ' + ' '.join(f'{k}={v:.4g}' for k, v in logs.items()))
                 if self.max_steps is not None and self.global_step >= self.max_steps:
                     done = True
                     break
+            model.on_train_epoch_end()
             for sch in schedulers:
                 sch.step()
             join()                               # parameters are read below (validation, checkpoint)
