@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def main_steps(out_path, defer, steps=3):
+def main_steps(out_path, defer, steps=int(os.environ.get('W2L_TEST_STEPS', '3'))):
     """``steps`` data-parallel training steps in bf16 mode with the top ``defer`` units' weight gradients held back for the
     next forward pass (optim.FusedSGD.defer_wgrad; 0 = the plain step): final parameters of every rank"""
     import torch.distributed as dist
