@@ -39,15 +39,15 @@ def jasper10x5_cfg(precision='bf16'):
     return jasper10x5_model(precision=precision)
 
 
-def cpu_baseline(budget_s=20.0):
+def cpu_baseline(budget_s=20.0, mid_layers=20, N=2, T=1000):
     """the oracle's training step (fp32, torch CPU ops = what the reference executes) on a bounded
-    sample of the same workload: W2L mid_layers=20, N=2, T=1000."""
+    sample of the same workload: W2L mid_layers=20, N=2, T=1000; the shipped default
+    ``mid_layers: 1`` at N=32 when the run is of that configuration."""
     from oracle import w2l_oracle as O
     cores = min(os.cpu_count() or 1, 32)       # torch CPU convolutions stop scaling (and regress) well before 256 threads
     torch.set_num_threads(cores)
-    layers = [l[:4] + (0.0,) for l in O.W2L_LAYERS]
+    layers = [l[:4] + (0.0,) for l in O.W2L_LAYERS][:mid_layers]
     sd = O.init_wav2letter_state(layers, seed=0)
-    N, T = 2, 1000
     x, il, tg, tl = O.synthetic_batch(N, T, seed=1234)
     t0 = time.perf_counter()
     O.wav2letter_step(x, il, tg, tl, sd, layers)            # warm-up, also sizes the sample
@@ -61,7 +61,7 @@ def cpu_baseline(budget_s=20.0):
     best, mean = min(times), sum(times) / len(times)
     return {'value': round(N * T / best, 1), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
             'mean_value': round(N * T / mean, 1),
-            'sample': f'W2L mid_layers=20 fp32 N={N} T={T}, dropout off (p = 0 in every layer; the GPU leg has the yaml dropout on): '
+            'sample': f'W2L mid_layers={mid_layers} fp32 N={N} T={T}, dropout off (p = 0 in every layer; the GPU leg has the yaml dropout on): '
                       f'{nsteps} timed step(s) after 1 warm-up, best step {best:.3f}s (value), mean step {mean:.3f}s (mean_value), '
                       f'torch CPU ops on {cores} threads of {os.cpu_count()} host cores'}
 
@@ -542,8 +542,16 @@ def main():
             elapsed_ = max(float(v) for v in every)
         return elapsed_ / args.steps * 1e3, rank_ms_, loss_
 
+    if getattr(model, 'grad_reducer', None) is not None:
+        model.grad_reducer.wire_bytes = 0
     ms, rank_ms, loss = timed_region()
     value = world * N * T / (ms * 1e-3)
+    comm_bytes = None
+    if getattr(model, 'grad_reducer', None) is not None and model.grad_reducer.active:
+        # payload handed to the gradient collectives per step in the timed region (fp32 unless W2L_DP_BF16=1: then the large
+        # gradients travel as bf16 copies)
+        comm_bytes = {'per_step': int(model.grad_reducer.wire_bytes // args.steps),
+                      'transport': 'bf16 copies of the large gradients (W2L_DP_BF16=1)' if model.grad_reducer.bf16 else 'fp32'}
 
     # ---- the same number of steps through the reference's loop body (see trainer_step above): what a train.py user gets.
     # Two legs: as shipped (metrics enqueued in training_step, scored in on_train_batch_end) and -- the "before" figure -- with
@@ -572,7 +580,7 @@ def main():
         fence()
 
     # ---- exposed communication: the same step with the gradient reducer detached (no collectives), same run, per rank ----
-    exposed_comm_ms = exposed_by_rank = solo_ms = None
+    exposed_comm_ms = exposed_by_rank = solo_ms = bf16_leg = None
     reducer = getattr(model, 'grad_reducer', None)
     if reducer is not None and not args.graph:
         model.grad_reducer = None
@@ -590,6 +598,24 @@ def main():
         exposed_comm_ms = max(exposed_by_rank)
         model.grad_reducer = reducer
         broadcast_parameters(model)                          # the replicas drifted apart while stepping alone
+        # ---- when more than a tenth of the step is exposed communication: the same region once more with the large gradients
+        # travelling as bf16 copies (half the bytes on every xGMI link; the average is then accurate to bf16's 8 bits, which is
+        # NOT what fp32 DDP computes -- reported beside the fp32 figure, never instead of it).  All ranks take the same branch
+        # (the decision is the maximum over the ranks, gathered above).
+        if exposed_comm_ms > 0.1 * ms and not reducer.bf16 and os.environ.get('W2L_BENCH_BF16_LEG', '1') != '0':
+            reducer.bf16 = True
+            step()
+            step()
+            fence()
+            reducer.wire_bytes = 0
+            ms_b, rank_ms_b, _ = timed_region()
+            bf16_leg = {'ms_per_step': round(ms_b, 3), 'value': round(world * N * T / (ms_b * 1e-3), 1),
+                        'comm_bytes_on_wire_per_step': int(reducer.wire_bytes // args.steps),
+                        'exposed_comm_ms': round(max(gather_objects(dist, world, rank_ms_b[rank] - solo_ms)), 3),
+                        'note': 'W2L_DP_BF16=1: not the headline (bf16-accurate averages); shown because the fp32 exchange '
+                                'left more than 10 % of the step exposed'}
+            reducer.bf16 = False
+            broadcast_parameters(model)
     tune_shas = gather_objects(dist, world, tune_sha) if tune_sha is not None else None
 
     # ---- instrumented pass: HIP events around every conv kernel launch (same stream) ----
@@ -723,7 +749,12 @@ def main():
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline() if args.model == 'wav2letter' else cpu_baseline_jasper()
+            if args.model != 'wav2letter':
+                cpu = cpu_baseline_jasper()
+            elif args.mid_layers >= 20:
+                cpu = cpu_baseline(T=args.frames)
+            else:          # truncated stacks (the shipped default mid_layers: 1): the run's own batch, SURVEY 8d
+                cpu = cpu_baseline(mid_layers=args.mid_layers, N=args.batch, T=args.frames)
         line = {
             'metric': (f'audio-frames/sec/GPU (fwd+bwd+CTC), Wav2Letter 64-mel x 1000-frame {args.dtype}' if args.model == 'wav2letter'
                        else f'audio-frames/sec/GPU (fwd+bwd+CTC), Jasper 10x5 {args.dtype} (secondary workload)'),
@@ -759,6 +790,8 @@ def main():
                                     'deferred launch of a timed step is inside the timed region (the fences flush them)'},
             'rank_ms_per_step': [round(v, 3) for v in rank_ms],
             'exposed_comm_ms': None if exposed_comm_ms is None else round(exposed_comm_ms, 3),
+            'comm_bytes_on_wire': comm_bytes,
+            'bf16_transport_leg': bf16_leg,
             # what a bandwidth-bound ring all-reduce of this step's gradients would take on xGMI: 2 (N-1)/N x bytes over ONE
             # link's ~153 GB/s (point-to-point links: a ring is per-link bound) -- to read exposed_comm_ms against
             'expected_ring_ms': (None if world < 2 else round(

@@ -1044,6 +1044,17 @@ def test_bench_self_launch_two_ranks(tmp_path):
     assert len(d['rank_ms_per_step']) == 2 and all(v > 0 for v in d['rank_ms_per_step'])
     assert d['exposed_comm_ms'] is not None and abs(d['per_gpu_value'] * 2 - d['value']) < 1.0
     assert len(d['exposed_comm_ms_by_rank']) == 2 and d['exposed_comm_ms'] == max(d['exposed_comm_ms_by_rank'])
+    # what the first multi-GPU curve needs to explain itself: the payload of the gradient collectives per step (fp32: four
+    # bytes per parameter + the per-channel pool), what a bandwidth-bound ring would take, where the bytes are reduced, and --
+    # whenever more than a tenth of the step is exposed communication, as over gloo here -- a bf16-transport leg beside it
+    cb = d['comm_bytes_on_wire']
+    assert cb['transport'] == 'fp32' and cb['per_step'] >= d['grad_bytes']['total'] * 0.99, cb
+    assert d['expected_ring_ms'] > 0 and d['trainer_ms_per_step'] > 0 and d['trainer_loop']['async_metrics']['ms_per_step'] > 0
+    if d['exposed_comm_ms'] > 0.1 * d['ms_per_step']:
+        leg = d['bf16_transport_leg']
+        assert leg['ms_per_step'] > 0 and leg['comm_bytes_on_wire_per_step'] < 0.75 * cb['per_step'], leg
+    else:
+        assert d['bf16_transport_leg'] is None
     # the in-run A/B of the two collective paths: both ran (the native one on one-rank rehearsal communicators here -- RCCL
     # refuses two ranks of one communicator on one device), the line carries both timings and names the path it kept, and
     # the timed region ran on that path

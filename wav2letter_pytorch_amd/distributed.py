@@ -223,6 +223,9 @@ class GradReducer:
         return self._stream
 
     def _all_reduce(self, t: torch.Tensor):
+        # payload handed to the collectives since the caller last reset the counter (bench.py: bytes per step; a ring moves
+        # 2 (N-1)/N of it over every link)
+        self.wire_bytes = getattr(self, 'wire_bytes', 0) + t.numel() * t.element_size()
         if self._comm is not None and t.is_cuda:
             side = torch.cuda.current_stream(t.device)           # (the caller has made the reducer's stream current)
             self._comm.all_reduce(t, average=True, stream=side)
