@@ -509,6 +509,53 @@ int w2l_rccl_all_reduce(void* comm, void* buf, int64_t count, int dtype, int ave
 int w2l_rccl_broadcast(void* comm, void* buf, int64_t bytes, int root, void* stream);
 int w2l_rccl_destroy(void* comm);
 
+/* ---- recorded launch lists (round 6) -----------------------------------------------------------------------------------
+ * The reference's host loop is PyTorch's dispatcher (one Python -> ATen transition per op of wav2letter.py:40-47,84-92 and
+ * of autograd's backward); the step engine here made one Python -> ctypes transition per launch, 200-500 per step.  After
+ * the tuned warm-up the engine records what a step calls -- entry point, argument values, stream, and the event records /
+ * waits between its streams -- and replays every phase of the step (forward, backward, optimizer, held-back weight
+ * gradients) with ONE w2l_replay call: a C loop over the very same entry points.  Not a hipGraph: each launch goes to the
+ * stream it was recorded on, so side streams and the cross-step overlap of the updates behave as in the eager step.
+ *   w2l_slot_t    one argument: p for pointers (and pointers to the by-reference structs, whose copies the RECORDER owns),
+ *                 i for every integer type, d for float / double (narrowed to the parameter's type at the call);
+ *   w2l_call_t    op = w2l_replay_op("w2l_..."), nargs = that entry point's arity, a[] = its arguments in order;
+ *   w2l_replay    runs calls[0..n) in order on the calling thread (thread-local library state -- w2l_conv_stats_mode -- is
+ *                 that thread's); stops at the first failing call: returns its code, *failed_at = its index, the message
+ *                 is the entry point's own (w2l_last_error).  Ownership as everywhere: the caller keeps every buffer the
+ *                 recorded pointers name alive and unmoved for as long as it replays the list. */
+typedef union { void* p; int64_t i; double d; } w2l_slot_t;
+#define W2L_REPLAY_MAX_ARGS 24
+typedef struct { int32_t op; int32_t nargs; w2l_slot_t a[W2L_REPLAY_MAX_ARGS]; } w2l_call_t;
+int w2l_replay_op(const char* entry_point_name);      /* -1: not a replayable entry point */
+int w2l_replay_arity(int op);
+int w2l_replay(const w2l_call_t* calls, int n, int* failed_at);
+
+/* Stream order as entry points, so that it can be recorded like a launch (the eager engine used torch.cuda.Event /
+ * Stream.wait_event here): events are created without timing; w2l_event_query: 0 fired, 1 not yet;
+ * w2l_stream_wait_stream(waiter, signaler): `waiter` waits for everything enqueued on `signaler` so far. */
+int w2l_event_create(void** event_out);
+int w2l_event_destroy(void* event);
+int w2l_event_record(void* event, void* stream);
+int w2l_stream_wait_event(void* stream, void* event);
+int w2l_event_query(void* event);
+int w2l_event_synchronize(void* event);
+int w2l_stream_wait_stream(void* waiter, void* signaler);
+
+/* What the eager engine left to torch ops between its launches, as entry points: tensor.zero_() of the statistics / slot /
+ * gradient pools (hipMemsetAsync); the zero- / one-padded copy of a per-channel vector (conv bias of the 29-label classifier
+ * padded to 64, wav2letter.py:69); `+= delta` on a device int64 (the dropout step counter of a replayed step: the Philox
+ * offset of nn.Dropout, wav2letter.py:38,44, must move every step); num_batches_tracked += 1 of every BatchNorm1d of the
+ * stack in one launch (table_dev: n device pointers to int64 scalars; wav2letter.py:37); torch.optim.SGD's update of all
+ * the small parameters -- biases, BatchNorm gamma / beta -- in one launch (exp_lr_optimizer.yaml:2-7; dampening 0;
+ * m == NULL: no momentum buffer). */
+int w2l_fill_zero(void* p, int64_t bytes, void* stream);
+int w2l_pad_vec_f32(const float* src, int n, float* dst, int cp, float fill, void* stream);
+int w2l_counter_add(void* counter_i64, int64_t delta, void* stream);
+int w2l_add_i64_multi(void* table_dev, int n, int64_t delta, void* stream);
+typedef struct { float* p; const float* g; float* m; int32_t n; int32_t pad_; } w2l_sgd_small_t;
+int w2l_sgd_small_multi(const w2l_sgd_small_t* items_dev, int nitems, float lr, float momentum, float weight_decay,
+                        int nesterov, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,6 +148,22 @@ _SIGNATURES = {
     'w2l_rccl_all_reduce': (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p]),
     'w2l_rccl_broadcast': (c_i, [c_p, c_p, c_i64, c_i, c_p]),
     'w2l_rccl_destroy': (c_i, [c_p]),
+    # recorded launch lists (replay.py): the replay loop and the recordable primitives
+    'w2l_replay_op': (c_i, [C.c_char_p]),
+    'w2l_replay_arity': (c_i, [c_i]),
+    'w2l_replay': (c_i, [c_p, c_i, c_p]),
+    'w2l_event_create': (c_i, [c_p]),
+    'w2l_event_destroy': (c_i, [c_p]),
+    'w2l_event_record': (c_i, [c_p, c_p]),
+    'w2l_stream_wait_event': (c_i, [c_p, c_p]),
+    'w2l_event_query': (c_i, [c_p]),
+    'w2l_event_synchronize': (c_i, [c_p]),
+    'w2l_stream_wait_stream': (c_i, [c_p, c_p]),
+    'w2l_fill_zero': (c_i, [c_p, c_i64, c_p]),
+    'w2l_pad_vec_f32': (c_i, [c_p, c_i, c_p, c_i, c_f, c_p]),
+    'w2l_counter_add': (c_i, [c_p, c_i64, c_p]),
+    'w2l_add_i64_multi': (c_i, [c_p, c_i, c_i64, c_p]),
+    'w2l_sgd_small_multi': (c_i, [c_p, c_i, c_f, c_f, c_f, c_i, c_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -263,3 +279,216 @@ def trace_dump(path: str) -> int:
             t0 = origin.elapsed_time(s)
             f.write('%s,%d,%d,%d\n' % (label, stream, int(t0 * 1e6), int((t0 + s.elapsed_time(e)) * 1e6)))
     return len(rows)
+
+
+# ---------------------------------------------------------------------------------------------------------------- events
+def raw_stream(stream=None) -> int:
+    """hipStream_t (as an int) of a torch stream, or of torch's current stream"""
+    if stream is None:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    return stream.cuda_stream
+
+
+class Event:
+    """A HIP event behind the C ABI (w2l_event_*): what the step engine orders its streams with.  Unlike torch.cuda.Event
+    every record / wait is an entry-point call, so a recorded launch list (replay.py) replays the stream order too.  Handles
+    are pooled; an event created while a phase is being recorded belongs to that record (its handle is in the list)."""
+    __slots__ = ('h', '__weakref__')
+    _free: list = []
+
+    def __init__(self):
+        if Event._free:
+            self.h = Event._free.pop()
+        else:
+            out = C.c_void_p()
+            check(lib.w2l_event_create(C.byref(out)), 'w2l_event_create')
+            self.h = out.value
+        rec = _recorder[0]
+        if rec is not None:
+            rec.keep.append(self)
+
+    def record(self, stream=None):
+        check(lib.w2l_event_record(self.h, raw_stream(stream)), 'w2l_event_record')
+
+    def wait(self, stream=None):
+        """make ``stream`` (default: the current one) wait for this event"""
+        check(lib.w2l_stream_wait_event(raw_stream(stream), self.h), 'w2l_stream_wait_event')
+
+    def query(self) -> bool:
+        rc = lib.w2l_event_query(self.h)
+        if rc not in (0, 1):
+            check(rc, 'w2l_event_query')
+        return rc == 0
+
+    def synchronize(self):
+        check(lib.w2l_event_synchronize(self.h), 'w2l_event_synchronize')
+
+    def __del__(self):
+        try:
+            Event._free.append(self.h)
+        except Exception:          # interpreter shutdown
+            pass
+
+
+def stream_wait_stream(waiter, signaler):
+    """``waiter`` waits for everything enqueued so far on ``signaler`` (torch streams or raw handles)"""
+    a = waiter if isinstance(waiter, int) else waiter.cuda_stream
+    b = signaler if isinstance(signaler, int) else signaler.cuda_stream
+    check(lib.w2l_stream_wait_stream(a, b), 'w2l_stream_wait_stream')
+
+
+# ---------------------------------------------------------------------------------------------------------------- recorder
+class Slot(C.Union):
+    """w2l_slot_t"""
+    _fields_ = [('p', c_p), ('i', c_i64), ('d', C.c_double)]
+
+
+REPLAY_MAX_ARGS = 24
+
+
+class Call(C.Structure):
+    """w2l_call_t"""
+    _fields_ = [('op', C.c_int32), ('nargs', C.c_int32), ('a', Slot * REPLAY_MAX_ARGS)]
+
+
+_recorder = [None]            # the Recorder of the phase being recorded (module-wide: a phase runs on ONE thread at a time)
+_REPLAY_OPS = {}              # entry point name -> (op index, per-argument kind: 'p' / 'i' / 'd')
+
+
+def _replay_ops():
+    if not _REPLAY_OPS:
+        for name, (_, args) in _SIGNATURES.items():
+            op = lib.w2l_replay_op(name.encode())
+            if op < 0:
+                continue
+            kinds = []
+            for a in args:
+                if a in (c_i, c_i64, c_u64, C.c_int32):
+                    kinds.append('i')
+                elif a in (c_f, C.c_double):
+                    kinds.append('d')
+                else:
+                    kinds.append('p')
+            assert lib.w2l_replay_arity(op) == len(kinds) <= REPLAY_MAX_ARGS, name
+            _REPLAY_OPS[name] = (op, tuple(kinds))
+    return _REPLAY_OPS
+
+
+class Phase:
+    """One recorded phase of a step: C segments (arrays of w2l_call_t, replayed by ONE w2l_replay call each) and -- only
+    where the engine had to call back into Python between launches -- Python items run with their recorded current stream."""
+    __slots__ = ('items', 'keep', 'n_calls')
+
+    def __init__(self, items, keep, n_calls):
+        self.items, self.keep, self.n_calls = items, keep, n_calls
+
+    def replay(self):
+        failed = C.c_int(-1)
+        for it in self.items:
+            if it[0] == 'c':
+                rc = lib.w2l_replay(it[1], it[2], C.byref(failed))
+                if rc != 0:
+                    msg = lib.w2l_last_error()
+                    raise W2LError(f'w2l_replay failed at record {failed.value} of {it[2]} (code {rc}): {msg.decode() if msg else "?"}')
+            else:
+                _, fn, args, stream = it
+                if stream is None:
+                    fn(*args)
+                else:
+                    with torch.cuda.stream(stream):
+                        fn(*args)
+
+
+class Recorder:
+    """While active (``with Recorder() as rec``) every replayable entry point called through ``lib`` on this thread is executed
+    AND appended to the list; ``python(fn, *args)`` runs and records a Python callback in sequence; ``poison(why)`` marks the
+    phase as not replayable (a code path that still uses torch ops between launches).  ``finish()`` -> Phase or None."""
+
+    def __init__(self):
+        self.calls = []          # pending C calls of the current segment: (op, kinds, args)
+        self.items = []
+        self.keep = []
+        self.poisoned = None
+        self.n_calls = 0
+        self._saved = {}
+        self._thread = None
+
+    def __enter__(self):
+        import threading
+        if _recorder[0] is not None:
+            raise W2LError('a phase is already being recorded')
+        self._thread = threading.get_ident()
+        for name, (op, kinds) in _replay_ops().items():
+            fn = getattr(lib, name)
+            self._saved[name] = fn
+
+            def wrapper(*args, _fn=fn, _op=op, _kinds=kinds, _name=name):
+                rc = _fn(*args)
+                if threading.get_ident() == self._thread and (rc == 0 or rc is None):
+                    self.calls.append((_op, _kinds, args))
+                return rc
+
+            setattr(lib, name, wrapper)
+        _recorder[0] = self
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self._saved.items():
+            setattr(lib, name, fn)
+        self._saved = {}
+        _recorder[0] = None
+        return False
+
+    def poison(self, why: str):
+        if self.poisoned is None:
+            self.poisoned = why
+
+    def python(self, fn, *args, stream=None):
+        self._flush()
+        fn(*args)
+        self.items.append(('py', fn, args, stream))
+
+    def _flush(self):
+        if not self.calls:
+            return
+        arr = (Call * len(self.calls))()
+        for c, (op, kinds, args) in zip(arr, self.calls):
+            c.op, c.nargs = op, len(kinds)
+            for slot, kind, v in zip(c.a, kinds, args):
+                if kind == 'i':
+                    slot.i = int(v)
+                elif kind == 'd':
+                    slot.d = float(v)
+                elif v is None:
+                    slot.p = None
+                elif isinstance(v, int):
+                    slot.p = v
+                elif isinstance(v, C.c_void_p):
+                    slot.p = v.value
+                else:
+                    # a by-reference struct (C.byref(obj)) or a ctypes array passed as a pointer: the record owns a copy
+                    obj = getattr(v, '_obj', v)
+                    copy = type(obj).from_buffer_copy(obj)
+                    self.keep.append(copy)
+                    slot.p = C.addressof(copy)
+        self.items.append(('c', arr, len(self.calls)))
+        self.n_calls += len(self.calls)
+        self.calls = []
+
+    def finish(self):
+        self._flush()
+        if self.poisoned is not None:
+            return None
+        return Phase(self.items, self.keep, self.n_calls)
+
+
+def recording() -> 'Recorder | None':
+    return _recorder[0]
+
+
+def poison(why: str):
+    """called from code paths a recorded launch list cannot reproduce (torch ops between launches, host synchronisation,
+    measuring launches): the phase being recorded, if any, is dropped and the step stays eager"""
+    rec = _recorder[0]
+    if rec is not None:
+        rec.poison(why)

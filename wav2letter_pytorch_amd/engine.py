@@ -58,6 +58,33 @@ def roundup(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+def zeros(shape, dtype, device) -> torch.Tensor:
+    """torch.zeros through the library's fill (w2l_fill_zero: an entry point, so a recorded launch list replays it)"""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if t.is_cuda:
+        check(lib.w2l_fill_zero(ptr(t), t.numel() * t.element_size(), stream_ptr()), 'w2l_fill_zero')
+    else:
+        t.zero_()
+    return t
+
+
+def zero_(t: torch.Tensor) -> torch.Tensor:
+    if t.is_cuda and t.is_contiguous():
+        check(lib.w2l_fill_zero(ptr(t), t.numel() * t.element_size(), stream_ptr()), 'w2l_fill_zero')
+    else:
+        t.zero_()
+    return t
+
+
+def _py(fn, *args):
+    """a Python callback between launches (optimizer / reducer hooks): run now, and -- while a phase is being recorded -- kept
+    in sequence in the record, with the stream that is current here"""
+    rec = _lib.recording()
+    if rec is None:
+        return fn(*args)
+    rec.python(fn, *args, stream=torch.cuda.current_stream())
+
+
 def padded_channels(c: int) -> int:
     return roundup(c, 64)
 
@@ -151,7 +178,8 @@ class _PackedW:
     cinp: int
     coutp: int
     src_ptr: int = 0
-    ready: Optional['torch.cuda.Event'] = None      # set by optim.FusedSGD when the pack was written on its side stream
+    ready: Optional['_lib.Event'] = None            # set by optim.FusedSGD when the pack was written on its side stream: the
+                                                    # weight's OWN event (weight_event), recorded again by every update
 
 
 @dataclass
@@ -269,7 +297,7 @@ def pack_weights(conv: ConvSpec, precise: bool, need_dgrad: bool = True) -> _Pac
     if (hit is not None and hit.version == w._version and hit.fwd_hi.device == w.device
             and hit.src_ptr == w.data_ptr()):
         if hit.ready is not None:          # the optimizer updated + packed this weight on its own stream: order after it
-            torch.cuda.current_stream(w.device).wait_event(hit.ready)
+            hit.ready.wait()
             hit.ready = None
         return hit
     cout, cin, kw = w.shape
@@ -285,6 +313,16 @@ def pack_weights(conv: ConvSpec, precise: bool, need_dgrad: bool = True) -> _Pac
     pk = _PackedW(w._version, fwd_hi, fwd_lo, dgr_hi, dgr_lo, cinp, coutp, w.data_ptr())
     cache[precise] = pk
     return pk
+
+
+def weight_event(w) -> '_lib.Event':
+    """the ONE event of a conv weight that every fused update of it records (on whichever stream runs the update) and the next
+    forward convolution of that layer waits for.  One persistent event per weight rather than a fresh one per step: a recorded
+    forward pass waits for the same handles whichever step -- eager or replayed -- made the update before it."""
+    ev = w.__dict__.get('_w2l_ready_ev')
+    if ev is None:
+        ev = w.__dict__['_w2l_ready_ev'] = _lib.Event()
+    return ev
 
 
 def invalidate_packed(params) -> int:
@@ -311,9 +349,14 @@ def _padded_vec(v: Optional[torch.Tensor], cp: int, fill: float) -> Optional[tor
         return None
     v = v.detach()
     if v.dtype != torch.float32:
+        _lib.poison('a per-channel vector that is not fp32')
         v = v.float()
     if v.numel() == cp and v.is_contiguous():
         return v
+    if v.is_cuda and v.is_contiguous():
+        out = torch.empty(cp, dtype=torch.float32, device=v.device)
+        check(lib.w2l_pad_vec_f32(ptr(v), v.numel(), ptr(out), cp, float(fill), stream_ptr()), 'w2l_pad_vec_f32')
+        return out
     out = torch.full((cp,), fill, dtype=torch.float32, device=v.device)
     out[: v.numel()] = v
     return out
@@ -329,6 +372,7 @@ def _splitk_workspace(dev, n, cout, tout):
     need = min(int(lib.w2l_conv_splitk_workspace_bytes(n, cout, tout)), SPLITK_WS_CAP)
     ws = _splitk_ws.get(dev.index)
     if ws is None or ws.numel() < need:
+        _lib.poison('split-K workspace grown')
         ws = torch.zeros(need, dtype=torch.uint8, device=dev)
         _splitk_ws[dev.index] = ws
     return ws
@@ -347,6 +391,7 @@ def _side_stream(dev, main=None) -> 'torch.cuda.Stream':
     st = _side_streams.get(dev.index)
     if st is None:
         from .streams import concurrent_stream
+        _lib.poison('side stream created')
         st = concurrent_stream(dev, 'wgrad', main=main)
         _side_streams[dev.index] = st
     return st
@@ -414,6 +459,7 @@ def _wgrad_workspace(dev, cin, cout, kw):
     if ws is None or ws.numel() < need:
         if ws is not None:
             _retired_ws.append(ws)         # side-stream kernels may still be using it: never hand the memory back
+        _lib.poison('weight-gradient workspace grown')
         ws = torch.zeros(need, dtype=torch.uint8, device=dev)
         _wgrad_ws[dev.index] = ws
     return ws
@@ -437,6 +483,7 @@ def _igemm(x: Act, row_off: int, w_hi, w_lo, y, bias, stats, Cin, Cout, Tout, Kw
             if key not in _tuned_shapes:       # once per shape and device, during the first (warm-up) step
                 _tuned_shapes.add(key)
                 _tune_state['dirty'] = True
+                _lib.poison('measuring launches')
                 check(lib.w2l_conv1d_igemm_tune_ws(xptr(x.hi), bstride, rows_total, ptr(w_hi), ptr(y),
                                                    int(y.dtype == torch.float32), ptr(bias), ptr(stats), n, Cin, Cout, Tout,
                                                    Kw, stride, dil, TUNE_REPS, ptr(ws), ws.numel(), st), 'w2l_conv1d_igemm_tune_ws')
@@ -484,6 +531,9 @@ FP8_WGRAD = os.environ.get('W2L_FP8_WGRAD', 'auto')
 JOIN_EVENTS = None                 # a list: backward() appends (event on the main stream, event on the weight-gradient stream) at its join
 
 
+_fp8_epoch = [0]                   # bumped whenever a weight adopts a new e4m3 scale (replay.py: records made before are stale)
+
+
 def _pow2_scale(amax: float) -> float:
     """the largest power of two s with amax * s <= 448 (e4m3's largest finite value)"""
     return 2.0 ** math.floor(math.log2(448.0 / max(float(amax), 1e-30)))
@@ -502,6 +552,7 @@ def _fp8_weights(conv: ConvSpec, pk: '_PackedW', dgrad: bool = False):
     w = conv.weight
     st = w.__dict__.get('_w2l_fp8')
     if st is None or st['q'].shape != pk.fwd_hi.shape or st['q'].device != pk.fwd_hi.device:
+        _lib.poison('fp8 weight scale: first use')
         mn, mx = torch.aminmax(pk.fwd_hi)
         scale = _pow2_scale(max(-float(mn), float(mx)))          # host sync: first use only
         dev = pk.fwd_hi.device
@@ -514,12 +565,15 @@ def _fp8_weights(conv: ConvSpec, pk: '_PackedW', dgrad: bool = False):
         if req is not None and st['age'] >= FP8_RESCALE_LAG:
             ev, host = req
             ev.synchronize()                                         # FP8_RESCALE_LAG versions old: returns at once
+            _lib.poison('fp8 weight scale: adoption point')
             st['req'] = None
             scale = _pow2_scale(max(-float(host[0]), float(host[1])))
             if scale != st['scale']:
                 st['scale'] = scale
+                _fp8_epoch[0] += 1                                   # recorded launch lists carry the old scale by value
                 st['version'] = st['version_d'] = None               # both layouts are requantised below / by the data gradient
         elif req is None and st['age'] >= FP8_WEIGHT_RESCALE:
+            _lib.poison('fp8 weight scale: amax request')
             host = torch.empty(2, dtype=torch.float32, pin_memory=True)
             host.copy_(torch.stack(torch.aminmax(pk.fwd_hi)).float(), non_blocking=True)
             ev = torch.cuda.Event()
@@ -652,7 +706,7 @@ class StackEngine:
                         need += STAT_SLOTS * 2 * padded_channels(c.cout)
             fold = need > 0
             if fold:
-                self._stat_pool = [torch.zeros(need, dtype=torch.float32, device=x.device), 0]
+                self._stat_pool = [zeros(need, torch.float32, x.device), 0]
         lib.w2l_conv_stats_mode(STAT_SLOTS if fold else 0)        # (thread-local: this thread's launches)
         x = x.contiguous().float()
         dev = x.device
@@ -731,6 +785,7 @@ class StackEngine:
                 out_q = torch.empty(N, opl + Tout + opr, coutp, dtype=torch.uint8, device=dev)
                 q_scale = FP8_ACT_SCALE[u.act]
                 if self._q_clipped is None or self._q_clipped.device != dev:
+                    _lib.poison('fp8 saturation counter created')
                     self._q_clipped = torch.zeros(1, dtype=torch.int64, device=dev)
                 d.q_clipped = self._q_clipped.data_ptr()
             if fins[0] is not None or fins[1] is not None:
@@ -739,6 +794,7 @@ class StackEngine:
                 check(lib.w2l_bn_act_fwd_fin(C.byref(d), C.byref(f1), C.byref(f2) if f2 is not None else None, ptr(out_hi),
                                              ptr(out_q), q_scale, opl + Tout + opr, opl, opr, omode, st()), 'w2l_bn_act_fwd_fin')
                 for rm, rv, rm_p, rv_p in self._after_apply:       # running statistics of a channel count that is padded
+                    _lib.poison('running statistics of a padded channel count')
                     rm.copy_(rm_p[: rm.numel()])
                     rv.copy_(rv_p[: rv.numel()])
                 self._after_apply = []
@@ -750,7 +806,7 @@ class StackEngine:
             ctx['units'].append(uc)
 
         if self._nbt_pending:
-            torch._foreach_add_(self._nbt_pending, 1)
+            self._bump_counters(self._nbt_pending)
             self._nbt_pending = []
         if fold:
             lib.w2l_conv_stats_mode(0)
@@ -760,6 +816,7 @@ class StackEngine:
         ctx['lens_out'] = lens_final
         last = acts[-1]
         if self.head is None:           # open stack: hand the last activation back in the caller's layout (cold path, torch ops)
+            _lib.poison('open stack')
             a = last.hi[:, last.pad_l:last.pad_l + last.T, :last.C].float()
             if last.lo is not None:
                 a = a + last.lo[:, last.pad_l:last.pad_l + last.T, :last.C].float()
@@ -772,8 +829,23 @@ class StackEngine:
               'w2l_log_softmax_fwd')
         ctx['out'] = out
         for hook in list(AFTER_FORWARD):
-            hook()
+            _py(hook)
         return out, ctx
+
+    def _bump_counters(self, tensors):
+        """num_batches_tracked += 1 of every BatchNorm1d that ran in training mode (wav2letter.py:37), one launch: a device
+        table of the counters' addresses, built once per set of counters"""
+        if not tensors[0].is_cuda or any(t.dtype != torch.int64 for t in tensors):
+            _lib.poison('BatchNorm counters off the device')
+            torch._foreach_add_(tensors, 1)
+            return
+        key = tuple(t.data_ptr() for t in tensors)
+        hit = self.__dict__.get('_nbt_table')
+        if hit is None or hit[0] != key:
+            _lib.poison('BatchNorm counter table built')
+            table = torch.tensor(key, dtype=torch.int64).to(tensors[0].device)
+            hit = self.__dict__['_nbt_table'] = (key, table, list(tensors))
+        check(lib.w2l_add_i64_multi(ptr(hit[1]), len(key), 1, stream_ptr()), 'w2l_add_i64_multi')
 
     def fp8_saturated(self, reset: bool = True) -> int:
         """fp8 mode: how many activation elements saturated the e4m3 range (|a| * scale > 448) since the last reset.
@@ -807,7 +879,26 @@ class StackEngine:
         if lens is None or not any(u.update_lens or u.mask_out for u in self.units):
             return None, mid, outl, None
         on_host = not lens.is_cuda
-        cur = lens.to(torch.int32) if on_host else lens.to(device=dev, dtype=torch.int32)
+        if on_host:
+            # host lengths: the chain in numpy float32 (same operations, same order as the device branch below), ONE upload --
+            # into the record set's static table while a step is being recorded / replayed (replay.py)
+            from .replay import lens_rows_host
+            rows, mid_has, out_has, final = lens_rows_host(self, lens)
+            st = getattr(self, '_lens_static', None)
+            if st is not None:
+                st['host'].numpy()[...] = rows
+                st['dev'].copy_(st['host'], non_blocking=True)
+                st['event'].record()
+                packed = st['dev']
+            else:
+                packed = torch.from_numpy(rows).pin_memory().to(dev, non_blocking=True)
+            it = iter(packed.unbind(0))
+            first_d = next(it)
+            mid = [next(it) if h else None for h in mid_has]
+            outl = [next(it) if h else None for h in out_has]
+            return first_d, mid, outl, final
+        _lib.poison('lengths on the device')
+        cur = lens.to(device=dev, dtype=torch.int32)
         first = cur
         cur_f = cur.float()
         for ui, u in enumerate(self.units):
@@ -822,15 +913,7 @@ class StackEngine:
                 cur = cur_f.to(torch.int32)
             if u.mask_out:
                 outl[ui] = cur
-        if not on_host:
-            return first, mid, outl, cur_f
-        rows = [first] + [t for t in mid if t is not None] + [t for t in outl if t is not None]
-        packed = torch.stack(rows).pin_memory().to(dev, non_blocking=True)
-        it = iter(packed.unbind(0))
-        first_d = next(it)
-        mid = [next(it) if t is not None else None for t in mid]
-        outl = [next(it) if t is not None else None for t in outl]
-        return first_d, mid, outl, cur_f
+        return first, mid, outl, cur_f
 
     def _conv_forward(self, conv: ConvSpec, src: Act, need_stats: bool, force_f32: bool = False):
         if src.pad_l < conv.pad_l or src.pad_r < conv.pad_r:
@@ -896,6 +979,7 @@ class StackEngine:
         km = w.permute(2, 0, 1).reshape(k, c)            # no copy for the tap-major parameter layout
         if cp == c and km.is_contiguous():
             return km
+        _lib.poison('depthwise weight of a padded channel count')
         out = torch.zeros(k, cp, dtype=torch.float32, device=w.device)
         out[:, :c] = km
         return out
@@ -926,7 +1010,7 @@ class StackEngine:
         row_off = src.pad_l - dwc.pad_l
         off = row_off * cp * 2
         k = dwc.kernel
-        dwg = torch.zeros(k, cp, dtype=torch.float32, device=dev)
+        dwg = zeros((k, cp), torch.float32, dev)
         check(lib.w2l_dwconv_wgrad(ptr(g), int(g.dtype == torch.float32), per, C.c_void_p(src.hi.data_ptr() + off),
                                    C.c_void_p(src.lo.data_ptr() + off) if src.lo is not None else None, src.rows, ptr(dwg), N,
                                    mid.T, cp, k, dwc.stride, dwc.dilation, ptr(mid.lens), stream_ptr()), 'w2l_dwconv_wgrad')
@@ -938,6 +1022,7 @@ class StackEngine:
         Tp = src.T + dwc.pad_l + dwc.pad_r
         tmid, lens_mid = mid.T, mid.lens
         if dwc.stride != 1:                # cold path (spectrogram gradient only): zero-stuff to stride 1
+            _lib.poison('strided depthwise data gradient')
             s_ = dwc.stride
             tup = (mid.T - 1) * s_ + 1
             up = torch.zeros(N, tup, cp, dtype=g.dtype, device=dev)
@@ -969,6 +1054,7 @@ class StackEngine:
                                       ptr(rm_p), ptr(rv_p), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
                                       stream_ptr()), 'w2l_bn_finalize')
             if padded_running:
+                _lib.poison('running statistics of a padded channel count')
                 rm.copy_(rm_p[: rm.numel()])
                 rv.copy_(rv_p[: rv.numel()])
             if conv.num_batches_tracked is not None:
@@ -1052,7 +1138,7 @@ class StackEngine:
         for uc in ctx['units']:
             if uc.unit.main.has_bn or (uc.unit.res is not None and uc.unit.res.has_bn):
                 pool_elems += 4 * acts[uc.out_index].CP
-        small_pool = torch.zeros(pool_elems, dtype=torch.float32, device=dev)       # rows of absent residual branches stay 0
+        small_pool = zeros(pool_elems, torch.float32, dev)       # rows of absent residual branches stay 0
         pool_off = 0
         # the two-launch BatchNorm-backward chain (FAST_BN_BWD): STAT_SLOTS zero rows per plain unit, ONE fill per step; the
         # data gradients that form the sums in their epilogue (w2l_conv1d_dgrad_bnreduce_ws) add onto the same rows
@@ -1061,13 +1147,14 @@ class StackEngine:
         if FAST_BN_BWD and not DETERMINISTIC_WGRAD and batch_stats and not self.precise and dev.type == 'cuda':
             need = sum(STAT_SLOTS * 2 * acts[uc.out_index].CP for uc in ctx['units'] if uc.unit.main.has_bn and uc.unit.res is None)
             if need:
-                self._slot_pool = [torch.zeros(need, dtype=torch.float32, device=dev), 0, {}]
+                self._slot_pool = [zeros(need, torch.float32, dev), 0, {}]
         lib.w2l_conv_stats_mode(STAT_SLOTS if self._slot_pool is not None else 0)
         lib.w2l_wgrad_deterministic(int(DETERMINISTIC_WGRAD))
         act_grads: List[List[tuple]] = [[] for _ in acts]
         if self.head is None:
             # open stack: the caller's gradient wrt the fp32 [N, C, T'] result becomes the (unpadded, fp32) gradient source
             last = acts[-1]
+            _lib.poison('open stack')
             gp = torch.zeros(N, last.T, last.CP, dtype=torch.float32, device=dev)
             gp[:, :, :last.C] = g_out.float().transpose(1, 2)
             act_grads[len(acts) - 1].append((gp, 0, 0, PAD_ZERO, last.T))
@@ -1082,16 +1169,16 @@ class StackEngine:
         self._wg_of = {}
         ctx['input_grad'] = self.input_grad(ctx, act_grads[0]) if ctx.get('want_dx') and act_grads[0] else None
         if self.flat_ready is not None:
-            self.flat_ready(small_pool)
+            _py(self.flat_ready, small_pool)
         elif self.grad_ready is not None:
-            self.grad_ready(None, small_pool, small_pool)
+            _py(self.grad_ready, None, small_pool, small_pool)
         if self._side_used:
             if JOIN_EVENTS is not None:        # tools/stream_lag.py: which stream does the backward pass end on?
                 em, es = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 em.record(self._main_stream)
                 es.record(self._side)
                 JOIN_EVENTS.append((em, es))
-            self._main_stream.wait_stream(self._side)
+            _lib.stream_wait_stream(self._main_stream, self._side)
             self._side_used = False
         self._main_stream = None
         self._held.clear()
@@ -1101,7 +1188,7 @@ class StackEngine:
         lib.w2l_conv_stats_mode(0)
         _flush_tune_cache()
         if self.backward_done is not None:
-            self.backward_done()
+            _py(self.backward_done)
         return [grads.get(id(p)) for p in self.parameters()]
 
     def _head_backward(self, ctx, g_out, small_pool, grads, act_grads) -> int:
@@ -1155,7 +1242,7 @@ class StackEngine:
         N = ctx['out'].shape[0]
         dev = ctx['out'].device
         st = stream_ptr
-        amax_pool = (torch.zeros(len(acts) + 1, 2, AMAX_SLOTS, dtype=torch.float32, device=dev)        # one fill per step
+        amax_pool = (zeros((len(acts) + 1, 2, AMAX_SLOTS), torch.float32, dev)        # one fill per step
                      if self.fp8 else None)
         slot_pool = self._slot_pool    # zero rows the two-launch BatchNorm-backward chain adds its sums onto (backward())
         for uc in reversed(ctx['units']):
@@ -1302,6 +1389,7 @@ class StackEngine:
         (cold path, torch ops: fold the reflected halo rows back, un-pad, back to channels-first)"""
         N, C0, T0 = ctx['x_shape']
         a0 = ctx['acts'][0]
+        _lib.poison('spectrogram gradient')
         total = None
         for (g, pl, pr, mode, per, *_) in srcs:
             gv = g.view(N, per, a0.CP)[:, :pl + T0 + pr, :C0].float()
@@ -1320,6 +1408,7 @@ class StackEngine:
     @staticmethod
     def _dy_colsum(dy_hi, dy_lo, halo, N, Tout, coutp, cout) -> torch.Tensor:
         """bias gradient sum_{n,t} dy of a conv that is not followed by batch-statistics BatchNorm (cold path, torch ops)"""
+        _lib.poison('bias gradient of a convolution without BatchNorm')
         v = dy_hi[halo:].view(N, Tout + halo, coutp)[:, :Tout, :cout].float()
         if dy_lo is not None:
             v = v + dy_lo[halo:].view(N, Tout + halo, coutp)[:, :Tout, :cout].float()
@@ -1335,7 +1424,7 @@ class StackEngine:
                 for c in (u.main, u.res):
                     if c is not None and c.bias is not None and c.has_bn:
                         total += roundup(c.cout, 64)
-            pool = [torch.zeros(max(total, need), dtype=torch.float32, device=dev), 0]
+            pool = [zeros(max(total, need), torch.float32, dev), 0]
             self._zero_pool = pool
         out = pool[0][pool[1]: pool[1] + n]
         pool[1] += need
@@ -1343,7 +1432,7 @@ class StackEngine:
 
     def _notify(self, param, grad, storage=None):
         if self.grad_ready is not None:
-            self.grad_ready(param, grad, storage)
+            _py(self.grad_ready, param, grad, storage)
 
     def _set(self, grads, param, grad, storage=None):
         grads[id(param)] = grad
@@ -1502,7 +1591,7 @@ class StackEngine:
     def join_side(self):
         """the current stream waits for the weight-gradient stream (deferred gradients and their updates run there)"""
         if self._side is not None and self._side_used:
-            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+            _lib.stream_wait_stream(_lib.raw_stream(), self._side)
 
     def _wgrad(self, conv: ConvSpec, pk: _PackedW, dy_hi, dy_lo, halo, Tout, src: Act, grads, amax=None, defer=False):
         """dW, optionally on the side stream (ordered after everything enqueued so far on the current stream).
@@ -1650,9 +1739,7 @@ class StackEngine:
             it.Cin, it.Cout, it.Kw = pk.cinp, pk.coutp, conv.kernel
         flops = sum(2.0 * N * Tout * r['pk'].coutp * r['pk'].cinp * r['conv'].kernel for r in recs)
         if fork is not None:
-            ev = torch.cuda.Event()
-            ev.record(fork[0])
-            fork[1].wait_event(ev)
+            _lib.stream_wait_stream(fork[1], fork[0])
             self._held.extend(dws)
             self._held.extend(t for r in recs for t in (r['dy_hi'], r['src'].hi) if t is not None)
             self._side_used = True
@@ -1745,9 +1832,7 @@ class StackEngine:
         if (recycled is not None and need_zero and w.grad is None and recycled.device == dev and recycled.is_contiguous()
                 and tuple(recycled.shape) == (kw, pk.coutp, pk.cinp)):
             if fork is not None:
-                ev = torch.cuda.Event()
-                ev.record(fork[0])
-                fork[1].wait_event(ev)
+                _lib.stream_wait_stream(fork[1], fork[0])
                 self._held.append(recycled)
                 with torch.cuda.stream(fork[1]):
                     return self._wgrad_launch(conv, pk, recycled, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride,
@@ -1758,17 +1843,15 @@ class StackEngine:
             # allocated on the main stream (the caching allocator then owns it there), zero-filled on the side stream:
             # the fill of a split-K gradient is as far off the critical path as the kernel that accumulates into it
             dw = torch.empty(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
-            ev = torch.cuda.Event()
-            ev.record(fork[0])
-            fork[1].wait_event(ev)
+            _lib.stream_wait_stream(fork[1], fork[0])
             self._held.append(dw)
             with torch.cuda.stream(fork[1]):
                 if need_zero:
-                    dw.zero_()
+                    zero_(dw)
                 return self._wgrad_launch(conv, pk, dw, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total,
                                           dy_bstride, row_off, direct, ws, f8, sink)
-        alloc = torch.zeros if need_zero else torch.empty
-        dw = alloc(kw, pk.coutp, pk.cinp, dtype=torch.float32, device=dev)
+        dw = (zeros if need_zero else (lambda shape, dtype, device: torch.empty(shape, dtype=dtype, device=device)))(
+            (kw, pk.coutp, pk.cinp), torch.float32, dev)
         return self._wgrad_launch(conv, pk, dw, dy_hi, dy_lo, halo, Tout, src, grads, x_bstride, x_rows_total, dy_bstride,
                                   row_off, direct, ws, f8, sink)
 
@@ -1875,6 +1958,7 @@ class StackEngine:
             def stuff(t):
                 if t is None:
                     return None
+                _lib.poison('strided data gradient')
                 up = torch.zeros(hup + N * (Tup + hup), pk.coutp, dtype=t.dtype, device=t.device)
                 up[hup:].view(N, Tup + hup, pk.coutp)[:, 0:Tup:s_] = t[halo:].view(N, Tout + halo, pk.coutp)[:, :Tout]
                 return up
@@ -1915,6 +1999,7 @@ class StackEngine:
         _igemm(dyact, halo - hb, pk.dgr_hi, pk.dgr_lo, dxp, None, None, pk.coutp, pk.cinp, flat_rows, conv.kernel, 1,
                conv.dilation, self.precise, alg_flops=flops)
         if per < Tp:                      # strided case: the last (Tp - Tup - hb) padded rows receive no gradient
+            _lib.poison('strided data gradient')
             full = torch.zeros(N, Tp, pk.cinp, dtype=dxp.dtype, device=dev)
             full[:, :per] = dxp.view(N, per, pk.cinp)
             return (full, conv.pad_l, conv.pad_r, conv.pad_mode, Tp)

@@ -193,6 +193,12 @@ class _StackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        from . import replay
+        rp = ctx.engine.__dict__.get('_replayer')
+        if rp is not None:                 # an eager backward pass: whatever it holds back is the eager engine's to launch
+            rp.before_eager()
+            rp.pending = None
+        replay._last_backward[0] = None
         grads = ctx.engine.backward(ctx.ectx, g)
         dx = ctx.ectx.get('input_grad')
         ctx.ectx = None
@@ -200,8 +206,18 @@ class _StackFn(torch.autograd.Function):
 
 
 def run_stack(engine: StackEngine, x, lens, training: bool, softmax_mode: int = 0, keep_ctx: bool = False):
-    """Returns (out, lens_out[, engine ctx when keep_ctx: test hook that exposes the saved activations])."""
+    """Returns (out, lens_out[, engine ctx when keep_ctx: test hook that exposes the saved activations]).
+    A warm training step is recorded once and replayed from then on (replay.py: one w2l_replay call per phase)."""
+    from . import replay
     holder = {'keep_ctx': keep_ctx}
+    rp = replay.replayer_for(engine) if x.is_cuda else None
+    if rp is not None:
+        plan = rp.plan_forward(x, lens, training, softmax_mode, keep_ctx)
+        if plan is not None:
+            out = replay._ReplayFn.apply(x, engine, lens, softmax_mode, holder, plan[0], plan[1], *engine.parameters())
+            return out, holder.get('lens_out')
+        rp.before_eager()
+        rp.flush_pending()                 # (a recorded set's held-back gradients, replayed; anything else is left to forward())
     out = _StackFn.apply(x, engine, lens, training, softmax_mode, holder, *engine.parameters())
     if keep_ctx:
         return out, holder.get('lens_out'), holder.get('ctx')

@@ -25,6 +25,7 @@ import weakref
 
 import torch
 
+from . import _lib
 from . import engine as E
 from ._lib import check, lib, ptr, stream_ptr
 
@@ -118,8 +119,8 @@ class FusedSGD(torch.optim.SGD):
         ok, group, hp = self._deferred_state()['hp'][id(p)]
         lr, mu, wd, nesterov = hp
         pk = self._fused_conv(p, g, lr, mu, wd, nesterov)
-        pk.ready = torch.cuda.Event()
-        pk.ready.record(torch.cuda.current_stream(p.device))
+        pk.ready = E.weight_event(p)
+        pk.ready.record()
 
     def join(self):
         """make the current stream wait for every update of the last step: deferred weight gradients are launched and
@@ -133,7 +134,7 @@ class FusedSGD(torch.optim.SGD):
         """make the current stream wait for the updates still running on the optimizer's side stream"""
         st = self._side_state()
         if st['pending'] and st['stream'] is not None:
-            torch.cuda.current_stream(st['stream'].device).wait_stream(st['stream'])
+            _lib.stream_wait_stream(_lib.raw_stream(), st['stream'])
         st['pending'] = False
         st['held'], st['packs'] = [], []
         if self._release_held in E.AFTER_FORWARD:
@@ -158,6 +159,19 @@ class FusedSGD(torch.optim.SGD):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        # the gradients of a recorded / replayed backward pass: the step is replayed as ONE w2l_replay call, or recorded now
+        from . import replay
+        if replay._last_backward[0] is not None and replay.optimizer_step(self, self._step_eager):
+            return loss
+        self._step_eager()
+        return loss
+
+    def _step_eager(self):
+        rp_hit = None
+        for eng in self._engines():
+            rp_hit = eng.__dict__.get('_replayer') or rp_hit
+        if rp_hit is not None:
+            rp_hit.before_eager()
         self._join_updates()         # (normally a no-op: the forward pass has already waited for every event)
         for eng in self._engines():  # a weight with BOTH a held-back gradient and a .grad gets one update with their sum
             eng.settle_before_step()
@@ -193,28 +207,30 @@ class FusedSGD(torch.optim.SGD):
             dev = fused[0][0].device
             if st['stream'] is None or st['stream'].device != dev:
                 from .streams import concurrent_stream        # measured to run beside the main and weight-gradient streams
+                _lib.poison('optimizer side stream created')
                 st['stream'] = concurrent_stream(dev, 'sgd')
             side = st['stream']
-            side.wait_stream(torch.cuda.current_stream(dev))     # gradients (wgrad join, all-reduce) are complete there
+            _lib.stream_wait_stream(side, _lib.raw_stream())     # gradients (wgrad join, all-reduce) are complete there
             with torch.cuda.stream(side):
                 for p, g in fused:               # parameter order = forward order: layer 0's event fires first
                     pk = self._fused_conv(p, g, lr, mu, wd, nesterov)
-                    pk.ready = torch.cuda.Event()
+                    pk.ready = E.weight_event(p)
                     pk.ready.record(side)
                     st['held'].append(g)         # zero_grad() must not hand this memory back while the kernel reads it
                     st['packs'].append(pk)
             st['pending'] = True
             if self._release_held not in E.AFTER_FORWARD:
                 E.AFTER_FORWARD.append(self._release_held)
-        return loss
 
     def _fused_conv(self, p, g, lr, mu, wd, nesterov):
         state = self.state[p]
         first = 'momentum_buffer' not in state or state['momentum_buffer'] is None
         if first:
+            _lib.poison('momentum buffer created')
             state['momentum_buffer'] = torch.empty_like(p)           # preserves the tap-major strides
         buf = state['momentum_buffer']
         if buf.stride() != p.stride():
+            _lib.poison('momentum buffer re-laid out')
             buf = torch.empty_like(p).copy_(buf)
             state['momentum_buffer'] = buf
         cout, cin, kw = p.shape
@@ -228,6 +244,7 @@ class FusedSGD(torch.optim.SGD):
         if old is not None and old.fwd_hi.device == dev and old.coutp == cout and old.cinp == cin:
             fwd_hi, fwd_lo, dgr_hi, dgr_lo = old.fwd_hi, old.fwd_lo, old.dgr_hi, old.dgr_lo
         else:
+            _lib.poison('operand pack buffers created')
             fwd_hi = torch.empty(kw, cout, cin, dtype=torch.bfloat16, device=dev)
             dgr_hi = torch.empty(kw, cin, cout, dtype=torch.bfloat16, device=dev)
             fwd_lo = torch.empty_like(fwd_hi) if precise else None
@@ -256,7 +273,59 @@ class FusedSGD(torch.optim.SGD):
             f8['age'] += 1
         return pk
 
+    def _small_multi(self, params, lr, mu, wd, nesterov) -> bool:
+        """torch.optim.SGD's update of all the small parameters (conv biases, BatchNorm gamma / beta) in ONE launch
+        (w2l_sgd_small_multi) instead of five torch._foreach_* calls over ~60 tensors: a device table of (p, g, m, n) built once
+        per set of addresses (``params``: those _multi_ok admits); an entry point, so a recorded launch list replays it."""
+        rows = []
+        for p in params:
+            g = p.grad
+            m = self.state[p].get('momentum_buffer') if mu != 0 else None
+            rows.append((p.data_ptr(), g.data_ptr(), m.data_ptr() if m is not None else 0, p.numel()))
+        key = tuple(rows)
+        cache = self.__dict__.setdefault('_w2l_small_tables', {})
+        table = cache.get(key)
+        if table is None:
+            # (built while the optimizer phase of a step is being recorded, the table lives in that phase's own memory pool:
+            # a live allocation nothing else of the record ever writes -- no reason to drop the recording)
+            if len(cache) > 8:
+                cache.clear()
+            flat = []
+            for pp, gp, mp, n in rows:
+                flat += [pp, gp, mp, n]                    # w2l_sgd_small_t: three pointers, then {int32 n, int32 pad} = one int64 < 2^31
+            table = cache[key] = torch.tensor(flat, dtype=torch.int64).to(params[0].device)
+        check(lib.w2l_sgd_small_multi(ptr(table), len(rows), float(lr), float(mu), float(wd), int(nesterov), stream_ptr()),
+              'w2l_sgd_small_multi')
+        for p in params:
+            torch.autograd.graph.increment_version(p)
+        return True
+
+    def _multi_ok(self, p, mu) -> bool:
+        """may this parameter take the one-launch elementwise update?  fp32 on the device, dense, and gradient / momentum
+        buffer in the parameter's own physical layout (contiguous, or -- a depthwise conv weight -- the tap-major permutation)"""
+        def same_layout(a, b):          # (the stride of a size-1 dimension means nothing)
+            return a.shape == b.shape and all(sa == sb for n, sa, sb in zip(a.shape, a.stride(), b.stride()) if n > 1)
+
+        g = p.grad
+        if not p.is_cuda or p.dtype != torch.float32 or g.dtype != torch.float32 or g.device != p.device or not same_layout(g, p):
+            return False
+        if not (p.is_contiguous() or (p.dim() == 3 and p.permute(2, 0, 1).is_contiguous())):
+            return False
+        if mu != 0:
+            m = self.state[p].get('momentum_buffer')
+            if m is None or not same_layout(m, p) or m.dtype != torch.float32:
+                return False
+        return True
+
     def _plain(self, params, lr, mu, wd, nesterov, dampening, maximize):
+        if not maximize and dampening == 0 and params:
+            multi = [p for p in params if self._multi_ok(p, mu)]
+            if multi and self._small_multi(multi, lr, mu, wd, nesterov):
+                if len(multi) == len(params):
+                    return
+                taken = set(id(p) for p in multi)
+                params = [p for p in params if id(p) not in taken]
+        _lib.poison('torch foreach update of the small parameters')
         grads = [p.grad for p in params]
         if maximize:
             grads = torch._foreach_neg(grads)
