@@ -89,7 +89,7 @@ def test_replayed_steps_equal_eager_steps_w2l(defer, monkeypatch):
     assert st['recorded'] == 2 and st['replayed_F'] >= 5 and st['replayed_B'] >= 5 and st['replayed_O'] >= 5, st
     if defer:
         assert st['replayed_X'] >= 4, st
-    sets = rep['shapes'][0]['sets']
+    sets = max(rep['shapes'], key=lambda g: g['seen'])['sets']      # (the first step ran under another key: no weight events yet)
     assert all(s['F'] and s['B'] and s['O'] and s['python_items'] <= 1 for s in sets), rep
     assert le == lr_, (le, lr_)
     for k in pe:
@@ -153,7 +153,8 @@ def test_replay_jasper_ragged_lengths(monkeypatch):
     make48 = lambda: build_jasper(meta48['blocks'], sd48, 'bf16')          # noqa: E731
     le, pe, _, _ = _run(make48, batches, 8, False)
     lr_, pr, st, rep = _run(make48, batches, 8, True)
-    assert st['replayed_F'] == 0 and rep['shapes'][0]['disabled'] is not None and 'padded' in rep['shapes'][0]['disabled'], (st, rep)
+    gave_up = [g['disabled'] for g in rep['shapes'] if g['disabled']]
+    assert st['replayed_F'] == 0 and gave_up and 'padded' in gave_up[0], (st, rep)
     assert le == lr_
     for k in pe:
         assert np.array_equal(pe[k], pr[k]), k

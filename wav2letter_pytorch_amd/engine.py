@@ -294,15 +294,34 @@ def pack_weights(conv: ConvSpec, precise: bool, need_dgrad: bool = True) -> _Pac
         cache = _Volatile()
         w._w2l_pack = cache
     hit = cache.get(precise)
-    if (hit is not None and hit.version == w._version and hit.fwd_hi.device == w.device
-            and hit.src_ptr == w.data_ptr()):
-        if hit.ready is not None:          # the optimizer updated + packed this weight on its own stream: order after it
-            hit.ready.wait()
-            hit.ready = None
+    recording = _lib.recording() is not None
+    if hit is not None and hit.fwd_hi.device == w.device and hit.src_ptr == w.data_ptr():
+        fused = w.__dict__.get('_w2l_ready_ev')
+        if hit.version == w._version:
+            if hit.ready is not None:      # the optimizer updated + packed this weight on its own stream: order after it
+                hit.ready.wait()
+                hit.ready = None
+            elif recording and fused is not None:
+                # a recorded forward pass must not depend on which flags happened to be up when it was recorded (an evaluation
+                # forward in front of it has consumed them): it ALWAYS waits for the weight's event -- free when it has fired
+                fused.wait()
+            if not recording or fused is not None:
+                return hit
+        # the weight moved since it was packed (an optimizer that does not pack: torch.optim.*, Novograd on a layer it does
+        # not fuse) -- or a forward pass is being recorded and no fused optimizer maintains this pack, so that the replayed
+        # pass must repack every step whatever the cache says now: packed again INTO THE SAME BUFFERS (every reader of the
+        # old contents is ahead of this launch on the caller's stream; the weight-gradient stream never reads operand packs)
+        cout, cin, kw = w.shape
+        s_co, s_ci, s_kw = _phys_strides(w)
+        check(lib.w2l_pack_weights(ptr(w), s_co, s_ci, s_kw, cout, cin, kw, hit.coutp, hit.cinp, ptr(hit.fwd_hi), ptr(hit.fwd_lo),
+                                   ptr(hit.dgr_hi), ptr(hit.dgr_lo), stream_ptr()), 'w2l_pack_weights')
+        hit.version, hit.ready = w._version, None
         return hit
     cout, cin, kw = w.shape
     coutp, cinp = padded_channels(cout), padded_channels(cin)
     dev = w.device
+    if recording:
+        _lib.poison('operand pack buffers created')        # (new buffers every step: not a step to record; the next one hits)
     fwd_hi = torch.empty(kw, coutp, cinp, dtype=torch.bfloat16, device=dev)
     dgr_hi = torch.empty(kw, cinp, coutp, dtype=torch.bfloat16, device=dev)
     fwd_lo = torch.empty_like(fwd_hi) if precise else None
@@ -322,7 +341,11 @@ def weight_event(w) -> '_lib.Event':
     ev = w.__dict__.get('_w2l_ready_ev')
     if ev is None:
         ev = w.__dict__['_w2l_ready_ev'] = _lib.Event()
+        _wev_epoch[0] += 1                 # forward passes recorded before this weight had an event do not wait for it: stale
     return ev
+
+
+_wev_epoch = [0]
 
 
 def invalidate_packed(params) -> int:

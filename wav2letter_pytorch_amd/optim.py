@@ -318,7 +318,9 @@ class FusedSGD(torch.optim.SGD):
         return True
 
     def _plain(self, params, lr, mu, wd, nesterov, dampening, maximize):
-        if not maximize and dampening == 0 and params:
+        # (not under hipGraph capture: the gradient addresses -- and with them the table -- are the capture's own, and building
+        # the table is a host-to-device copy from pageable memory, which a capturing stream refuses)
+        if not maximize and dampening == 0 and params and not torch.cuda.is_current_stream_capturing():
             multi = [p for p in params if self._multi_ok(p, mu)]
             if multi and self._small_multi(multi, lr, mu, wd, nesterov):
                 if len(multi) == len(params):

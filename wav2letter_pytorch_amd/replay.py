@@ -194,7 +194,7 @@ class StepReplayer:
         defer = eng.defer_wgrad if eng.deferred is not None else 0
         key = (tuple(x.shape), softmax_mode, lens is None, x.device.index, _lib.raw_stream(), self._mode_flags(),
                defer if isinstance(defer, int) else tuple(sorted(defer)), id(eng.deferred), bool(eng.overlap_wgrad),
-               torch.initial_seed())
+               torch.initial_seed(), E._wev_epoch[0])
         self.clock += 1
         g = self.groups.get(key)
         if g is None:
