@@ -413,7 +413,11 @@ def main():
             dt = float(t)
         return dt / k * 1e3
 
-    for _ in range(args.warmup):
+    # steps a configuration needs before it is in its steady state: the eager warm steps of a step shape + the two steps that
+    # record its two launch lists (wav2letter_pytorch_amd/replay.py) + one replayed step of each
+    from wav2letter_pytorch_amd import replay as _replay
+    settle = (_replay.WARM_STEPS + 4) if _replay.ENABLED else 2
+    for _ in range(max(args.warmup, settle)):
         step()
     fence()
 
@@ -429,12 +433,13 @@ def main():
         defer_ab = {}
         for k in cands:
             opt.defer_wgrad(model, defer_spec(k))
-            step()
-            step()
+            for _ in range(settle):          # a new configuration: warm steps, then the two steps that record it (replay.py)
+                step()
             defer_ab[k] = round(timed_ms(5), 3)
         defer_k = min(defer_ab, key=lambda k: defer_ab[k])
         opt.defer_wgrad(model, defer_spec(defer_k))
-        step()
+        for _ in range(settle):
+            step()
         fence()
 
     collective_paths = None
@@ -564,8 +569,8 @@ def main():
         legs += (('async_metrics', trainer_step, True), ('sync_metrics_before', trainer_step, False))
         for name, fn, async_on in legs:
             model.async_metrics = async_on
-            fn()
-            fn()
+            for _ in range(settle):
+                fn()
             fence()
             h0 = time.perf_counter()
             for _ in range(args.steps):
@@ -803,6 +808,8 @@ def main():
             'tune_plans': (None if tune_shas is None else
                            {'shared_from_rank0': tune_path, 'sha16_by_rank': tune_shas, 'identical': len(set(tune_shas)) == 1}),
             'per_gpu_value': round(value / world, 1),
+            # recorded launch lists (replay.py): which step shapes are replayed through one w2l_replay call per phase
+            'replay': _replay.report(model.engine()),
         }
     else:
         line = None

@@ -301,7 +301,7 @@ def pack_weights(conv: ConvSpec, precise: bool, need_dgrad: bool = True) -> _Pac
             if hit.ready is not None:      # the optimizer updated + packed this weight on its own stream: order after it
                 hit.ready.wait()
                 hit.ready = None
-            elif recording and fused is not None:
+            elif recording and fused is not None and _in_forward[0]:
                 # a recorded forward pass must not depend on which flags happened to be up when it was recorded (an evaluation
                 # forward in front of it has consumed them): it ALWAYS waits for the weight's event -- free when it has fired
                 fused.wait()
@@ -346,6 +346,7 @@ def weight_event(w) -> '_lib.Event':
 
 
 _wev_epoch = [0]
+_in_forward = [False]              # (the backward pass looks packs up too: it has nothing to wait for -- its forward already did)
 
 
 def invalidate_packed(params) -> int:
@@ -701,9 +702,11 @@ class StackEngine:
     def forward(self, x: torch.Tensor, lens: Optional[torch.Tensor], training: bool, softmax_mode: int = 0,
                 want_input_grad: bool = False):
         """x fp32 [N, C, T] on device -> (out fp32 [N, T', n_labels], lens_out or None)."""
+        _in_forward[0] = True
         try:
             return self._forward(x, lens, training, softmax_mode, want_input_grad)
         finally:
+            _in_forward[0] = False
             lib.w2l_conv_stats_mode(0)      # thread-local library state: never left in slot mode, whatever was raised
             self._stat_pool = None
 

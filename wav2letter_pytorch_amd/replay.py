@@ -71,6 +71,7 @@ MAX_FAILURES = 3
 FP8_EAGER_EVERY = 256           # fp8 mode: replayed steps between two eager stretches (the e4m3 weight-scale upkeep lives there)
 FP8_EAGER_STEPS = 10
 VERBOSE = os.environ.get('W2L_REPLAY_VERBOSE', '0') == '1'
+LENS_RING = 4
 
 # the record set whose backward pass ran last on this process (a weak reference to its replayer + the set): how
 # optim.FusedSGD.step finds out that the gradients it is about to consume are a record's static buffers
@@ -411,11 +412,19 @@ def _upload_lens(rset, engine, lens):
     st = rset.lens_static
     if st is None or tuple(st['host'].shape) != rows.shape:
         return None, None
-    if st['event'] is not None:
-        st['event'].synchronize()                      # the copy issued from this pinned buffer two steps ago (long done)
-    st['host'].numpy()[...] = rows
-    st['dev'].copy_(st['host'], non_blocking=True)
-    st['event'].record()
+    # a ring of pinned staging buffers: the copy issued from a buffer LENS_RING uses of this set ago (2 x LENS_RING steps) is
+    # long done, so the wait below never holds the host back
+    ring = st.setdefault('ring', [(st['host'], st['event'])])
+    if len(ring) < LENS_RING:
+        ring.append((torch.empty(rows.shape, dtype=torch.int32, pin_memory=True), _lib.Event()))
+        host, ev = ring[-1]
+    else:
+        st['turn'] = (st.get('turn', 0) + 1) % LENS_RING
+        host, ev = ring[st['turn']]
+        ev.synchronize()
+    host.numpy()[...] = rows
+    st['dev'].copy_(host, non_blocking=True)
+    ev.record()
     return st, final
 
 
@@ -426,8 +435,7 @@ def _replay_forward(rp, engine, rset, x, lens):
         if st is None:
             raise RuntimeError('replayed step: the length table of this record set does not fit the batch')
         rset.lens_out = final
-    if x is not rset.x_ref or x.data_ptr() != rset.x_static.data_ptr():
-        rset.x_static.copy_(x, non_blocking=True)
+    rset.x_static.copy_(x, non_blocking=True)
     rp.flush_pending()
     if engine._deferred:                               # what an eager backward held back: launched eagerly, as engine.forward would
         rp.before_eager()
