@@ -787,6 +787,41 @@ def test_ctc_vs_oracle_random(L, N, T, S):
     np.testing.assert_allclose(ld.grad.cpu().numpy(), lr.grad.numpy(), rtol=2e-3, atol=1e-6)
 
 
+def test_ctc_extreme_emissions(L):
+    """the alpha / beta recursion at the edges of fp32: (a) very peaked distributions -- log-probs down to -60; (b) frames where
+    EVERY label an alignment may emit has a log-prob of -100 (its probability underflows fp32: only a log-domain recursion keeps
+    such an utterance finite -- a linear-domain recursion with one power-of-two scale per frame was built in round 6 and dropped
+    for exactly this: states 2^-126 below a column's maximum flush to zero, and with peaked emissions they are the ones whose
+    beta is large, DESIGN Appendix B); (c) in the same batch an infeasible alignment (target longer than the input) ends at
+    +inf -> 0 under zero_infinity, and ordinary utterances are untouched.  Loss and gradients against torch CPU."""
+    from wav2letter_pytorch_amd.ctc_loss import CTCLoss
+    g = torch.Generator().manual_seed(77)
+    N, T, S = 5, 120, 20
+    logits = torch.randn(N, T, 29, generator=g) * 2
+    logits[0] *= 12                                      # (a) peaked: log-probs of the losers around -50
+    tg = torch.randint(1, 29, (N, S), generator=g, dtype=torch.int32)
+    tl = torch.tensor([S, S, 12, S, 7], dtype=torch.int32)
+    il = torch.tensor([T, T, 10, T, 90], dtype=torch.int32)        # utterance 2: 12 labels in 10 frames -- infeasible
+    lp = torch.log_softmax(logits, -1)
+    # (b) utterance 1, frames 40-42: every target label and the blank at -100 (renormalised below by a junk label at ~0)
+    junk = next(c for c in range(1, 29) if c not in set(int(v) for v in tg[1]))
+    for t in (40, 41, 42):
+        lp[1, t, :] = -100.0
+        lp[1, t, junk] = 0.0
+    lr = lp.clone().requires_grad_(True)
+    ref = F.ctc_loss(lr.transpose(0, 1), tg, il, tl, blank=0, reduction='mean', zero_infinity=True)
+    ref.backward()
+    per = F.ctc_loss(lp.transpose(0, 1), tg, il, tl, blank=0, reduction='none', zero_infinity=False)
+    assert torch.isinf(per[2]) and float(per[1]) > 250 and torch.isfinite(per[[0, 1, 3, 4]]).all()
+    ld = lp.cuda().requires_grad_(True)
+    loss = CTCLoss(0, 'mean', True)(ld.transpose(0, 1), tg, il, tl)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) < 1e-4 * max(1.0, abs(float(ref))), (float(loss), float(ref))
+    got, want = ld.grad.cpu().numpy(), lr.grad.numpy()
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-6)
+
+
 def _bnact_desc(L, N, T, C, y, scale, shift, mean, invstd, act, p=0.0, mask=None, lens=None, y2=None, bn2=None):
     d = L.BnActDesc()
     d.N, d.T, d.C = N, T, C

@@ -52,6 +52,8 @@ def main():
         loss.backward()
         opt.step()
 
+    counts = []
+
     def block(on):
         replay.ENABLED = on
         for _ in range(3):
@@ -67,6 +69,7 @@ def main():
         opt.join()
         e.record()
         torch.cuda.synchronize()
+        counts.append((on, replay.STATS['replayed_F']))
         return s.elapsed_time(e) / args.steps, host
 
     replay.ENABLED = True
@@ -75,6 +78,7 @@ def main():
     opt.join()
     torch.cuda.synchronize()
     res = {True: [], False: []}
+    counts.clear()
     for b in range(args.blocks):
         for on in (True, False):
             res[on].append(block(on))
@@ -85,6 +89,7 @@ def main():
         print('%-8s ms/step %s  (mean %.3f)   host enqueue ms/step %s (mean %.3f)' % (
             'replay' if on else 'eager', ' '.join('%.3f' % v for v in ms), sum(ms) / len(ms), ' '.join('%.2f' % v for v in host),
             sum(host) / len(host)))
+    print('replayed forward passes after each block:', counts)
     print('replay state:', replay.report(model.engine()), replay.STATS)
 
 

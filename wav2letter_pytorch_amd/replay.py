@@ -66,7 +66,7 @@ from ._lib import check, lib, ptr
 
 ENABLED = os.environ.get('W2L_REPLAY', '1') != '0'
 WARM_STEPS = int(os.environ.get('W2L_REPLAY_WARM', '2'))          # eager steps of a shape before it is recorded
-MAX_GROUPS = int(os.environ.get('W2L_REPLAY_MAX_SHAPES', '4'))    # step shapes kept recorded per engine (least recently used out)
+MAX_GROUPS = int(os.environ.get('W2L_REPLAY_MAX_SHAPES', '8'))    # step shapes kept recorded per engine (least recently used out)
 MAX_FAILURES = 3
 FP8_EAGER_EVERY = 256           # fp8 mode: replayed steps between two eager stretches (the e4m3 weight-scale upkeep lives there)
 FP8_EAGER_STEPS = 10
@@ -172,6 +172,7 @@ class StepReplayer:
         self.clock = 0
         self.after_replayed_O = False                 # an eager phase must first wait for the optimizer's stream
         self.opt_stream = None
+        self.first_seen = {}                          # step shapes seen so far that have no group yet -> how often
 
     # ------------------------------------------------------------------ eligibility
     def _mode_flags(self):
@@ -199,12 +200,26 @@ class StepReplayer:
         self.clock += 1
         g = self.groups.get(key)
         if g is None:
+            # a shape gets a group (and with it, once warm, two sets of static buffers) only after it has COME BACK: with
+            # variable-length batches most shapes are seen once, and must neither cost a recording nor push a hot shape out
+            n = self.first_seen.get(key, 0) + 1
+            if len(self.first_seen) > 4096:
+                self.first_seen.clear()
+            self.first_seen[key] = n
+            if n <= WARM_STEPS:
+                return None
             if len(self.groups) >= MAX_GROUPS:
                 victim = min(self.groups.values(), key=lambda v: v.last_use)
-                if self.pending is not None and self.pending.group() is victim:
-                    return None                        # (its held-back gradients are still to be launched: keep it this step)
+                if (self.pending is not None and self.pending.group() is victim) or self.clock - victim.last_use < 4 * MAX_GROUPS:
+                    return None                        # (every recorded shape is in recent use: this one stays eager)
                 del self.groups[victim.key]
+            free, total = torch.cuda.mem_get_info(x.device)
+            if free < 0.2 * total:                     # static buffers double a step's activations: not on a nearly full device
+                return None
             g = self.groups[key] = Group(key)
+            g.seen = WARM_STEPS
+            g.tune_sig = (len(E._tuned_shapes), len(E._wgroup_forms), len(E._wgroup_plans))
+            g.fp8_epoch = E._fp8_epoch[0]
         g.last_use = self.clock
         if g.disabled is not None:
             return None
@@ -459,6 +474,7 @@ def _record_forward(rp, engine, rset, x, lens, softmax_mode):
     pool = rset.ensure_pool()
     n_drop = len(engine.units) + 1
     counter = rp.sync_counter(x.device, n_drop)
+    tune0 = (len(E._tuned_shapes), len(E._wgroup_forms))
     with torch.cuda.use_mem_pool(pool):
         rset.x_static = torch.empty_like(x)
         rset.x_static.copy_(x)
@@ -480,6 +496,8 @@ def _record_forward(rp, engine, rset, x, lens, softmax_mode):
             engine._lens_static = None
     ph = rec.finish()
     rset.ectx, rset.out, rset.lens_out = ectx, out, ectx['lens_out']
+    if ph is not None and tune0 != (len(E._tuned_shapes), len(E._wgroup_forms)):
+        ph, rec.poisoned = None, 'kernel plans were measured during the step'
     if ph is None:
         why = rec.poisoned
         # this step still completes eagerly: its context is whole, only the list is dropped
@@ -498,7 +516,9 @@ def _assign_grads(rset):
 
 
 def _record_backward(rp, engine, rset, g):
+    from . import engine as E
     pool = rset.ensure_pool()
+    tune0 = (len(E._tuned_shapes), len(E._wgroup_forms))
     with torch.cuda.use_mem_pool(pool):
         rset.g_static = torch.empty(g.shape, dtype=torch.float32, device=g.device)
         rset.g_static.copy_(g)
@@ -507,6 +527,8 @@ def _record_backward(rp, engine, rset, g):
     ph = rec.finish() if rset.F is not None else None
     params = engine.parameters()
     why = rec.poisoned
+    if ph is not None and tune0 != (len(E._tuned_shapes), len(E._wgroup_forms)):
+        ph, why = None, 'kernel plans were measured during the step'
     fixed = []
     for p, gr in zip(params, grads):
         # autograd stores a gradient whose strides are not the parameter's (the sliced dW of a padded channel count) as a copy
