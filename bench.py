@@ -164,14 +164,17 @@ def live_traffic(E, kernel, timeout_s=170):
     try:
         cache = os.path.join(tmp, 'tune.txt')
         E.save_tune_cache(cache)
-        env = dict(os.environ, W2L_TUNE_CACHE=cache, TMPDIR='/tmp')
+        # (the counted launches are the same kernels with the same plans whichever way the step is driven: the child passes run
+        # the eager step, without the deferral A/B and the trainer legs, to stay short under the profiler)
+        env = dict(os.environ, W2L_TUNE_CACHE=cache, TMPDIR='/tmp', W2L_REPLAY='0')
         for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
             env.pop(k, None)
         vals = {}
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
             out = os.path.join(tmp, counter)
             cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', out, '--', sys.executable,
-                   os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-live-traffic']
+                   os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-live-traffic',
+                   '--no-trainer-leg', '--defer-wgrad', '4']
             r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
             if r.returncode != 0:
                 return None, f'rocprofv3 --pmc {counter} exited with {r.returncode}'

@@ -589,7 +589,7 @@ def test_training_step_async_metrics_equal_synchronous(kind, monkeypatch):
         assert set(a) >= keys and set(b) >= keys
         for k in keys:
             assert a[k] == b[k], (k, a[k], b[k])
-    # and without the explicit resolve: the hook alone never leaves more than one batch outstanding, an epoch end none
+    # and without the explicit resolve: the hook alone never leaves more than METRICS_MAX_PENDING batches outstanding, an epoch end none
     model.async_metrics = True
     for i in range(4):
         opt.zero_grad(set_to_none=True)
@@ -597,7 +597,7 @@ def test_training_step_async_metrics_equal_synchronous(kind, monkeypatch):
         loss.backward()
         opt.step()
         model.on_train_batch_end(loss, batches[i % 3], i)
-        assert len(model._pending_metrics) <= 1
+        assert len(model._pending_metrics) <= model.METRICS_MAX_PENDING
     model.on_train_epoch_end()
     assert not model._pending_metrics
     opt.join()

@@ -75,5 +75,26 @@ def main():
               f'finalize {t_z:6.1f} us  apply {t_a:7.1f} us ({el * 6 / t_a / 1e6:5.2f} TB/s)')
 
 
+def sgd_pack():
+    """w2l_sgd_pack alone on the table's layer shapes: 24 B per parameter (read p, g, m; write p, m, two bf16 operands).  In the
+    step it runs on the optimizer's stream under the next forward pass, beside MFMA-bound convolutions -- where a rocprofv3 trace
+    shows 2.0 (serial-wgrad profile: beside the forward) to 3.5 TB/s (default profile) for the same kernel."""
+    st = L.stream_ptr()
+    print('w2l_sgd_pack alone (no other kernel on the chip):')
+    total_b = total_t = 0.0
+    for cin, cout, kw, mult in [(256, 256, 11, 3), (384, 384, 13, 2), (512, 512, 17, 2), (640, 640, 21, 2), (768, 768, 25, 2), (896, 896, 29, 2)]:
+        p, g, m = (torch.randn(kw, cout, cin, device='cuda') for _ in range(3))
+        fwd = torch.empty(kw, cout, cin, dtype=torch.bfloat16, device='cuda')
+        dgr = torch.empty(kw, cin, cout, dtype=torch.bfloat16, device='cuda')
+        t = timeit(lambda: L.check(L.lib.w2l_sgd_pack(L.ptr(p), L.ptr(g), L.ptr(m), 0, 1e-5, 0.9, 1e-5, 1, 0, cout, cin, kw, L.ptr(fwd), None,
+                                                      L.ptr(dgr), None, None, None, 1.0, st)))
+        b = cin * cout * kw * 24
+        total_b += b * mult
+        total_t += t * mult
+        print(f'  {cin:4d} -> {cout:4d} k{kw:2d}: {t:7.1f} us  {b / t / 1e6:5.2f} TB/s   ({b / 1e6:6.1f} MB)')
+    print(f'  these 13 layers: {total_t / 1e3:.3f} ms for {total_b / 1e9:.2f} GB = {total_b / total_t / 1e6:.2f} TB/s')
+
+
 if __name__ == '__main__':
     main()
+    sgd_pack()

@@ -3,8 +3,8 @@
 # copied into profiles/ with the round prefix by hand -- delete the local gpurun_out/final first (gpurun MERGES: files of older
 # runs stay there): `rm -rf gpurun_out/final; gpurun ... bash tools/make_profiles.sh; for f in gpurun_out/final/*; do cp $f profiles/r03_$(basename $f); done`).
 # Stages are independent: a failing one leaves its file empty, the others still run.
-# Three stages (a gpurun call is limited to 20 minutes): `bash tools/make_profiles.sh headline`, `... kernels`, `... workloads`
-# (no argument: all three); each writes its own files under gpurun_out/final/.
+# Four stages (a gpurun call is limited to 20 minutes): `bash tools/make_profiles.sh headline`, `... kernels`, `... workloads`,
+# `... replay` (no argument: all four); each writes its own files under gpurun_out/final/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/final
 mkdir -p $OUT
@@ -80,5 +80,24 @@ W2L_DP_NATIVE=1 python3 bench.py --force-dp --early-collective --steps 20 --warm
 python3 tools/stream_map.py 12 2>/dev/null > $OUT/stream_map.txt
 python3 tools/bench_features.py 2>/dev/null | last > $OUT/bench_features.txt
 python3 bench.py --ragged --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | last > $OUT/bench_ragged.json
+fi
+if [ "$STAGE" = replay ] || [ "$STAGE" = all ]; then
+# ---- round 6: the reference's loop body and the recorded launch lists
+# host lead / host ms per step (bench.py --lead-trace: last column pair), replayed and eager, headline and Jasper 10x5
+python3 bench.py --lead-trace --steps 12 --warmup 8 --no-cpu-baseline 2> $OUT/lead_trace.txt > /dev/null
+W2L_REPLAY=0 python3 bench.py --lead-trace --steps 12 --warmup 8 --no-cpu-baseline 2> $OUT/lead_trace_eager.txt > /dev/null
+python3 bench.py --model jasper10x5 --batch 16 --lead-trace --steps 12 --warmup 8 --no-cpu-baseline 2> $OUT/lead_trace_jasper10x5.txt > /dev/null
+W2L_REPLAY=0 python3 bench.py --model jasper10x5 --batch 16 --lead-trace --steps 12 --warmup 8 --no-cpu-baseline 2> $OUT/lead_trace_jasper10x5_eager.txt > /dev/null
+# replayed vs eager steps interleaved in one process: device ms per step and host enqueue ms per step
+for cfg in "" "--batch 8" "--batch 16" "--mid-layers 1" "--model jasper10x5 --batch 16" "--model jasper10x5 --batch 16 --dtype fp8" "--dtype fp8"; do
+  echo "== tools/replay_ab.py $cfg"; python3 tools/replay_ab.py $cfg 2>/dev/null | head -3
+done > $OUT/replay_ab.txt
+# the timed region through training_step (host batch, per-step greedy decode + CER / WER): value / ms_per_step ARE the trainer's
+python3 bench.py --through-trainer --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic 2>/dev/null | last > $OUT/bench_through_trainer.json
+python3 bench.py --through-trainer --model jasper10x5 --batch 16 --steps 10 --warmup 4 --no-cpu-baseline 2>/dev/null | last > $OUT/bench_through_trainer_jasper10x5.json
+python3 bench.py --through-trainer --model jasper10x5 --batch 16 --dtype fp8 --steps 10 --warmup 4 --no-cpu-baseline 2>/dev/null | last > $OUT/bench_through_trainer_jasper10x5_fp8.json
+# SURVEY 8d's other CPU-baseline legs: the shipped default mid_layers: 1 at N = 32, Jasper at N = 2 (cpu_baseline of each line)
+python3 bench.py --mid-layers 1 --steps 20 --warmup 5 2>/dev/null | last > $OUT/bench_w2l_mid1_cpu_baseline.json
+python3 bench.py --model jasper10x5 --batch 16 --steps 6 --warmup 4 --no-trainer-leg 2>/dev/null | last > $OUT/bench_jasper10x5_cpu_baseline.json
 fi
 ls $OUT | head -80

@@ -42,6 +42,17 @@ except ImportError:  # pragma: no cover - exercised in this image
 
 EXAMPLE_BATCH, EXAMPLE_FRAMES = 4, (100, 200)         # base_asr_models.py:27-31
 
+_SCORING = []
+
+
+def _scoring_pool():
+    """the scoring threads of the process: greedy collapse + CER / WER of the batches training_step enqueued"""
+    if not _SCORING:
+        from concurrent.futures import ThreadPoolExecutor
+        # (jobs are independent and are harvested in submission order; the C call in each holds no interpreter lock)
+        _SCORING.append(ThreadPoolExecutor(max_workers=max(1, min(4, (os.cpu_count() or 2) // 2)), thread_name_prefix='w2l-metrics'))
+    return _SCORING[0]
+
 
 def _nothing():
     return None
@@ -152,11 +163,11 @@ class ConvCTCASR(_Base):
     # argmax, 16 000 .item() calls, 64 Levenshtein runs -- with the GPU idle, because backward() is enqueued after it.  Here
     # the step only ENQUEUES what the metrics need -- the argmax kernel, one asynchronous copy of the int32 index matrix (and
     # of the loss scalar) into pinned host memory, an event -- and returns; the strings are scored when the event has fired,
-    # which is after backward() and the optimizer step have been enqueued (on_train_batch_end; the host part is ONE C call,
-    # decoder.GreedyDecoder.score_batch).  The logged values are the same numbers, bit for bit; they reach log_dict one
-    # hook later.  ``async_metrics = False`` (or W2L_SYNC_METRICS=1) restores the reference's order: score, log, then return.
+    # which is after backward() and the optimizer step have been enqueued: a worker thread waits for the event and makes ONE C
+    # call (decoder.GreedyDecoder.score_batch, no interpreter lock held), on_train_batch_end logs what has arrived.  The logged
+    # values are the same numbers, bit for bit; they reach log_dict one hook (or, while the scorer is busy, a few) later.  ``async_metrics = False`` (or W2L_SYNC_METRICS=1) restores the reference's order: score, log, then return.
     async_metrics = os.environ.get('W2L_SYNC_METRICS', '0') != '1'
-    METRICS_MAX_PENDING = 2          # batches whose metrics may be outstanding: the newest is never waited for
+    METRICS_MAX_PENDING = 4          # batches whose metrics may be outstanding before the enqueuing thread waits for the oldest
 
     def _score_indices(self, idx_host, sizes, texts, prefix) -> Dict[str, float]:
         """host part of add_string_metrics: argmax indices (on the host) -> the three logged ratios"""
@@ -202,27 +213,35 @@ class ConvCTCASR(_Base):
             sizes = host
         ev = torch.cuda.Event()
         ev.record()
+        # scored on the package's worker thread: it waits for the event (the copies have landed), then makes ONE C call that holds
+        # no interpreter lock (decoder.GreedyDecoder.score_batch) -- the thread that enqueues the step never waits for either
+        job = _scoring_pool().submit(self._score_job, ev, idx_host, sizes, tuple(texts), prefix)
         pend = self.__dict__.setdefault('_pending_metrics', [])
-        pend.append((ev, idx_host, loss_host, sizes, tuple(texts), prefix, dict(extra or {}), idx))
+        pend.append((job, loss_host, prefix, dict(extra or {}), idx))
         return ev
 
+    def _score_job(self, ev, idx_host, sizes, texts, prefix):
+        ev.synchronize()
+        return self._score_indices(idx_host, sizes, texts, prefix)
+
     def resolve_metrics(self, wait_all: bool = True) -> int:
-        """score and log the enqueued batches, oldest first.  ``wait_all``: block until every one is done (logging points,
-        epoch ends, validation); otherwise take what has already arrived and wait only for batches older than the newest
-        METRICS_MAX_PENDING - 1 (the host never runs further ahead than that).  Returns the number of batches logged."""
+        """log the enqueued batches, oldest first, as their scores arrive from the worker thread.  ``wait_all``: block until
+        every one is in (logging points, epoch ends, validation); otherwise take what is ready and wait only while more than
+        METRICS_MAX_PENDING batches are outstanding (the host never runs further ahead than that).  Returns the number of
+        batches logged."""
         pend = self.__dict__.get('_pending_metrics')
         done = 0
         while pend:
-            ev = pend[0][0]
-            if not wait_all and len(pend) < self.METRICS_MAX_PENDING and not ev.query():
+            job = pend[0][0]
+            if not wait_all and len(pend) <= self.METRICS_MAX_PENDING and not job.done():
                 break
-            ev.synchronize()
-            _, idx_host, loss_host, sizes, texts, prefix, extra, _idx = pend.pop(0)
+            metrics = job.result()                       # (re-raises whatever the scoring raised)
+            _, loss_host, prefix, extra, _idx = pend.pop(0)
             logs = {}
             if loss_host is not None:
                 logs[f'{prefix}_loss'] = float(loss_host[0])
             logs.update(extra)
-            logs.update(self._score_indices(idx_host, sizes, texts, prefix))
+            logs.update(metrics)
             self.log_dict(logs)
             done += 1
         return done
@@ -262,11 +281,27 @@ class ConvCTCASR(_Base):
                 ent[1].synchronize()               # the copy issued from this buffer two batches ago (long done)
             stage = ent[0][: inputs.numel()].view(inputs.shape)
             stage.copy_(inputs)
-            out = stage.to(dev, non_blocking=True)
-            ent[1] = torch.cuda.Event()
-            ent[1].record()
+            out, ent[1] = self._upload(stage, dev)
             return out
+        if inputs.device.type == 'cpu' and dev.type == 'cuda':
+            return self._upload(inputs, dev)[0]
         return inputs.to(dev, non_blocking=True)
+
+    def _upload(self, pinned, dev):
+        """page-locked host tensor -> device on a COPY STREAM of the module's own: the host enqueues step i + 1 while the GPU
+        still runs step i, so the 8 MB of the next batch cross PCIe under step i's kernels instead of in front of step i + 1's
+        first one (0.16 ms of an idle chip per step on the caller's stream); the caller's stream waits for the copy's event"""
+        st = self.__dict__.get('_copy_stream')
+        if st is None or st.device != dev:
+            st = self.__dict__['_copy_stream'] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(st):
+            out = pinned.to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        main.wait_event(ev)
+        out.record_stream(main)                # (allocated on the copy stream, consumed on the caller's)
+        return out, ev
 
     def _device_ints(self, dev, *tensors):
         """small host integer tensors of a batch (targets, lengths) -> int32 device tensors through ONE pinned buffer and one
