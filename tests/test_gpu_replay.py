@@ -191,6 +191,45 @@ def test_replay_draws_fresh_dropout_masks():
     assert max(tail) - min(tail) > 1e-4, losses
 
 
+def test_replay_fp8_eager_stretches_for_scale_upkeep(monkeypatch):
+    """fp8 mode keeps its e4m3 weight scales current in EAGER steps (amax request, adoption eight weight versions later): a replayed
+    run therefore drops to the eager step for a stretch every FP8_EAGER_EVERY replays, with the skipped versions added to every
+    weight's age.  With the period shrunk to 3 replays and the rescale interval to 8 versions the cycle runs several times in 30
+    steps: replays and eager stretches alternate, the loss keeps falling, requests are made and adopted."""
+    from wav2letter_pytorch_amd import engine as E, replay
+    from wav2letter_pytorch_amd.optim import FusedSGD
+    from oracle import w2l_oracle as O
+    monkeypatch.setattr(replay, 'FP8_EAGER_EVERY', 3)
+    monkeypatch.setattr(replay, 'FP8_EAGER_STEPS', 4)
+    monkeypatch.setattr(E, 'FP8_WEIGHT_RESCALE', 8)
+    monkeypatch.setattr(E, 'FP8_RESCALE_LAG', 2)
+    layers = [(128, 11, 2, 1, 0.0), (256, 13, 1, 1, 0.0), (128, 29, 1, 2, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=45)
+    x, il, tg, tl = O.synthetic_batch(8, 600, seed=46, s_lo=10, s_hi=40)
+    x, tg, tl = x.cuda(), tg.cuda(), tl.cuda()
+    model = build_w2l(layers, sd, 'fp8').cuda().train()
+    opt = FusedSGD.from_sgd(torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, nesterov=True))
+    opt.overlap = True
+    before = replay.STATS['replayed_F']
+    losses, replayed = [], []
+    for i in range(30):
+        opt.zero_grad(set_to_none=True)
+        out, ol = model(x, il)
+        loss = model.criterion(out.transpose(0, 1), tg, ol, tl)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        replayed.append(replay.STATS['replayed_F'] - before)
+    opt.join()
+    steps_replayed = [b - a for a, b in zip([0] + replayed[:-1], replayed)]
+    assert sum(steps_replayed) >= 6 and steps_replayed.count(0) >= 10, steps_replayed      # both kinds of step, repeatedly
+    runs = ''.join(str(v) for v in steps_replayed)
+    assert '1110' in runs and '01' in runs[8:], runs                                        # ... alternating
+    assert all(np.isfinite(losses)) and losses[-1] < 0.7 * losses[0], losses
+    w = list(model.conv1ds.children())[1].conv1.weight
+    assert w.__dict__['_w2l_fp8']['scale'] > 0
+
+
 def test_replay_fp8_and_eval_in_between():
     """fp8 mode replays too (e4m3 operands, device-side dy scales), and an evaluation-mode forward between training steps
     (validation) runs eagerly without disturbing the records"""

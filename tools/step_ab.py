@@ -94,6 +94,10 @@ def main():
             elif k == 'PROBE':
                 E.StackEngine._wgrad = (lambda self, *a, **kw: None) if 'nowgrad' in str(v) else real_wgrad
                 type(opt).step = (lambda self, closure=None: None) if 'nosgd' in str(v) else real_step
+                # a probe patches engine methods, which a recorded launch list neither sees nor is keyed on: probe variants run
+                # the eager step (same device time: tools/replay_ab.py), everything else the replayed one
+                from wav2letter_pytorch_amd import replay
+                replay.ENABLED = not str(v)
             elif k == 'DEFER':
                 opt.defer_wgrad(model, [int(t) for t in str(v).split('|')] if '|' in str(v) else int(v))
             else:

@@ -72,6 +72,10 @@ FP8_EAGER_EVERY = 256           # fp8 mode: replayed steps between two eager str
 FP8_EAGER_STEPS = 10
 VERBOSE = os.environ.get('W2L_REPLAY_VERBOSE', '0') == '1'
 LENS_RING = 4
+# reasons for dropping a recording that pass by themselves (one-time set-up, the periodic e4m3 scale upkeep, plans still being
+# measured): the shape is tried again after its warm steps, without counting towards MAX_FAILURES
+TRANSIENT = ('fp8 weight scale', 'kernel plans were measured', 'measuring launches', 'workspace grown', 'created', 'table built',
+             'momentum buffer')
 
 # the record set whose backward pass ran last on this process (a weak reference to its replayer + the set): how
 # optim.FusedSGD.step finds out that the gradients it is about to consume are a record's static buffers
@@ -268,9 +272,12 @@ class StepReplayer:
         s.reset()
         if g is None:
             return
-        g.failures += 1
         STATS['poisoned'].append(why)
         _say(f'recording dropped: {why}')
+        if any(t in why for t in TRANSIENT):
+            g.seen = 0                                 # something that passes by itself: warm steps again, then another try
+            return
+        g.failures += 1
         if g.failures >= MAX_FAILURES:
             g.disabled = why
             for t in g.sets:
