@@ -553,8 +553,8 @@ int w2l_pad_vec_f32(const float* src, int n, float* dst, int cp, float fill, voi
 int w2l_counter_add(void* counter_i64, int64_t delta, void* stream);
 int w2l_add_i64_multi(void* table_dev, int n, int64_t delta, void* stream);
 typedef struct { float* p; const float* g; float* m; int32_t n; int32_t pad_; } w2l_sgd_small_t;
-int w2l_sgd_small_multi(const w2l_sgd_small_t* items_dev, int nitems, float lr, float momentum, float weight_decay,
-                        int nesterov, void* stream);
+int w2l_sgd_small_multi(const w2l_sgd_small_t* items_dev, int nitems, int max_n /* the largest items[i].n */, float lr,
+                        float momentum, float weight_decay, int nesterov, void* stream);
 
 #ifdef __cplusplus
 }

@@ -233,6 +233,34 @@ print('dropin ok')
     assert out.returncode == 0 and 'dropin ok' in out.stdout, out.stderr[-3000:]
 
 
+def test_replay_table_matches_the_binding_and_rejects_bad_records():
+    """recorded launch lists, host side only (no launch): every replayable entry point of the library's table (w2l_replay_op /
+    w2l_replay_arity) has the arity the ctypes binding declares -- the recorder stores one slot per declared argument --, the
+    layout of w2l_call_t / w2l_slot_t is the header's (8-byte slots, 24 of them behind two int32), an empty list replays to 0,
+    and a record naming an unknown entry point or the wrong argument count is refused with its index (nothing is called)"""
+    import ctypes as C
+    from wav2letter_pytorch_amd import _lib
+    ops = _lib._replay_ops()
+    assert len(ops) >= 40 and 'w2l_conv1d_igemm_ws' in ops and 'w2l_event_record' in ops and 'w2l_sgd_small_multi' in ops
+    for name, (op, kinds) in ops.items():
+        assert _lib.lib.w2l_replay_arity(op) == len(_lib._SIGNATURES[name][1]) == len(kinds), name
+        assert _lib.lib.w2l_replay_op(name.encode()) == op
+    # host-only queries and the measuring entry points are NOT replayable: their results are recorded control flow
+    for name in ('w2l_wgrad_needs_zero_x', 'w2l_conv1d_igemm_tune_ws', 'w2l_bn_bwd_fast_ok', 'w2l_tune_save', 'w2l_greedy_score_host'):
+        assert _lib.lib.w2l_replay_op(name.encode()) == -1, name
+    assert C.sizeof(_lib.Slot) == 8 and C.sizeof(_lib.Call) == 8 + 8 * _lib.REPLAY_MAX_ARGS
+    failed = C.c_int(-1)
+    assert _lib.lib.w2l_replay(None, 0, C.byref(failed)) == 0
+    calls = (_lib.Call * 2)()
+    calls[0].op, calls[0].nargs = ops['w2l_conv_stats_mode'][0], 1          # a harmless host-state call: stats mode 0
+    calls[0].a[0].i = 0
+    calls[1].op, calls[1].nargs = 9999, 0
+    assert _lib.lib.w2l_replay(calls, 2, C.byref(failed)) != 0 and failed.value == 1
+    calls[1].op, calls[1].nargs = ops['w2l_fill_zero'][0], 2                # wrong arity (3 declared)
+    assert _lib.lib.w2l_replay(calls, 2, C.byref(failed)) != 0 and failed.value == 1
+    assert b'replay' in _lib.lib.w2l_last_error()
+
+
 def test_config_loader_hydra_tree(tmp_path):
     """defaults list, `# @package model` groups, ${a.b} interpolation, key=value and group overrides
     (the structure of configuration/config.yaml:1-28, rebuilt here from Python dicts)"""

@@ -163,7 +163,7 @@ _SIGNATURES = {
     'w2l_pad_vec_f32': (c_i, [c_p, c_i, c_p, c_i, c_f, c_p]),
     'w2l_counter_add': (c_i, [c_p, c_i64, c_p]),
     'w2l_add_i64_multi': (c_i, [c_p, c_i, c_i64, c_p]),
-    'w2l_sgd_small_multi': (c_i, [c_p, c_i, c_f, c_f, c_f, c_i, c_p]),
+    'w2l_sgd_small_multi': (c_i, [c_p, c_i, c_i, c_f, c_f, c_f, c_i, c_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

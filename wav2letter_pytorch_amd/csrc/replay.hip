@@ -91,9 +91,13 @@ __global__ void add_i64_multi_kernel(long long* const* table, int n, long long d
 }
 // torch.optim.SGD's update of one small parameter (bias, BatchNorm gamma / beta) per block: g' = g + wd p;
 // m = mu m + g' (dampening 0);  p -= lr (nesterov ? g' + mu m : m)
+// grid = (items, chunks of SGD_SMALL_CHUNK elements): most items are one chunk (a few hundred channels); the classifier weight
+// (29 x 1024) is fifteen -- one block walking it alone took 96 us on the caller's stream at every step boundary
+constexpr int SGD_SMALL_CHUNK = 2048;
 __global__ __launch_bounds__(256) void sgd_small_multi_kernel(const w2l_sgd_small_t* items, float lr, float mu, float wd, int nesterov) {
     const w2l_sgd_small_t it = items[blockIdx.x];
-    for (int i = threadIdx.x; i < it.n; i += 256) {
+    const int lo = blockIdx.y * SGD_SMALL_CHUNK, hi = min(it.n, lo + SGD_SMALL_CHUNK);
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
         float pv = it.p[i];
         float gv = it.g[i];
         if (wd != 0.f) gv += wd * pv;
@@ -129,12 +133,14 @@ extern "C" int w2l_add_i64_multi(void* table_dev, int n, int64_t delta, void* st
     W2L_CHECK_LAUNCH();
     return 0;
 }
-extern "C" int w2l_sgd_small_multi(const w2l_sgd_small_t* items_dev, int nitems, float lr, float momentum, float weight_decay,
-                                   int nesterov, void* stream) {
+extern "C" int w2l_sgd_small_multi(const w2l_sgd_small_t* items_dev, int nitems, int max_n, float lr, float momentum,
+                                   float weight_decay, int nesterov, void* stream) {
     W2L_CHECK_ARG(items_dev != nullptr || nitems == 0, "sgd_small_multi: null table");
-    if (nitems <= 0) return 0;
-    hipLaunchKernelGGL(sgd_small_multi_kernel, dim3(nitems), dim3(256), 0, (hipStream_t)stream, items_dev, lr, momentum, weight_decay,
-                       nesterov);
+    W2L_CHECK_ARG(max_n >= 0 && max_n <= (1 << 26), "sgd_small_multi: max_n (the largest item's element count) out of range");
+    if (nitems <= 0 || max_n == 0) return 0;
+    const int chunks = (max_n + SGD_SMALL_CHUNK - 1) / SGD_SMALL_CHUNK;
+    hipLaunchKernelGGL(sgd_small_multi_kernel, dim3(nitems, chunks), dim3(256), 0, (hipStream_t)stream, items_dev, lr, momentum,
+                       weight_decay, nesterov);
     W2L_CHECK_LAUNCH();
     return 0;
 }

@@ -294,8 +294,8 @@ class FusedSGD(torch.optim.SGD):
             for pp, gp, mp, n in rows:
                 flat += [pp, gp, mp, n]                    # w2l_sgd_small_t: three pointers, then {int32 n, int32 pad} = one int64 < 2^31
             table = cache[key] = torch.tensor(flat, dtype=torch.int64).to(params[0].device)
-        check(lib.w2l_sgd_small_multi(ptr(table), len(rows), float(lr), float(mu), float(wd), int(nesterov), stream_ptr()),
-              'w2l_sgd_small_multi')
+        check(lib.w2l_sgd_small_multi(ptr(table), len(rows), max(r[3] for r in rows), float(lr), float(mu), float(wd), int(nesterov),
+                                      stream_ptr()), 'w2l_sgd_small_multi')
         for p in params:
             torch.autograd.graph.increment_version(p)
         return True
