@@ -42,7 +42,10 @@ def _bf16_grad_bound(key, n):
 # amplifies the difference) and travels down unchanged; the classifier's own gradient is at 0.006.  (Carrying the
 # classifier's data gradient in fp32 with a hi + lo split of softmax - posterior was measured: no change -- the source is
 # the forward deviation, not a backward rounding.)
-BF16_N32_GRAD_L2, BF16_N32_GRAD_COS = 0.14, 0.991
+# Round 6: the figures move with the dropout REALISATION (Philox seed and offsets, i.e. with whatever ran before in the process):
+# L2 0.083-0.108 / cosine 0.9942-0.9966 for the test on its own, 0.113-0.137 / 0.9907-0.9935 behind the rest of the suite.  The test
+# now pins seed and offset; the bounds keep room for both populations.
+BF16_N32_GRAD_L2, BF16_N32_GRAD_COS = 0.15, 0.9885
 
 
 def _report(title, errs):
@@ -115,6 +118,8 @@ def test_w2l_full_table_N32_bench_workload_bf16():
     sd = O.init_wav2letter_state(layers, seed=0)
     model = build_w2l(layers, sd, 'bf16', dropout=True).train()
     x, il, tg, tl = O.synthetic_batch(32, 1000, seed=1234)
+    torch.manual_seed(20261005)         # (the masks are a function of torch's seed and the engine's draw counter: pinned, so that the
+    E._dropout_calls = 0                # comparison below does not depend on which tests ran before this one)
     start = E._dropout_calls
     out, out_lens, loss, ectx = device_step(model, x, il, tg, tl)
     assert out.shape == (32, 500, 29) and torch.isfinite(out).all()
