@@ -325,6 +325,54 @@ def test_deferred_weight_gradients_match_plain_sgd(k, monkeypatch):
     assert ma.engine().defer_wgrad == 0
 
 
+@pytest.mark.parametrize('spread', ['even', 'la:1', 'la:2'])
+def test_deferred_weight_gradients_spread_over_the_forward(spread, monkeypatch):
+    """W2L_DEFER_SPREAD other than the default 'start': the held-back weight gradients are launched in front of later units of the
+    forward pass (flush_deferred(pos=ui): 'even' = spread over the units in front of the first deferred layer, 'la:K' = K units ahead
+    of the layer whose update it carries).  Five steps with the top three of six units deferred must end on the parameters of the
+    same run with everything launched at the start -- every update still lands before its layer's forward convolution."""
+    from oracle import w2l_oracle as O
+    from wav2letter_pytorch_amd import engine as E
+    from wav2letter_pytorch_amd.optim import FusedSGD
+    _bit_reproducible_engine(monkeypatch)
+    monkeypatch.setattr(E, 'DETERMINISTIC_WGRAD', True)
+    layers = [(128, 11, 2, 1, 0.0), (128, 13, 1, 2, 0.0), (128, 5, 1, 1, 0.0), (192, 5, 1, 1, 0.0), (128, 7, 1, 1, 0.0),
+              (128, 3, 1, 1, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=15)
+    x, il, tg, tl = O.synthetic_batch(2, 160, seed=12, s_lo=5, s_hi=15)
+    res = {}
+    for mode in ('start', spread):
+        monkeypatch.setattr(E, 'DEFER_SPREAD', mode)
+        m = build_w2l(layers, sd, 'bf16').train()
+        o = FusedSGD.from_sgd(torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-3))
+        o.overlap = True
+        o.defer_wgrad(m, 3)
+        launched_at = []
+        real = E.StackEngine.flush_deferred
+
+        def spy(self, pos=None, _real=real):
+            before = len(self._deferred)
+            _real(self, pos)
+            if before != len(self._deferred):
+                launched_at.append(pos)
+
+        monkeypatch.setattr(E.StackEngine, 'flush_deferred', spy)
+        for it in range(5):
+            o.zero_grad(set_to_none=True)
+            out, ol = m(x.cuda(), il)
+            m.criterion(out.transpose(0, 1), tg, ol, tl).backward()
+            assert len(m.engine()._deferred) == 3
+            o.step()
+        o.join()
+        monkeypatch.setattr(E.StackEngine, 'flush_deferred', real)
+        torch.cuda.synchronize()
+        res[mode] = ({k: v.detach().cpu().numpy().copy() for k, v in m.named_parameters()}, launched_at)
+    assert set(p for p in res['start'][1] if p is not None) == {0}
+    assert any(p not in (0, None) for p in res[spread][1]), res[spread][1]          # something really was launched mid-forward
+    for k, v in res['start'][0].items():
+        assert np.array_equal(v, res[spread][0][k]), k
+
+
 def test_deferred_weight_gradients_skipped_step_and_double_backward(monkeypatch):
     """the two ways a held-back gradient could leak (round-4 advisor finding): (1) backward, NO step (a non-finite-loss guard),
     optimizer.zero_grad(), next batch: the skipped batch's top-layer gradients must be gone -- zero_grad drops them --, not
