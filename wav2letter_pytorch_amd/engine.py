@@ -1164,16 +1164,27 @@ class StackEngine:
         for uc in ctx['units']:
             if uc.unit.main.has_bn or (uc.unit.res is not None and uc.unit.res.has_bn):
                 pool_elems += 4 * acts[uc.out_index].CP
-        small_pool = zeros(pool_elems, torch.float32, dev)       # rows of absent residual branches stay 0
-        pool_off = 0
-        # the two-launch BatchNorm-backward chain (FAST_BN_BWD): STAT_SLOTS zero rows per plain unit, ONE fill per step; the
-        # data gradients that form the sums in their epilogue (w2l_conv1d_dgrad_bnreduce_ws) add onto the same rows
-        # (w2l_conv_stats_mode: thread-local, this -- the autograd -- thread's launches)
-        self._slot_pool = None
+        # the two-launch BatchNorm-backward chain (FAST_BN_BWD): STAT_SLOTS zero rows per plain unit; the data gradients that form
+        # the sums in their epilogue (w2l_conv1d_dgrad_bnreduce_ws) add onto the same rows (w2l_conv_stats_mode: thread-local,
+        # this -- the autograd -- thread's launches)
+        slot_need = 0
         if FAST_BN_BWD and not DETERMINISTIC_WGRAD and batch_stats and not self.precise and dev.type == 'cuda':
-            need = sum(STAT_SLOTS * 2 * acts[uc.out_index].CP for uc in ctx['units'] if uc.unit.main.has_bn and uc.unit.res is None)
-            if need:
-                self._slot_pool = [zeros(need, torch.float32, dev), 0, {}]
+            slot_need = sum(STAT_SLOTS * 2 * acts[uc.out_index].CP for uc in ctx['units'] if uc.unit.main.has_bn and uc.unit.res is None)
+        # the identically-zero gradients of conv biases in front of batch-statistics BatchNorm (_zeros)
+        bias_need = 0
+        if batch_stats:
+            for u in self.units:
+                for c in (u.main, u.res):
+                    if c is not None and c.bias is not None and c.has_bn:
+                        bias_need += roundup(c.cout, 64)
+        # ONE zero-filled buffer (one fill launch on the caller's stream at the head of the backward pass, not three): the
+        # per-channel gradient pool first -- a data-parallel run averages exactly that slice --, then the slot rows, then the
+        # zero bias gradients
+        zbuf = zeros(pool_elems + slot_need + bias_need, torch.float32, dev)
+        small_pool = zbuf[:pool_elems]                           # rows of absent residual branches stay 0
+        pool_off = 0
+        self._slot_pool = [zbuf[pool_elems: pool_elems + slot_need], 0, {}] if slot_need else None
+        self._zero_pool = [zbuf[pool_elems + slot_need:], 0] if bias_need else None
         lib.w2l_conv_stats_mode(STAT_SLOTS if self._slot_pool is not None else 0)
         lib.w2l_wgrad_deterministic(int(DETERMINISTIC_WGRAD))
         act_grads: List[List[tuple]] = [[] for _ in acts]

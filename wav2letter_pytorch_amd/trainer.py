@@ -106,6 +106,13 @@ class Trainer:
             k = int(os.environ.get('W2L_DEFER_WGRAD', min(4, n_units // 4)))
             if k and hasattr(opt, 'defer_wgrad'):
                 opt.defer_wgrad(model, k)
+        from . import engine as _E, replay as _replay
+        self._say('wav2letter_pytorch_amd: '
+                  + ('bit-reproducible step (W2L_DETERMINISTIC=1)' if _E.DETERMINISTIC_WGRAD else
+                     'default step: fp32 atomics in split reductions, not bit-reproducible from run to run (W2L_DETERMINISTIC=1: +0.6 %)')
+                  + ('; warm step shapes are replayed from recorded launch lists (W2L_REPLAY=0: eager)' if _replay.ENABLED else
+                     '; eager step (W2L_REPLAY=0)')
+                  + ('; string metrics scored behind backward()' if getattr(model, 'async_metrics', False) else ''))
         done = self.max_steps is not None and self.global_step >= self.max_steps
         for epoch in range(first_epoch, self.max_epochs):
             if done:
