@@ -152,7 +152,6 @@ class Group:
         self.seen = 0
         self.failures = 0
         self.disabled = None
-        self.tune_sig = None
         self.fp8_epoch = None
         self.replays = 0
         self.eager_left = 0
@@ -222,16 +221,14 @@ class StepReplayer:
                 return None
             g = self.groups[key] = Group(key)
             g.seen = WARM_STEPS
-            g.tune_sig = (len(E._tuned_shapes), len(E._wgroup_forms), len(E._wgroup_plans))
             g.fp8_epoch = E._fp8_epoch[0]
         g.last_use = self.clock
         if g.disabled is not None:
             return None
-        tune_sig = (len(E._tuned_shapes), len(E._wgroup_forms), len(E._wgroup_plans))
-        if tune_sig != g.tune_sig:                     # kernel plans were still being measured: the shape is not warm yet
-            g.tune_sig = tune_sig
-            g.seen = 0
-            self._drop(g)
+        # (kernel plans: a step that measured any -- its own first steps -- is not recorded, _record_forward / _record_backward
+        # check the plan tables around the step; plans measured for OTHER shapes later on change nothing a record names, so a
+        # growing table must not -- and does not -- invalidate the shapes already recorded: variable-length training keeps
+        # meeting new shapes)
         if g.fp8_epoch != E._fp8_epoch[0]:             # an e4m3 weight scale moved: recorded scales (by value) are stale
             g.fp8_epoch = E._fp8_epoch[0]
             self._drop(g)
