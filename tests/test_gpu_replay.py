@@ -97,6 +97,32 @@ def test_replayed_steps_equal_eager_steps_w2l(defer, monkeypatch):
         assert np.array_equal(pe[k], pr[k]), k
 
 
+def test_replay_several_batch_shapes_interleaved(monkeypatch):
+    """variable-length training: three batch shapes in rotation (plus one that shows up only twice).  Every recurring shape gets
+    its own pair of record sets once it has come back, a shape met for the first time -- or still measuring its kernel plans --
+    never disturbs the shapes already recorded, the one-off shape stays eager; same trajectory as the eager run, bit for bit."""
+    from oracle import w2l_oracle as O
+    _bit_reproducible(monkeypatch)
+    layers = [(128, 11, 2, 1, 0.0), (192, 13, 1, 1, 0.0), (128, 29, 1, 2, 0.0)]
+    sd = O.init_wav2letter_state(layers, seed=47)
+    shapes = [(4, 300), (3, 260), (2, 340)]
+    batches = []
+    for i in range(21):
+        n, t = shapes[i % 3] if i not in (7, 16) else (5, 220)
+        x, il, tg, tl = O.synthetic_batch(n, t, seed=300 + i, s_lo=8, s_hi=25)
+        batches.append((x.cuda(), il, tg.cuda(), tl.cuda()))
+    make = lambda: build_w2l(layers, sd, 'bf16')          # noqa: E731
+    le, pe, _, _ = _run(make, batches, 21, False, defer=1)
+    lr_, pr, st, rep = _run(make, batches, 21, True, defer=1)
+    recorded = [g for g in rep['shapes'] if all(s_['F'] and s_['B'] and s_['O'] for s_ in g['sets'])]
+    assert len(recorded) == 3 and sorted(tuple(g['input'][::2]) for g in recorded) == sorted(shapes), rep
+    assert not any(g['input'][0] == 5 for g in rep['shapes']), rep            # the one-off shape never got buffers
+    assert st['replayed_F'] >= 3 and st['poisoned'] == [], st
+    assert le == lr_, (le, lr_)
+    for k in pe:
+        assert np.array_equal(pe[k], pr[k]), k
+
+
 def test_replay_learning_rate_change_and_accumulation(monkeypatch):
     """the learning rate is a by-value argument of the recorded optimizer phase: a scheduler step must re-record it (same
     trajectory as eager); a backward pass that finds p.grad set (gradient accumulation) takes the eager backward on the record's
