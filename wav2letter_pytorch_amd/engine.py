@@ -1676,6 +1676,13 @@ class StackEngine:
         setting = WG.setting()
         if self.precise or self.fp8 or setting.strip().lower() in ('0', 'off', 'none') or not ctx['training']:
             return
+        # data parallel: a group's gradients reach the reducer when the WHOLE group's kernel is done -- the all-reduce of its
+        # first members starts up to two layers late.  Measured with one rank and the RCCL path forced (round 6, same box,
+        # communicator created first as in a real run): 13.10 / 13.14 ms with groups against 13.36 / 13.49 without -- the groups'
+        # gain outweighs the later start when nothing has to cross a link; W2L_WGRAD_GROUPS_DP=0 plans no groups while a reducer
+        # is attached (the switch to try on a real node if the exchange turns out exposed)
+        if self.grad_ready is not None and os.environ.get('W2L_WGRAD_GROUPS_DP', '1') == '0' and setting.strip().lower() in ('auto', '1', ''):
+            return
         acts: List[Act] = ctx['acts']
         N = ctx['out'].shape[0]
         convs, seq = [], []
