@@ -592,7 +592,8 @@ def main():
     reducer = getattr(model, 'grad_reducer', None)
     if reducer is not None and not args.graph:
         model.grad_reducer = None
-        k2 = max(2, min(args.steps, 10))
+        _replay_was, _replay.ENABLED = _replay.ENABLED, False      # the data-parallel step runs eagerly (its collectives are not
+        k2 = max(2, min(args.steps, 10))                            # entry points): so does the step it is compared with
         step()
         fence()
         t0 = time.perf_counter()
@@ -605,6 +606,7 @@ def main():
         exposed_by_rank = [round(v, 3) for v in gather_objects(dist, world, own)]
         exposed_comm_ms = max(exposed_by_rank)
         model.grad_reducer = reducer
+        _replay.ENABLED = _replay_was
         broadcast_parameters(model)                          # the replicas drifted apart while stepping alone
         # ---- when more than a tenth of the step is exposed communication: the same region once more with the large gradients
         # travelling as bf16 copies (half the bytes on every xGMI link; the average is then accurate to bf16's 8 bits, which is
