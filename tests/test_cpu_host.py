@@ -261,6 +261,46 @@ def test_replay_table_matches_the_binding_and_rejects_bad_records():
     assert b'replay' in _lib.lib.w2l_last_error()
 
 
+def test_recorder_records_and_replays_host_state_calls():
+    """the recorder itself, on the CPU: entry points that only move HOST state (w2l_conv_stats_mode, w2l_wgrad_deterministic)
+    are in the replay table like any launch, so recording and replaying them needs no device.  Checked: calls are executed
+    while recorded, land in C segments in call order, a Python callback splits the segments and is replayed in sequence, the
+    library's functions are restored when the recorder exits (also on an exception), a poisoned recording yields no phase,
+    and only one recorder can be active."""
+    from wav2letter_pytorch_amd import _lib
+    lib = _lib.lib
+    orig = lib.w2l_conv_stats_mode
+    seen = []
+    with _lib.Recorder() as rec:
+        assert _lib.recording() is rec and lib.w2l_conv_stats_mode is not orig
+        lib.w2l_conv_stats_mode(3)
+        lib.w2l_wgrad_deterministic(1)
+        rec.python(seen.append, 'callback')
+        lib.w2l_wgrad_deterministic(0)
+        lib.w2l_conv_stats_mode(0)
+        with pytest.raises(_lib.W2LError):
+            with _lib.Recorder():
+                pass
+    assert _lib.recording() is None and lib.w2l_conv_stats_mode is orig
+    phase = rec.finish()
+    assert phase is not None and phase.n_calls == 4 and [it[0] for it in phase.items] == ['c', 'py', 'c']
+    assert [phase.items[0][2], phase.items[2][2]] == [2, 2] and seen == ['callback']
+    ops = _lib._replay_ops()
+    first = phase.items[0][1]
+    assert first[0].op == ops['w2l_conv_stats_mode'][0] and first[0].a[0].i == 3 and first[1].a[0].i == 1
+    phase.replay()
+    phase.replay()
+    assert seen == ['callback'] * 3
+    with _lib.Recorder() as rec2:
+        lib.w2l_conv_stats_mode(0)
+        _lib.poison('a torch op between launches')
+    assert rec2.finish() is None and rec2.poisoned == 'a torch op between launches'
+    with pytest.raises(ZeroDivisionError):
+        with _lib.Recorder():
+            1 / 0
+    assert _lib.recording() is None and lib.w2l_conv_stats_mode is orig
+
+
 def test_config_loader_hydra_tree(tmp_path):
     """defaults list, `# @package model` groups, ${a.b} interpolation, key=value and group overrides
     (the structure of configuration/config.yaml:1-28, rebuilt here from Python dicts)"""
