@@ -13,6 +13,7 @@
 // third, fully parallel kernel turns alpha+beta into posteriors and the gradient.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -26,10 +27,14 @@ __device__ __forceinline__ float lse2(float a, float b) {
     if (m == NEG_INF) return NEG_INF;
     return m + __logf(__expf(a - m) + __expf(b - m));
 }
+// (one of the three terms is exp(0): with v_max3 / v_med3 / v_min3 -- one instruction each -- only the two smaller ones cost a
+// transcendental; the recursion is bound by the quarter-rate v_exp / v_log issue of its waves, see ctc_alpha_beta_kernel)
 __device__ __forceinline__ float lse3(float a, float b, float c) {
-    const float m = fmaxf(fmaxf(a, b), c);
+    const float m = __builtin_fmaxf(__builtin_fmaxf(a, b), c);
     if (m == NEG_INF) return NEG_INF;
-    return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+    const float lo = __builtin_fminf(__builtin_fminf(a, b), c);
+    const float md = __builtin_amdgcn_fmed3f(a, b, c);
+    return m + __logf(1.f + __expf(md - m) + __expf(lo - m));
 }
 
 // ---------------------------------------------------------------- softmax family
@@ -84,7 +89,7 @@ struct CtcParams {
     float* nll;                // [N]
 };
 
-// NT = block size (256, or 1024 for long transcripts), SPT = states per thread.  LP_LDS: the utterance's whole log-prob matrix (T x C fp32,
+// NT = block size (the states rounded up to whole waves, at most 1024), SPT = states per thread (1 up to 1024 states).  LP_LDS: the utterance's whole log-prob matrix (T x C fp32,
 // 58 KB at T'=500) is staged in LDS once, so a time step never waits on an L2 round trip; otherwise the
 // emissions are prefetched from global memory one step ahead (long utterances, T*C*4 > ~150 KB).
 template <int NT, int SPT, bool LP_LDS>
@@ -322,9 +327,18 @@ extern "C" int w2l_ctc_loss(const float* log_probs, const int32_t* targets, cons
     p.nll = nll;
     // one thread per extended-label state while 4 x 256 covers them (S <= 511: every utterance of <= ~40 s), else 1024
     // threads with up to 8 states each (S <= 4095: the T = 16 000 frame utterances of BASELINE config 5)
-    const int nt = L <= 4 * 256 ? 256 : 1024;
+    // One extended-label state per thread while a block can hold them (L <= 1024: every utterance of <= ~80 s), the block just
+    // wide enough in waves; beyond that 1024 threads with up to 8 states each (S <= 4095: the T = 16 000 frame utterances of
+    // BASELINE config 5).  Round 6 measured what bounds a time step: not the barrier or the LDS round trip but the waves'
+    // transcendental issue (v_exp / v_log at a quarter of the rate) -- fewer, fatter threads are slower in proportion (L = 321:
+    // 64 x 6 states 509 us, 128 x 3 320, 256 x 2 224, 384 x 1 156 for loss + gradient at N = 32, T' = 500), idle state slots
+    // cost like busy ones, and two waves per SIMD hide each other's latency.
+    static const int kWide[] = {64, 128, 192, 256, 320, 384, 448, 512, 640, 768, 896, 1024};
+    int nt = 1024;
+    for (int w : kWide)
+        if (L <= w) { nt = w; break; }
     int spt = (L + nt - 1) / nt;
-    if (nt == 1024) spt = spt <= 4 ? (spt < 2 ? 2 : spt) : (spt <= 6 ? 6 : 8);    // the instantiated variants
+    if (spt > 1) spt = spt <= 4 ? spt : (spt <= 6 ? 6 : 8);    // the instantiated variants of the 1024-thread form
     dim3 grid(N, 2), block(nt);
     size_t lds = 2 * (size_t)(spt * nt + 4) * sizeof(float);
     const size_t lp_bytes = (size_t)T * C * sizeof(float);
@@ -339,12 +353,20 @@ extern "C" int w2l_ctc_loss(const float* log_probs, const int32_t* targets, cons
             hipLaunchKernelGGL((ctc_alpha_beta_kernel<NT, SPT, false>), grid, block, lds, (hipStream_t)stream, p); \
         }                                                                                                    \
     } while (0)
-    if (nt == 256) {
-        switch (spt) {
-            case 1: W2L_CTC_LAUNCH(256, 1); break;
-            case 2: W2L_CTC_LAUNCH(256, 2); break;
-            case 3: W2L_CTC_LAUNCH(256, 3); break;
-            default: W2L_CTC_LAUNCH(256, 4); break;
+    if (spt == 1) {
+        switch (nt) {
+            case 64: W2L_CTC_LAUNCH(64, 1); break;
+            case 128: W2L_CTC_LAUNCH(128, 1); break;
+            case 192: W2L_CTC_LAUNCH(192, 1); break;
+            case 256: W2L_CTC_LAUNCH(256, 1); break;
+            case 320: W2L_CTC_LAUNCH(320, 1); break;
+            case 384: W2L_CTC_LAUNCH(384, 1); break;
+            case 448: W2L_CTC_LAUNCH(448, 1); break;
+            case 512: W2L_CTC_LAUNCH(512, 1); break;
+            case 640: W2L_CTC_LAUNCH(640, 1); break;
+            case 768: W2L_CTC_LAUNCH(768, 1); break;
+            case 896: W2L_CTC_LAUNCH(896, 1); break;
+            default: W2L_CTC_LAUNCH(1024, 1); break;
         }
     } else {
         switch (spt) {
