@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Fills the R6_* placeholders of DESIGN.md / README.md from the round's profile files (profiles/r06_*), so that every number
-in the prose is the one in the committed record.  Run after copying gpurun_out/final/* to profiles/r06_*."""
+in the prose is the one in the committed record.  Run after copying gpurun_out/final/* to profiles/r06_*.
+(One-shot: the templates with the R6_* markers are the DESIGN.md / README.md of commit "r06 profiles (final code); DESIGN / README
+drafts"; the files in the tree are its output.)"""
 import json
 import os
 import re
